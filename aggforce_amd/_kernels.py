@@ -1,0 +1,290 @@
+"""Thin Python wrappers over the libaggf C ABI, operating on torch (ROCm) tensors.
+
+torch is only the array container here (device memory, current stream); all
+arithmetic happens in the hand-written HIP kernels behind ``include/aggf.h``.
+"""
+from __future__ import annotations
+
+import contextlib
+import weakref
+from typing import Optional, Tuple
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import F32, F64, check, dtype_code, lib, ptr, stream_ptr, workspace
+
+_TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
+_NP_OF = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64)}
+
+# ------------------------------------------------------------------ containers
+
+_cache_stack: list = []
+
+
+@contextlib.contextmanager
+def upload_cache():
+    """Within this context a NumPy array is copied to the GPU at most once (keyed by identity)."""
+    _cache_stack.append({})
+    try:
+        yield
+    finally:
+        _cache_stack.pop()
+
+
+def is_torch(x) -> bool:
+    return isinstance(x, torch.Tensor)
+
+
+def default_device() -> torch.device:
+    lib()
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def as_device(x, dtype: Optional[torch.dtype] = None) -> torch.Tensor:
+    """NumPy array / CPU tensor / GPU tensor -> contiguous GPU tensor (float32 or float64)."""
+    if is_torch(x):
+        t = x
+        if t.dtype not in (torch.float32, torch.float64):
+            t = t.to(torch.float64)
+        if not t.is_cuda:
+            t = t.to(default_device())
+        if dtype is not None and t.dtype != dtype:
+            t = t.to(dtype)
+        return t.contiguous()
+    arr = np.asarray(x)
+    key = None
+    if _cache_stack and isinstance(x, np.ndarray):
+        key = (id(x), str(dtype))
+        hit = _cache_stack[-1].get(key)
+        if hit is not None and hit[0]() is x:
+            return hit[1]
+    if arr.dtype not in (np.float32, np.float64):
+        arr = arr.astype(np.float64)
+    t = torch.from_numpy(np.ascontiguousarray(arr)).to(default_device())
+    if dtype is not None and t.dtype != dtype:
+        t = t.to(dtype)
+    if key is not None:
+        _cache_stack[-1][key] = (weakref.ref(x), t)
+    return t
+
+
+def like_input(t: torch.Tensor, template):
+    """Return t as the same kind of container as template (NumPy array or torch tensor)."""
+    if is_torch(template):
+        return t if template.is_cuda else t.cpu()
+    return t.cpu().numpy()
+
+
+def np_dtype_of(x) -> np.dtype:
+    if is_torch(x):
+        return _NP_OF.get(x.dtype, np.dtype(np.float64))
+    return np.asarray(x).dtype if not isinstance(x, np.ndarray) else x.dtype
+
+
+def torch_dtype(npdt) -> torch.dtype:
+    return _TORCH_OF[np.dtype(npdt)]
+
+
+# ------------------------------------------------------------------ K1 Gram
+
+
+def gram(
+    forces: torch.Tensor,
+    grp_ptr: Optional[torch.Tensor],
+    grp_atoms: Optional[torch.Tensor],
+    n_red: int,
+    compute_dtype: torch.dtype,
+    out: Optional[torch.Tensor] = None,
+    accumulate: bool = False,
+    ws_limit_bytes: Optional[int] = None,
+) -> torch.Tensor:
+    """G (n_red, n_red) float64 from forces (T, N, 3); see aggf_gram in include/aggf.h."""
+    l = lib()
+    T, N, D = forces.shape
+    if D != 3:
+        raise ValueError("forces must have shape (n_frames, n_sites, 3)")
+    if T == 0:
+        raise ValueError("empty trajectory")
+    dev = forces.device
+    if out is None:
+        out = torch.empty((n_red, n_red), dtype=torch.float64, device=dev)
+        accumulate = False
+    ind, cd = dtype_code(forces.dtype), dtype_code(compute_dtype)
+    need = l.aggf_gram_workspace_bytes(T, N, n_red, ind, cd, 1 if grp_ptr is not None else 0)
+    if ws_limit_bytes is not None:
+        need = min(need, int(ws_limit_bytes))
+    ws = workspace(need, dev, "gram")
+    check(
+        l.aggf_gram(ptr(forces), T, N, ind, cd, ptr(grp_ptr), ptr(grp_atoms), n_red, ptr(out),
+                    1 if accumulate else 0, ptr(ws), need, stream_ptr()),
+        "aggf_gram",
+    )
+    return out
+
+
+# ------------------------------------------------------------------ K2 solve
+
+
+def eq_qp_solve(
+    G: torch.Tensor,
+    l2: float,
+    l2_diag: Optional[torch.Tensor],
+    A: torch.Tensor,
+    B: Optional[torch.Tensor] = None,
+    schur_reg: float = 0.0,
+    n_refine: int = 1,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """X (nrhs, n) and stats (4,) -- both on the device; see aggf_eq_qp_solve."""
+    l = lib()
+    n = G.shape[0]
+    m = A.shape[0]
+    nrhs = m if B is None else B.shape[1]
+    dev = G.device
+    X = torch.empty((nrhs, n), dtype=torch.float64, device=dev)
+    stats = torch.empty(4, dtype=torch.float64, device=dev)
+    need = l.aggf_eq_qp_workspace_bytes(n, m, nrhs)
+    ws = workspace(need, dev, "solve")
+    check(
+        l.aggf_eq_qp_solve(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), m, ptr(B), nrhs, float(schur_reg), int(n_refine), ptr(X), ptr(stats),
+                           ptr(ws), need, stream_ptr()),
+        "aggf_eq_qp_solve",
+    )
+    return X, stats
+
+
+def expand_map(X: torch.Tensor, group_of_atom: torch.Tensor, N: int) -> torch.Tensor:
+    l = lib()
+    n_rows, n_red = X.shape
+    W = torch.empty((n_rows, N), dtype=torch.float64, device=X.device)
+    check(l.aggf_expand_map(ptr(X), n_rows, n_red, ptr(group_of_atom), N, ptr(W), stream_ptr()), "aggf_expand_map")
+    return W
+
+
+# ------------------------------------------------------------------ K3 apply
+
+
+def linearmap_apply(
+    points: torch.Tensor,
+    matrix: torch.Tensor,
+    nan_fill: Optional[float] = None,
+    want_sumsq: bool = False,
+):
+    """out (T, n_cg, 3) in matrix.dtype; optional device scalar sum of squares."""
+    l = lib()
+    T, N, D = points.shape
+    n_cg, N2 = matrix.shape
+    if D != 3 or N2 != N:
+        raise ValueError(f"shape mismatch: points {tuple(points.shape)}, matrix {tuple(matrix.shape)}")
+    dev = points.device
+    out = torch.empty((T, n_cg, 3), dtype=matrix.dtype, device=dev)
+    if T == 0:
+        return (out, torch.zeros(1, dtype=torch.float64, device=dev)) if want_sumsq else out
+    sumsq = torch.empty(1, dtype=torch.float64, device=dev) if want_sumsq else None
+    need = l.aggf_linearmap_apply_workspace_bytes(T, N, n_cg) if want_sumsq else 0
+    ws = workspace(need, dev, "apply") if want_sumsq else None
+    check(
+        l.aggf_linearmap_apply(ptr(points), T, N, dtype_code(points.dtype), ptr(matrix), n_cg,
+                               dtype_code(matrix.dtype), _lib.NAN_REPLACE if nan_fill is not None else _lib.NAN_PROPAGATE,
+                               0.0 if nan_fill is None else float(nan_fill), ptr(out), ptr(sumsq), ptr(ws), need,
+                               stream_ptr()),
+        "aggf_linearmap_apply",
+    )
+    return (out, sumsq) if want_sumsq else out
+
+
+def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+    l = lib()
+    T, N, D = points.shape
+    n_cg = idx.numel()
+    out = torch.empty((T, n_cg, 3), dtype=out_dtype, device=points.device)
+    if T == 0:
+        return out
+    check(
+        l.aggf_slice_gather(ptr(points), T, N, dtype_code(points.dtype), ptr(idx), n_cg, dtype_code(out_dtype),
+                            ptr(out), stream_ptr()),
+        "aggf_slice_gather",
+    )
+    return out
+
+
+def has_nan(x: torch.Tensor) -> bool:
+    l = lib()
+    if x.numel() == 0:
+        return False
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    check(l.aggf_has_nan(ptr(x), x.numel(), dtype_code(x.dtype), ptr(flag), stream_ptr()), "aggf_has_nan")
+    return bool(flag.item())
+
+
+def allclose(a: torch.Tensor, b: torch.Tensor, rtol: float = 1e-5, atol: float = 1e-8) -> bool:
+    l = lib()
+    if a.numel() == 0:
+        return True
+    flag = torch.zeros(1, dtype=torch.int32, device=a.device)
+    check(
+        l.aggf_not_close(ptr(a), ptr(b), a.numel(), dtype_code(a.dtype), float(rtol), float(atol), ptr(flag),
+                         stream_ptr()),
+        "aggf_not_close",
+    )
+    return not bool(flag.item())
+
+
+def sumsq(x: torch.Tensor) -> torch.Tensor:
+    """Device scalar (shape (1,), float64): sum of squares of x, fixed summation order."""
+    l = lib()
+    out = torch.zeros(1, dtype=torch.float64, device=x.device)
+    if x.numel() == 0:
+        return out
+    need = l.aggf_sumsq_workspace_bytes()
+    ws = workspace(need, x.device, "sumsq")
+    check(l.aggf_sumsq(ptr(x), x.numel(), dtype_code(x.dtype), ptr(out), ptr(ws), need, stream_ptr()), "aggf_sumsq")
+    return out
+
+
+# ------------------------------------------------------------------ K5 augment
+
+
+def condnormal_augment(
+    coords: torch.Tensor,
+    forces: torch.Tensor,
+    matrix: torch.Tensor,
+    mean: torch.Tensor,
+    var: float,
+    kbt: float,
+    noise: Optional[torch.Tensor],
+    seed: int,
+    frame_offset: int,
+):
+    l = lib()
+    T, N, _ = coords.shape
+    n_cg = matrix.shape[0]
+    out_dtype = torch.promote_types(coords.dtype, matrix.dtype)
+    oc = torch.empty((T, N + n_cg, 3), dtype=out_dtype, device=coords.device)
+    of = torch.empty((T, N + n_cg, 3), dtype=out_dtype, device=coords.device)
+    if T == 0:
+        return oc, of
+    check(
+        l.aggf_condnormal_augment(ptr(coords), ptr(forces), T, N, dtype_code(coords.dtype), ptr(matrix), n_cg,
+                                  dtype_code(matrix.dtype), ptr(mean), ptr(noise), int(seed) & (2**64 - 1),
+                                  int(frame_offset), float(var), float(kbt), ptr(oc), ptr(of), stream_ptr()),
+        "aggf_condnormal_augment",
+    )
+    return oc, of
+
+
+# ------------------------------------------------------------------ synthetic data
+
+
+def synth_normal(T: int, N: int, dtype: torch.dtype, seed: int, frame_offset: int = 0, mean: float = 0.0,
+                 sigma: float = 1.0, lattice: float = 0.0, device=None) -> torch.Tensor:
+    l = lib()
+    dev = device or default_device()
+    out = torch.empty((T, N, 3), dtype=dtype, device=dev)
+    check(
+        l.aggf_synth_normal(ptr(out), T, N, dtype_code(dtype), int(seed), int(frame_offset), float(mean),
+                            float(sigma), float(lattice), stream_ptr()),
+        "aggf_synth_normal",
+    )
+    return out

@@ -1,0 +1,121 @@
+"""ctypes binding of libaggf.so (the C ABI declared in include/aggf.h).
+
+The library is the product's only compute path: there is no CPU fallback.  If
+``libaggf.so`` has not been built (``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C aggforce_amd/csrc``) every compute entry point raises ``RuntimeError``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libaggf.so")
+
+F32, F64 = 0, 1
+NAN_PROPAGATE, NAN_REPLACE = 0, 1
+
+_lib: Optional[C.CDLL] = None
+
+_vp, _i32, _i64, _u64, _dbl, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64, C.c_double, C.c_size_t
+
+# name -> (restype, argtypes); mirrors include/aggf.h one to one
+PROTOTYPES = {
+    "aggf_version": (C.c_int, []),
+    "aggf_last_error": (C.c_char_p, []),
+    "aggf_device_info": (C.c_int, [C.POINTER(_i32), C.POINTER(_sz), C.POINTER(_sz)]),
+    "aggf_gram_workspace_bytes": (_sz, [_i64, _i32, _i32, C.c_int, C.c_int, C.c_int]),
+    "aggf_gram": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _vp, _vp, _i32, _vp, C.c_int, _vp, _sz, _vp]),
+    "aggf_eq_qp_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "aggf_eq_qp_solve": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_expand_map": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
+    "aggf_linearmap_apply_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "aggf_linearmap_apply": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_slice_gather": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, _vp, _vp]),
+    "aggf_has_nan": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "aggf_not_close": (C.c_int, [_vp, _vp, _i64, C.c_int, _dbl, _dbl, _vp, _vp]),
+    "aggf_sumsq_workspace_bytes": (_sz, []),
+    "aggf_sumsq": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _sz, _vp]),
+    "aggf_condnormal_augment": (C.c_int, [_vp, _vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, _vp, _vp, _u64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
+    "aggf_synth_normal": (C.c_int, [_vp, _i64, _i32, C.c_int, _u64, _i64, _dbl, _dbl, _dbl, _vp]),
+}
+
+
+class AggfError(RuntimeError):
+    """A libaggf call returned an error code."""
+
+
+def load() -> C.CDLL:
+    """Load libaggf.so and set the prototypes (no GPU needed for this)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            f"libaggf.so not found at {LIB_PATH}: the HIP library is not built. "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` (or `make -C aggforce_amd/csrc`). "
+            "aggforce_amd has no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def lib() -> C.CDLL:
+    """The loaded library, for compute calls: also requires a visible GPU."""
+    l = load()
+    if not torch.cuda.is_available():
+        raise RuntimeError(
+            "aggforce_amd needs an AMD GPU (torch.cuda.is_available() is False); "
+            "there is no CPU fallback for the force-map hot path."
+        )
+    return l
+
+
+def check(rc: int, what: str = "") -> None:
+    if rc != 0:
+        msg = load().aggf_last_error()
+        raise AggfError(f"{what or 'libaggf'} failed (code {rc}): {msg.decode() if msg else ''}")
+
+
+def dtype_code(dt) -> int:
+    if dt in (torch.float32, np.float32) or (not isinstance(dt, torch.dtype) and np.dtype(dt) == np.float32):
+        return F32
+    if dt in (torch.float64, np.float64) or (not isinstance(dt, torch.dtype) and np.dtype(dt) == np.float64):
+        return F64
+    raise TypeError(f"unsupported dtype {dt}: libaggf computes in float32 or float64")
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+_ws_cache: dict = {}
+
+
+def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
+    """A cached uint8 scratch tensor of at least nbytes (256-byte aligned by the allocator)."""
+    key = (str(device), tag)
+    w = _ws_cache.get(key)
+    if w is None or w.numel() < nbytes:
+        _ws_cache.pop(key, None)
+        w = None
+        w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = w
+    return w
+
+
+def free_workspaces() -> None:
+    _ws_cache.clear()

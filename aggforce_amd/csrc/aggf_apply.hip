@@ -1,0 +1,304 @@
+// K3: LinearMap apply  out[t,c,d] = sum_a M[c,a] * P[t,a,d]  on MFMA, plus the one-hot
+// (slice map) gather.  Replaces util.trjdot (util.py:119-125) behind
+// LinearMap.__call__ (map/core.py:219-240) of the reference.
+//
+// One workgroup = 64 frames x 64 coarse-grained sites; the atom axis is the MFMA K
+// dimension, walked in chunks of 16 atoms.  Frame rows are staged in LDS as they lie
+// in HBM ((atom, xyz) interleaved); the three xyz components are three accumulator
+// sets fed from the same staged tile, so P is read exactly once per site block.
+#include "aggf_common.h"
+
+namespace aggf {
+
+constexpr int AP_TF = 64;   // frames per workgroup
+constexpr int AP_TC = 64;   // cg sites per workgroup
+constexpr int AP_KA = 16;   // atoms per stage
+constexpr int AP_XS = AP_KA * 3 + 2;  // LDS row stride of the P tile (elements)
+constexpr int AP_MS = AP_KA + 2;      // LDS row stride of the M tile
+constexpr int AP_THREADS = 256;
+
+template <typename TC>
+__device__ __forceinline__ TC fix_nan(TC v, bool replace, TC fill) {
+  return (replace && v != v) ? fill : v;
+}
+
+template <typename TIn, typename TC, bool NANREP>
+__global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
+    const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
+    int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
+    double* __restrict__ sumsq_partials) {
+  using MF = Mfma<TC>;
+  using acc_t = typename MF::acc_t;
+  constexpr int VI = 16 / sizeof(TIn);   // input elements per 16-byte chunk
+  constexpr int VM = 16 / sizeof(TC);
+  constexpr int P_CH_ROW = AP_KA * 3 / VI;                 // chunks per P tile row
+  constexpr int P_CH = P_CH_ROW * AP_TF;
+  constexpr int P_PER_THREAD = P_CH / AP_THREADS;
+  constexpr int M_CH_ROW = AP_KA / VM;
+  constexpr int M_CH = M_CH_ROW * AP_TC;
+  constexpr int M_PER_THREAD = M_CH / AP_THREADS;
+  static_assert(P_CH % AP_THREADS == 0 && M_CH % AP_THREADS == 0, "staging split");
+  constexpr int XBUF = AP_TF * AP_XS;
+  constexpr int MBUF = AP_TC * AP_MS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  TC* sX = reinterpret_cast<TC*>(smem_raw);     // [2][XBUF]
+  TC* sM = sX + 2 * XBUF;                       // [2][MBUF]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t bid = blockIdx.x;
+  const int cb = (int)(bid % ncb);
+  const int64_t fb = bid / ncb;
+  const int64_t t0 = fb * AP_TF;
+  const int c0 = cb * AP_TC;
+  const int64_t rowP = (int64_t)N * 3;
+  const int n_stage = (N + AP_KA - 1) / AP_KA;
+
+  TIn rp[P_PER_THREAD][VI];
+  TC rm[M_PER_THREAD][VM];
+
+  auto load_stage = [&](int s) {
+    const int a0 = s * AP_KA;
+#pragma unroll
+    for (int q = 0; q < P_PER_THREAD; ++q) {
+      const int c = tid + q * AP_THREADS;
+      const int r = c / P_CH_ROW, col = (c - r * P_CH_ROW) * VI;  // col in [0,48)
+      const int64_t t = t0 + r;
+      const int64_t e0 = (int64_t)a0 * 3 + col;                    // element in the frame row
+#pragma unroll
+      for (int e = 0; e < VI; ++e) rp[q][e] = 0;
+      if (t < T) {
+        const TIn* src = P + t * rowP + e0;
+        if (p_vec_ok && e0 + VI <= rowP) {
+          typedef TIn __attribute__((ext_vector_type(VI))) vin_t;
+          vin_t v = *reinterpret_cast<const vin_t*>(src);
+#pragma unroll
+          for (int e = 0; e < VI; ++e) rp[q][e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < VI; ++e)
+            if (e0 + e < rowP) rp[q][e] = src[e];
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < M_PER_THREAD; ++q) {
+      const int c = tid + q * AP_THREADS;
+      const int r = c / M_CH_ROW, col = (c - r * M_CH_ROW) * VM;
+      const int cg = c0 + r;
+      const int a = a0 + col;
+#pragma unroll
+      for (int e = 0; e < VM; ++e) rm[q][e] = 0;
+      if (cg < n_cg) {
+        const TC* src = Mx + (int64_t)cg * N + a;
+        if (m_vec_ok && a + VM <= N) {
+          typedef TC __attribute__((ext_vector_type(VM))) vm_t;
+          vm_t v = *reinterpret_cast<const vm_t*>(src);
+#pragma unroll
+          for (int e = 0; e < VM; ++e) rm[q][e] = v[e];
+        } else {
+#pragma unroll
+          for (int e = 0; e < VM; ++e)
+            if (a + e < N) rm[q][e] = src[e];
+        }
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    TC* x = sX + buf * XBUF;
+    TC* m = sM + buf * MBUF;
+#pragma unroll
+    for (int q = 0; q < P_PER_THREAD; ++q) {
+      const int c = tid + q * AP_THREADS;
+      const int r = c / P_CH_ROW, col = (c - r * P_CH_ROW) * VI;
+#pragma unroll
+      for (int e = 0; e < VI; ++e) x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[q][e], NANREP, nan_fill);
+    }
+#pragma unroll
+    for (int q = 0; q < M_PER_THREAD; ++q) {
+      const int c = tid + q * AP_THREADS;
+      const int r = c / M_CH_ROW, col = (c - r * M_CH_ROW) * VM;
+#pragma unroll
+      for (int e = 0; e < VM; ++e) m[r * AP_MS + col + e] = rm[q][e];
+    }
+  };
+
+  acc_t acc[4][3];
+#pragma unroll
+  for (int n = 0; n < 4; ++n)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) acc[n][d] = acc_zero<TC>();
+
+  const int offX = (16 * wave + (lane & 15)) * AP_XS + 3 * (lane >> 4);
+  const int offM = (lane & 15) * AP_MS + (lane >> 4);
+
+  load_stage(0);
+  store_stage(0);
+  __syncthreads();
+  for (int s = 0; s < n_stage; ++s) {
+    const int cur = s & 1;
+    if (s + 1 < n_stage) load_stage(s + 1);
+    const TC* x = sX + cur * XBUF;
+    const TC* m = sM + cur * MBUF;
+#pragma unroll
+    for (int kk = 0; kk < AP_KA / 4; ++kk) {
+      TC a[3], b[4];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) a[d] = x[offX + 12 * kk + d];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) b[n] = m[offM + 16 * n * AP_MS + 4 * kk];
+#pragma unroll
+      for (int n = 0; n < 4; ++n)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], b[n], acc[n][d]);
+    }
+    if (s + 1 < n_stage) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: out[t, c, d]; optional sum of squares (fixed order: lane tree, then waves)
+  double ss = 0.0;
+#pragma unroll
+  for (int n = 0; n < 4; ++n) {
+    const int c = c0 + 16 * n + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t t = t0 + 16 * wave + MF::row(lane, r);
+      if (t < T && c < n_cg) {
+        TC* o = out + (t * n_cg + c) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const TC v = acc[n][d][r];
+          o[d] = v;
+          ss += (double)v * (double)v;
+        }
+      }
+    }
+  }
+  if (sumsq_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    __shared__ double wsum[4];
+    if (lane == 0) wsum[wave] = ss;
+    __syncthreads();
+    if (tid == 0) sumsq_partials[bid] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+  }
+}
+
+// fixed-order final sum of per-workgroup partials: one workgroup, strided then tree
+__global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restrict__ part,
+                                                           int64_t n, double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int64_t i = threadIdx.x; i < n; i += 256) s += part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+template <typename TIn, typename TO>
+__global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict__ P, int64_t T,
+                                                           int32_t N, const int32_t* __restrict__ idx,
+                                                           int32_t n_cg, TO* __restrict__ out) {
+  const int64_t row_out = (int64_t)n_cg * 3;
+  const int64_t total = T * row_out;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / row_out;
+    const int e = (int)(i - t * row_out);
+    const int c = e / 3, d = e - 3 * c;
+    out[i] = (TO)P[(t * N + idx[c]) * 3 + d];
+  }
+}
+
+template <typename TIn, typename TC>
+static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
+                       int nan_mode, double nan_fill, void* out, double* sumsq, void* ws,
+                       size_t ws_bytes, hipStream_t stream) {
+  const int ncb = (int)ceil_div(n_cg, AP_TC);
+  const int64_t nfb = ceil_div(T, AP_TF);
+  const int64_t nblocks = nfb * ncb;
+  if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "apply grid too large");
+  double* partials = nullptr;
+  if (sumsq) {
+    if (!ws || ws_bytes < (size_t)nblocks * sizeof(double))
+      return fail(AGGF_ERR_WORKSPACE, "aggf_linearmap_apply: workspace too small for sumsq");
+    partials = reinterpret_cast<double*>(ws);
+  }
+  const int p_vec_ok = (((uintptr_t)P & 15) == 0) && (((int64_t)N * 3 * sizeof(TIn)) % 16 == 0);
+  const int m_vec_ok = (((uintptr_t)Mx & 15) == 0) && (((int64_t)N * sizeof(TC)) % 16 == 0);
+  const size_t lds = (size_t)2 * (AP_TF * AP_XS + AP_TC * AP_MS) * sizeof(TC);
+  if (nan_mode == AGGF_NAN_REPLACE)
+    hipLaunchKernelGGL((apply_kernel<TIn, TC, true>), dim3((unsigned)nblocks), dim3(AP_THREADS), lds,
+                       stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)nan_fill, p_vec_ok,
+                       m_vec_ok, (TC*)out, partials);
+  else
+    hipLaunchKernelGGL((apply_kernel<TIn, TC, false>), dim3((unsigned)nblocks), dim3(AP_THREADS), lds,
+                       stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)0, p_vec_ok,
+                       m_vec_ok, (TC*)out, partials);
+  AGGF_LAUNCH_OK();
+  if (sumsq) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, sumsq);
+    AGGF_LAUNCH_OK();
+  }
+  return AGGF_OK;
+}
+
+}  // namespace aggf
+
+using namespace aggf;
+
+extern "C" size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg) {
+  (void)N;
+  if (T <= 0 || n_cg <= 0) return 256;
+  return (size_t)round_up(ceil_div(T, AP_TF) * ceil_div(n_cg, AP_TC) * 8, 256);
+}
+
+extern "C" int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype,
+                                    const void* Mx, int32_t n_cg, int out_dtype, int nan_mode,
+                                    double nan_fill, void* out, double* sumsq, void* ws,
+                                    size_t ws_bytes, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!P || !Mx || !out) return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: NULL pointer");
+  if (T <= 0 || N <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: empty problem");
+  if (nan_mode != AGGF_NAN_PROPAGATE && nan_mode != AGGF_NAN_REPLACE)
+    return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: bad nan_mode");
+  if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
+    return apply_typed<double, double>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+  if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
+    return apply_typed<float, double>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+  if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
+    return apply_typed<float, float>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+  if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
+    return apply_typed<double, float>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+  return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: unsupported dtype combination (in %d, out %d)",
+              in_dtype, out_dtype);
+}
+
+extern "C" int aggf_slice_gather(const void* P, int64_t T, int32_t N, int in_dtype,
+                                 const int32_t* idx, int32_t n_cg, int out_dtype, void* out,
+                                 void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!P || !idx || !out) return fail(AGGF_ERR_ARG, "aggf_slice_gather: NULL pointer");
+  if (T <= 0 || N <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_slice_gather: empty problem");
+  const int64_t total = T * (int64_t)n_cg * 3;
+  int64_t g = ceil_div(total, 256);
+  if (g > 8192) g = 8192;
+  const dim3 grid((unsigned)g), block(256);
+  if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out);
+  else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out);
+  else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out);
+  else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_slice_gather: unsupported dtype combination");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}

@@ -1,0 +1,115 @@
+// Shared device/host helpers for libaggf (gfx950 / CDNA4 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string>
+
+#include "../../include/aggf.h"
+
+namespace aggf {
+
+// ---- error plumbing (thread-local last error string; see aggf_last_error) ----
+void set_error(const char* fmt, ...);
+int fail(int code, const char* fmt, ...);
+
+#define AGGF_HIP_OK(expr)                                                         \
+  do {                                                                            \
+    hipError_t _e = (expr);                                                       \
+    if (_e != hipSuccess)                                                         \
+      return ::aggf::fail(AGGF_ERR_HIP, "%s failed: %s (%s:%d)", #expr,           \
+                          hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+
+#define AGGF_LAUNCH_OK()                                                          \
+  do {                                                                            \
+    hipError_t _e = hipGetLastError();                                            \
+    if (_e != hipSuccess)                                                         \
+      return ::aggf::fail(AGGF_ERR_HIP, "kernel launch failed: %s (%s:%d)",       \
+                          hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+
+static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
+static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
+int device_cu_count();
+
+typedef double __attribute__((ext_vector_type(4))) f64x4;
+typedef float __attribute__((ext_vector_type(4))) f32x4;
+
+// ---- MFMA 16x16x4 wrappers.  A: lane l holds A[i=l&15][k=l>>4]; B: B[k=l>>4][j=l&15].
+//      C/D: col = l&15 for both; row = (l>>4)+4*r for f64, (l>>4)*4+r for f32
+//      (cdna_hip_programming.md section 3, "Fragment layout").
+template <typename T>
+struct Mfma;
+
+template <>
+struct Mfma<double> {
+  using acc_t = f64x4;
+  __device__ static __forceinline__ acc_t mma(double a, double b, acc_t c) {
+    return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ int row(int lane, int r) { return (lane >> 4) + 4 * r; }
+};
+
+template <>
+struct Mfma<float> {
+  using acc_t = f32x4;
+  __device__ static __forceinline__ acc_t mma(float a, float b, acc_t c) {
+    return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0);
+  }
+  __device__ static __forceinline__ int row(int lane, int r) { return (lane >> 4) * 4 + r; }
+};
+
+template <typename T>
+__device__ __forceinline__ typename Mfma<T>::acc_t acc_zero() {
+  typename Mfma<T>::acc_t z = {0, 0, 0, 0};
+  return z;
+}
+
+// 16-byte vector of T
+template <typename T>
+struct Vec16;
+template <>
+struct Vec16<double> {
+  typedef double __attribute__((ext_vector_type(2))) type;
+  static constexpr int N = 2;
+};
+template <>
+struct Vec16<float> {
+  typedef float __attribute__((ext_vector_type(4))) type;
+  static constexpr int N = 4;
+};
+
+// ---- Philox4x32-10 (Salmon et al., SC'11): counter = 64-bit quad index, key = seed ----
+__device__ __forceinline__ void philox4x32_10(uint32_t c[4], uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u, W0 = 0x9E3779B9u, W1 = 0xBB67AE85u;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    const uint64_t p0 = (uint64_t)M0 * c[0];
+    const uint64_t p1 = (uint64_t)M1 * c[2];
+    const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+    const uint32_t n1 = (uint32_t)p1;
+    const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+    const uint32_t n3 = (uint32_t)p0;
+    c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+    k0 += W0; k1 += W1;
+  }
+}
+
+// four standard normals for quad index q of stream `seed` (Box-Muller on 32-bit uniforms)
+__device__ __forceinline__ void normal_quad(uint64_t seed, uint64_t stream, int64_t q, double z[4]) {
+  uint32_t c[4] = {(uint32_t)q, (uint32_t)((uint64_t)q >> 32), (uint32_t)stream, (uint32_t)(stream >> 32)};
+  philox4x32_10(c, (uint32_t)seed, (uint32_t)(seed >> 32));
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const double u1 = ((double)c[2 * h] + 0.5) * (1.0 / 4294967296.0);
+    const double u2 = ((double)c[2 * h + 1] + 0.5) * (1.0 / 4294967296.0);
+    const double rad = sqrt(-2.0 * log(u1));
+    double sn, cs;
+    sincos(6.283185307179586476925 * u2, &sn, &cs);
+    z[2 * h] = rad * cs;
+    z[2 * h + 1] = rad * sn;
+  }
+}
+
+}  // namespace aggf

@@ -1,0 +1,423 @@
+// K1: Gram / normal matrix of (constraint-reduced) forces on MFMA.
+//
+// Replaces qp/qplinear.py:66-71 of the reference (qp_form copy, `@ con_mat`,
+// `reg_mat.T @ reg_mat`).  Three kernels:
+//   pack_groups_kernel   (T,N,3) -> (T,n_pad,3): constraint-group column sums, dtype
+//                        conversion and zero padding to a multiple of 128 columns
+//                        (skipped when the input already has that shape and dtype);
+//   gram_tile_kernel     split-K SYRK: one 128x128 upper-triangle tile x one frame
+//                        range per workgroup, MFMA 16x16x4 (f64 or f32), frame rows
+//                        staged through LDS exactly as they lie in HBM -- the
+//                        (t,d)-major / atom-minor transpose the reference pays a
+//                        full copy for (qp_form) is done by the LDS read pattern;
+//   gram_reduce_kernel   fixed-order fp64 sum of the split-K slabs into G (both
+//                        triangles) -- no float atomics, bit-reproducible.
+#include "aggf_common.h"
+
+namespace aggf {
+
+constexpr int TILE = 128;         // output tile edge (reduced atoms)
+constexpr int ROW_ELEMS = TILE * 3;
+constexpr int ROW_PAD = 16;       // row stride == 128 B (f64) / 64 B (f32) mod bank period:
+                                  // the two k-rows a 32-lane half reads hit disjoint banks
+constexpr int ROW_STRIDE = ROW_ELEMS + ROW_PAD;
+constexpr int GRAM_THREADS = 256;
+
+template <typename T>
+struct GramCfg;
+template <>
+struct GramCfg<double> {
+  static constexpr int KB = 4;  // frames per LDS stage
+};
+template <>
+struct GramCfg<float> {
+  static constexpr int KB = 8;
+};
+
+// ---------------------------------------------------------------------------
+template <typename TIn, typename TC>
+__global__ __launch_bounds__(256) void pack_groups_kernel(
+    const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
+    const int32_t* __restrict__ grp_atoms, int32_t n_red, int32_t n_pad, TC* __restrict__ out) {
+  const int64_t row_in = (int64_t)N * 3;
+  const int64_t row_out = (int64_t)n_pad * 3;
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+    const TIn* src = F + t * row_in;
+    TC* dst = out + t * row_out;
+    for (int e = threadIdx.x; e < (int)row_out; e += blockDim.x) {
+      const int g = e / 3, d = e - 3 * g;
+      TC acc = 0;
+      if (g < n_red) {
+        if (grp_ptr) {
+          const int b = grp_ptr[g], en = grp_ptr[g + 1];
+          for (int j = b; j < en; ++j) acc += (TC)src[(int64_t)grp_atoms[j] * 3 + d];
+        } else {
+          acc = (TC)src[e];
+        }
+      }
+      dst[e] = acc;
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+// X: (rows, ld) with ld = 3*n_pad elements, n_pad % 128 == 0, 16-byte aligned rows.
+// grid.x = ksplit * n_tiles, tile fastest (co-running workgroups share a frame range).
+template <typename T>
+__global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
+    const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles,
+    int64_t frames_per_split, T* __restrict__ slabs) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  using vec_t = typename Vec16<T>::type;
+  constexpr int KB = GramCfg<T>::KB;
+  constexpr int VN = Vec16<T>::N;
+  constexpr int CH_PER_ROW = ROW_ELEMS / VN;          // 16-byte chunks per panel row
+  constexpr int CH_PER_PANEL = CH_PER_ROW * KB;       // 768 for both dtypes
+  constexpr int CH_PER_THREAD = CH_PER_PANEL / GRAM_THREADS;  // 3
+  static_assert(CH_PER_PANEL % GRAM_THREADS == 0, "staging split");
+  constexpr int PANEL_ELEMS = KB * ROW_STRIDE;
+  constexpr int BUF_ELEMS = 2 * PANEL_ELEMS;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int b = blockIdx.x;
+  const int ks = b / n_tiles;
+  int tile = b - ks * n_tiles;
+  // tile -> (ti, tj), upper triangle, row-major
+  int ti = 0;
+  {
+    int rowlen = nt1;
+    while (tile >= rowlen) {
+      tile -= rowlen;
+      --rowlen;
+      ++ti;
+    }
+  }
+  const int tj = ti + tile;
+  const bool diag = (ti == tj);
+  const int tile_lin = b - ks * n_tiles;
+
+  const int64_t t_begin = (int64_t)ks * frames_per_split;
+  int64_t t_end = t_begin + frames_per_split;
+  if (t_end > n_rows) t_end = n_rows;
+  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KB - 1) / KB) : 0;
+
+  // per-thread staging coordinates (same for every stage)
+  int st_row[CH_PER_THREAD], st_col[CH_PER_THREAD];
+#pragma unroll
+  for (int q = 0; q < CH_PER_THREAD; ++q) {
+    const int c = tid + q * GRAM_THREADS;
+    st_row[q] = c / CH_PER_ROW;
+    st_col[q] = (c - st_row[q] * CH_PER_ROW) * VN;
+  }
+  const T* gA = X + (int64_t)ti * ROW_ELEMS;
+  const T* gB = X + (int64_t)tj * ROW_ELEMS;
+
+  vec_t ra[CH_PER_THREAD], rb[CH_PER_THREAD];
+  auto load_stage = [&](int it) {
+    const int64_t t0 = t_begin + (int64_t)it * KB;
+#pragma unroll
+    for (int q = 0; q < CH_PER_THREAD; ++q) {
+      const int64_t t = t0 + st_row[q];
+      vec_t z;
+#pragma unroll
+      for (int e = 0; e < VN; ++e) z[e] = 0;
+      ra[q] = z;
+      rb[q] = z;
+      if (t < t_end) {
+        ra[q] = *reinterpret_cast<const vec_t*>(gA + t * ld + st_col[q]);
+        if (!diag) rb[q] = *reinterpret_cast<const vec_t*>(gB + t * ld + st_col[q]);
+      }
+    }
+  };
+  auto store_stage = [&](int buf) {
+    T* pa = smem + buf * BUF_ELEMS;
+    T* pb = pa + PANEL_ELEMS;
+#pragma unroll
+    for (int q = 0; q < CH_PER_THREAD; ++q) {
+      *reinterpret_cast<vec_t*>(pa + st_row[q] * ROW_STRIDE + st_col[q]) = ra[q];
+      if (!diag) *reinterpret_cast<vec_t*>(pb + st_row[q] * ROW_STRIDE + st_col[q]) = rb[q];
+    }
+  };
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = acc_zero<T>();
+
+  // lane-constant LDS read offsets: k-row (lane>>4), column 3*(wave tile + lane&15)
+  const int offA = (lane >> 4) * ROW_STRIDE + 3 * (wm * 64 + (lane & 15));
+  const int offB = (lane >> 4) * ROW_STRIDE + 3 * (wn * 64 + (lane & 15));
+
+  if (n_it > 0) {
+    load_stage(0);
+    store_stage(0);
+  }
+  __syncthreads();
+
+  for (int it = 0; it < n_it; ++it) {
+    const int cur = it & 1;
+    if (it + 1 < n_it) load_stage(it + 1);
+    const T* pa = smem + cur * BUF_ELEMS;
+    const T* pb = diag ? pa : pa + PANEL_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        T a[4], bb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bb[n] = pb[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+      }
+    }
+    if (it + 1 < n_it) store_stage(cur ^ 1);
+    __syncthreads();
+  }
+
+  // partial tile -> slab [(tile_lin * ksplit + ks)][128][128]
+  const int ksplit = gridDim.x / n_tiles;
+  T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + m * 16 + M::row(lane, r);
+        const int col = wn * 64 + n * 16 + (lane & 15);
+        slab[row * TILE + col] = acc[m][n][r];
+      }
+}
+
+// ---------------------------------------------------------------------------
+// G[(ti,tj) tile] (+)= sum_ks slab, and the mirrored tile.  grid = (n_tiles, 16): each
+// workgroup handles 8 rows of a tile... (16 row-groups of 8 rows x 128 cols, 256 threads,
+// 4 elements per thread).
+template <typename T>
+__global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ slabs,
+                                                          int32_t nt1, int32_t ksplit,
+                                                          int32_t n_red, int accumulate,
+                                                          double* __restrict__ G) {
+  int tile = blockIdx.x;
+  const int tile_lin = tile;
+  int ti = 0;
+  {
+    int rowlen = nt1;
+    while (tile >= rowlen) {
+      tile -= rowlen;
+      --rowlen;
+      ++ti;
+    }
+  }
+  const int tj = ti + tile;
+  const T* base = slabs + (int64_t)tile_lin * ksplit * (TILE * TILE);
+  const int r0 = blockIdx.y * 8;
+  for (int e = threadIdx.x; e < 8 * TILE; e += blockDim.x) {
+    const int row = r0 + e / TILE, col = e % TILE;
+    double s = 0.0;
+    for (int ks = 0; ks < ksplit; ++ks)
+      s += (double)base[(int64_t)ks * (TILE * TILE) + row * TILE + col];
+    const int gi = ti * TILE + row, gj = tj * TILE + col;
+    if (gi < n_red && gj < n_red) {
+      if (ti != tj || gj >= gi) {
+        double* p = G + (int64_t)gi * n_red + gj;
+        *p = accumulate ? *p + s : s;
+      }
+      if (ti != tj || gj > gi) {
+        // mirror (for diagonal tiles only the strict upper part is mirrored so that
+        // G stays exactly symmetric)
+        double* p = G + (int64_t)gj * n_red + gi;
+        *p = accumulate ? *p + s : s;
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------
+struct GramPlan {
+  int32_t n_pad, nt1, n_tiles;
+  bool direct;         // gram kernel reads F in place
+  int ksplit;
+  int64_t frames_per_split;
+  int64_t chunk_frames;  // frames per pack chunk (direct: T)
+  size_t slab_bytes, pack_bytes;
+};
+
+static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t max_splits) {
+  // enough workgroups for ~6 rounds over the chip, with the last round as full as possible
+  int64_t hi = ceil_div(frames, (int64_t)kb * 8);  // at least 8 stages per split
+  if (hi < 1) hi = 1;
+  if (hi > max_splits) hi = max_splits;
+  int64_t want = ceil_div((int64_t)slots * 6, n_tiles);
+  if (want > hi) want = hi;
+  if (want < 1) want = 1;
+  int64_t lo = want * 3 / 4;
+  if (lo < 1) lo = 1;
+  int64_t up = want * 5 / 4 + 1;
+  if (up > hi) up = hi;
+  double best_eff = -1;
+  int64_t best = want;
+  for (int64_t k = lo; k <= up; ++k) {
+    const double blocks = (double)k * n_tiles;
+    const double rounds = (double)ceil_div((int64_t)blocks, slots);
+    const double eff = blocks / (rounds * slots);
+    if (eff > best_eff + 1e-9) {
+      best_eff = eff;
+      best = k;
+    }
+  }
+  return (int)best;
+}
+
+static size_t dtype_size(int dt) { return dt == AGGF_F64 ? 8 : 4; }
+
+static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
+                     bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p) {
+  p->n_pad = (int32_t)round_up(n_red, TILE);
+  p->nt1 = p->n_pad / TILE;
+  p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
+  p->direct = !has_groups && (N % TILE == 0) && in_dtype == compute_dtype && aligned;
+  const int kb = compute_dtype == AGGF_F64 ? GramCfg<double>::KB : GramCfg<float>::KB;
+  const size_t cs = dtype_size(compute_dtype);
+  const int slots = 2 * device_cu_count();
+  const size_t slab1 = (size_t)p->n_tiles * TILE * TILE * cs;  // one split
+  const size_t row_bytes = (size_t)p->n_pad * 3 * cs;
+  if (query) {
+    // recommended: slabs for the preferred split count + a pack chunk of <= 1 GiB
+    p->chunk_frames = T;
+    if (!p->direct) {
+      int64_t cf = (int64_t)((size_t)1 << 30) / (int64_t)row_bytes;
+      if (cf < 256) cf = 256;
+      if (cf > T) cf = T;
+      p->chunk_frames = cf > 0 ? cf : 1;
+    }
+    p->ksplit = choose_ksplit(p->n_tiles, p->chunk_frames, kb, slots, 1 << 20);
+    p->slab_bytes = slab1 * p->ksplit;
+    p->pack_bytes = p->direct ? 0 : round_up((int64_t)(p->chunk_frames * row_bytes), 256);
+    return AGGF_OK;
+  }
+  // fit into the given workspace: pack chunk gets at most half of it
+  p->pack_bytes = 0;
+  p->chunk_frames = T;
+  size_t avail = ws_bytes;
+  if (!p->direct) {
+    int64_t cf = (int64_t)(ws_bytes / 2 / row_bytes);
+    if (cf > T) cf = T;
+    if (cf < 1) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small for one packed frame");
+    int64_t cap = (int64_t)((size_t)1 << 30) / (int64_t)row_bytes;
+    if (cap < 256) cap = 256;
+    if (cf > cap) cf = cap;
+    p->chunk_frames = cf;
+    p->pack_bytes = (size_t)round_up((int64_t)(cf * row_bytes), 256);
+    avail = ws_bytes - p->pack_bytes;
+  }
+  avail = avail > 512 ? avail - 512 : 0;  // room for the 256-byte roundings
+  const int64_t max_splits = (int64_t)(avail / slab1);
+  if (max_splits < 1) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small for one slab set");
+  p->ksplit = choose_ksplit(p->n_tiles, p->chunk_frames, kb, slots, max_splits);
+  p->slab_bytes = slab1 * p->ksplit;
+  return AGGF_OK;
+}
+
+template <typename T>
+static int launch_gram(const T* X, int64_t rows, const GramPlan& p, T* slabs, double* G,
+                       int32_t n_red, int accumulate, hipStream_t stream) {
+  constexpr int KB = GramCfg<T>::KB;
+  const int ksplit = p.ksplit;
+  int64_t fps = round_up(ceil_div(rows, ksplit), KB);
+  if (fps < KB) fps = KB;
+  const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T);
+  const int64_t nblocks = (int64_t)ksplit * p.n_tiles;
+  if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
+  hipLaunchKernelGGL((gram_tile_kernel<T>), dim3((unsigned)nblocks), dim3(GRAM_THREADS), lds,
+                     stream, X, rows, (int64_t)p.n_pad * 3, p.nt1, p.n_tiles, fps, slabs);
+  AGGF_LAUNCH_OK();
+  hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
+                     slabs, p.nt1, ksplit, n_red, accumulate, G);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+template <typename TIn, typename TC>
+static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_ptr,
+                      const int32_t* grp_atoms, int32_t n_red, double* G, int accumulate,
+                      const GramPlan& p, char* ws, hipStream_t stream) {
+  TC* slabs = reinterpret_cast<TC*>(ws);
+  if (p.direct) {
+    // only reachable with TIn == TC
+    return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, p, slabs, G, n_red, accumulate,
+                           stream);
+  }
+  TC* pack = reinterpret_cast<TC*>(ws + round_up((int64_t)p.slab_bytes, 256));
+  const TIn* F = reinterpret_cast<const TIn*>(Fv);
+  int acc = accumulate;
+  for (int64_t t0 = 0; t0 < T; t0 += p.chunk_frames) {
+    const int64_t rows = (T - t0 < p.chunk_frames) ? T - t0 : p.chunk_frames;
+    int grid = (int)(rows < 4096 ? rows : 4096);
+    hipLaunchKernelGGL((pack_groups_kernel<TIn, TC>), dim3(grid), dim3(256), 0, stream,
+                       F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad,
+                       pack);
+    AGGF_LAUNCH_OK();
+    int rc = launch_gram<TC>(pack, rows, p, slabs, G, n_red, acc, stream);
+    if (rc) return rc;
+    acc = 1;
+  }
+  return AGGF_OK;
+}
+
+}  // namespace aggf
+
+using namespace aggf;
+
+extern "C" size_t aggf_gram_workspace_bytes(int64_t T, int32_t N, int32_t n_red, int in_dtype,
+                                            int compute_dtype, int has_groups) {
+  if (T <= 0 || N <= 0 || n_red <= 0) return 0;
+  GramPlan p;
+  make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups != 0, true, 0, true, &p);
+  return (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 256;
+}
+
+extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+                         const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red,
+                         double* G, int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!F || !G || !ws) return fail(AGGF_ERR_ARG, "aggf_gram: NULL pointer");
+  if (T <= 0 || N <= 0 || n_red <= 0) return fail(AGGF_ERR_ARG, "aggf_gram: empty problem");
+  if ((in_dtype != AGGF_F32 && in_dtype != AGGF_F64) ||
+      (compute_dtype != AGGF_F32 && compute_dtype != AGGF_F64))
+    return fail(AGGF_ERR_ARG, "aggf_gram: bad dtype");
+  if (in_dtype == AGGF_F64 && compute_dtype == AGGF_F32)
+    return fail(AGGF_ERR_ARG, "aggf_gram: float64 input with float32 products is not supported");
+  const bool has_groups = grp_ptr != nullptr;
+  if (has_groups != (grp_atoms != nullptr))
+    return fail(AGGF_ERR_ARG, "aggf_gram: grp_ptr and grp_atoms must be given together");
+  if (!has_groups && n_red != N)
+    return fail(AGGF_ERR_ARG, "aggf_gram: n_red must equal N without constraint groups");
+  if (n_red > N) return fail(AGGF_ERR_ARG, "aggf_gram: n_red > N");
+  if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram: workspace not 256-byte aligned");
+  const bool aligned = ((uintptr_t)F & 15) == 0;
+  GramPlan p;
+  int rc = make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups, aligned, ws_bytes, false, &p);
+  if (rc) return rc;
+  if ((size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes > ws_bytes)
+    return fail(AGGF_ERR_WORKSPACE, "aggf_gram: workspace too small");
+  char* w = reinterpret_cast<char*>(ws);
+  if (in_dtype == AGGF_F64)
+    return gram_typed<double, double>(F, T, N, grp_ptr, grp_atoms, n_red, G, accumulate, p, w, stream);
+  if (compute_dtype == AGGF_F64)
+    return gram_typed<float, double>(F, T, N, grp_ptr, grp_atoms, n_red, G, accumulate, p, w, stream);
+  return gram_typed<float, float>(F, T, N, grp_ptr, grp_atoms, n_red, G, accumulate, p, w, stream);
+}

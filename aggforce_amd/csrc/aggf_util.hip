@@ -1,0 +1,258 @@
+// Error plumbing, small streaming kernels (NaN scan, allclose, sum of squares, map
+// expansion) and the counter-based synthetic trajectory generator.
+#include <stdarg.h>
+
+#include "aggf_common.h"
+
+namespace aggf {
+
+static thread_local std::string g_last_error;
+
+void set_error(const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+}
+
+int fail(int code, const char* fmt, ...) {
+  char buf[1024];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof(buf), fmt, ap);
+  va_end(ap);
+  g_last_error = buf;
+  return code;
+}
+
+int device_cu_count() {
+  static thread_local int cached = 0;
+  if (cached > 0) return cached;
+  int dev = 0, n = 0;
+  if (hipGetDevice(&dev) != hipSuccess ||
+      hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+    n = 256;  // MI355X
+  cached = n;
+  return n;
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void has_nan_kernel(const T* __restrict__ x, int64_t n,
+                                                      int32_t* __restrict__ flag) {
+  bool found = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const T v = x[i];
+    found |= (v != v);
+  }
+  if (__any(found) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void not_close_kernel(const T* __restrict__ a,
+                                                        const T* __restrict__ b, int64_t n,
+                                                        double rtol, double atol,
+                                                        int32_t* __restrict__ flag) {
+  bool bad = false;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const double x = (double)a[i], y = (double)b[i];
+    // np.isclose: finite -> |x-y| <= atol + rtol|y|; equal infinities are close; NaN never
+    const bool ok = (x == y) || (fabs(x - y) <= atol + rtol * fabs(y));
+    bad |= !ok;
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
+}
+
+constexpr int SUMSQ_BLOCKS = 1024;
+
+template <typename T>
+__global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, int64_t n,
+                                                    double* __restrict__ partials) {
+  // contiguous slice per workgroup, fixed order inside: lane-strided, lane tree, wave sum
+  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
+  const int64_t b = (int64_t)blockIdx.x * per;
+  int64_t e = b + per;
+  if (e > n) e = n;
+  double s = 0.0;
+  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
+    const double v = (double)x[i];
+    s += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
+  __shared__ double w[4];
+  if ((threadIdx.x & 63) == 0) w[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) partials[blockIdx.x] = (w[0] + w[1]) + (w[2] + w[3]);
+}
+
+__global__ __launch_bounds__(256) void sum_fixed_kernel(const double* __restrict__ part, int n,
+                                                        double* __restrict__ out) {
+  __shared__ double sh[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < n; i += 256) s += part[i];
+  sh[threadIdx.x] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) out[0] = sh[0];
+}
+
+__global__ __launch_bounds__(256) void expand_map_kernel(const double* __restrict__ X,
+                                                         int32_t n_rows, int32_t n_red,
+                                                         const int32_t* __restrict__ goa,
+                                                         int32_t N, double* __restrict__ W) {
+  const int64_t total = (int64_t)n_rows * N;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / N;
+    const int a = (int)(i - r * N);
+    W[i] = X[r * n_red + goa[a]];
+  }
+}
+
+// ---------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void synth_normal_kernel(T* __restrict__ out, int64_t T_frames,
+                                                           int32_t N, uint64_t seed,
+                                                           int64_t frame_offset, double mean,
+                                                           double sigma, double lattice) {
+  const int64_t row = (int64_t)N * 3;
+  const int64_t g_begin = frame_offset * row;
+  const int64_t g_end = g_begin + T_frames * row;
+  const int64_t q_begin = g_begin / 4, q_end = (g_end + 3) / 4;
+  int side = 1;
+  if (lattice != 0.0) {
+    side = (int)ceil(cbrt((double)N));
+    while ((int64_t)side * side * side < N) ++side;
+  }
+  for (int64_t q = q_begin + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; q < q_end;
+       q += (int64_t)gridDim.x * blockDim.x) {
+    double z[4];
+    normal_quad(seed, 0, q, z);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int64_t g = 4 * q + e;
+      if (g < g_begin || g >= g_end) continue;
+      double mu = mean;
+      if (lattice != 0.0) {
+        const int64_t in_row = g % row;
+        const int a = (int)(in_row / 3), d = (int)(in_row - 3 * (int64_t)a);
+        const int coord = d == 0 ? a % side : (d == 1 ? (a / side) % side : a / (side * side));
+        mu += lattice * coord;
+      }
+      out[g - g_begin] = (T)(mu + sigma * z[e]);
+    }
+  }
+}
+
+static dim3 stream_grid(int64_t n) {
+  int64_t g = ceil_div(n, 256);
+  if (g > 8192) g = 8192;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+}  // namespace aggf
+
+using namespace aggf;
+
+extern "C" int aggf_version(void) { return AGGF_VERSION; }
+
+extern "C" const char* aggf_last_error(void) { return aggf::g_last_error.c_str(); }
+
+extern "C" int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes) {
+  int dev = 0, n = 0;
+  AGGF_HIP_OK(hipGetDevice(&dev));
+  AGGF_HIP_OK(hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev));
+  size_t f = 0, t = 0;
+  AGGF_HIP_OK(hipMemGetInfo(&f, &t));
+  if (cu_count) *cu_count = n;
+  if (free_bytes) *free_bytes = f;
+  if (total_bytes) *total_bytes = t;
+  return AGGF_OK;
+}
+
+extern "C" int aggf_has_nan(const void* x, int64_t count, int dtype, int32_t* flag, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!x || !flag) return fail(AGGF_ERR_ARG, "aggf_has_nan: NULL pointer");
+  if (count <= 0) return AGGF_OK;
+  if (dtype == AGGF_F64)
+    hipLaunchKernelGGL(has_nan_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)x, count, flag);
+  else if (dtype == AGGF_F32)
+    hipLaunchKernelGGL(has_nan_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)x, count, flag);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_has_nan: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_not_close(const void* a, const void* b, int64_t count, int dtype, double rtol,
+                              double atol, int32_t* flag, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!a || !b || !flag) return fail(AGGF_ERR_ARG, "aggf_not_close: NULL pointer");
+  if (count <= 0) return AGGF_OK;
+  if (dtype == AGGF_F64)
+    hipLaunchKernelGGL(not_close_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)a, (const double*)b, count, rtol, atol, flag);
+  else if (dtype == AGGF_F32)
+    hipLaunchKernelGGL(not_close_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)a, (const float*)b, count, rtol, atol, flag);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_not_close: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" size_t aggf_sumsq_workspace_bytes(void) { return SUMSQ_BLOCKS * sizeof(double); }
+
+extern "C" int aggf_sumsq(const void* x, int64_t count, int dtype, double* out, void* ws,
+                          size_t ws_bytes, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!x || !out || !ws) return fail(AGGF_ERR_ARG, "aggf_sumsq: NULL pointer");
+  if (ws_bytes < SUMSQ_BLOCKS * sizeof(double)) return fail(AGGF_ERR_WORKSPACE, "aggf_sumsq: workspace too small");
+  if (count < 0) return fail(AGGF_ERR_ARG, "aggf_sumsq: negative count");
+  double* part = (double*)ws;
+  if (dtype == AGGF_F64)
+    hipLaunchKernelGGL(sumsq_kernel<double>, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, (const double*)x, count, part);
+  else if (dtype == AGGF_F32)
+    hipLaunchKernelGGL(sumsq_kernel<float>, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, (const float*)x, count, part);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_sumsq: bad dtype");
+  AGGF_LAUNCH_OK();
+  hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(256), 0, stream, part, SUMSQ_BLOCKS, out);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
+                               const int32_t* group_of_atom, int32_t N, double* W, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!X || !group_of_atom || !W) return fail(AGGF_ERR_ARG, "aggf_expand_map: NULL pointer");
+  if (n_rows <= 0 || n_red <= 0 || N <= 0) return fail(AGGF_ERR_ARG, "aggf_expand_map: empty problem");
+  hipLaunchKernelGGL(expand_map_kernel, stream_grid((int64_t)n_rows * N), dim3(256), 0, stream, X, n_rows, n_red, group_of_atom, N, W);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_synth_normal(void* out, int64_t T, int32_t N, int dtype, uint64_t seed,
+                                 int64_t frame_offset, double mean, double sigma, double lattice,
+                                 void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!out) return fail(AGGF_ERR_ARG, "aggf_synth_normal: NULL pointer");
+  if (T <= 0 || N <= 0 || frame_offset < 0) return fail(AGGF_ERR_ARG, "aggf_synth_normal: bad shape");
+  const int64_t quads = T * (int64_t)N * 3 / 4 + 2;
+  dim3 grid = stream_grid(quads);
+  if (dtype == AGGF_F64)
+    hipLaunchKernelGGL(synth_normal_kernel<double>, grid, dim3(256), 0, stream, (double*)out, T, N, seed, frame_offset, mean, sigma, lattice);
+  else if (dtype == AGGF_F32)
+    hipLaunchKernelGGL(synth_normal_kernel<float>, grid, dim3(256), 0, stream, (float*)out, T, N, seed, frame_offset, mean, sigma, lattice);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_synth_normal: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}

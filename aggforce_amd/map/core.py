@@ -1,0 +1,253 @@
+"""LinearMap and CLAMap: the reference's map objects with GPU-backed application.
+
+Reference: map/core.py (LinearMap 46-317, CLAMap 320-430).  The objects keep the
+reference's constructor arguments, properties, algebra and error behaviour; the
+contraction itself (``util.trjdot``, util.py:119-125) runs in the HIP kernels K3
+(``aggf_linearmap_apply``, MFMA) and K3b (``aggf_slice_gather`` for one-hot rows).
+Arrays may be NumPy arrays (copied to the GPU and back) or torch ROCm tensors (results
+stay on the device).
+"""
+from typing import Callable, Dict, Final, List, Literal, Optional, Union
+
+import numpy as np
+
+from .. import _kernels as K
+from ..util import trjdot
+
+
+class _Taggable:
+    """Carries a free-form ``tags`` dictionary (reference map/core.py:21-43)."""
+
+    def __init__(self, tags: Union[None, Dict[str, str]]) -> None:
+        self.tags = {} if tags is None else tags
+
+
+class LinearMap:
+    """Linear fine-grained -> coarse-grained map given by its standard matrix.
+
+    ``standard_matrix`` has shape (n_cg_sites, n_fg_sites).  Calling the map contracts
+    it with arrays of shape (n_steps, n_fg_sites, 3).
+    """
+
+    n_dim: Final = 3
+
+    def __init__(
+        self,
+        mapping: Union[List[List[int]], np.ndarray],
+        n_fg_sites: Union[int, None] = None,
+        handle_nans: Union[bool, Literal["safe"]] = True,
+        nan_check_threshold: float = 1e-6,
+    ) -> None:
+        """Build from a 2-D matrix, or from per-cg-site lists of fg indices (uniform weights).
+
+        ``[[0,2,3],[4]]`` with ``n_fg_sites=6`` gives rows ``[1/3,0,1/3,1/3,0,0]`` and
+        ``[0,0,0,0,1,0]`` (reference map/core.py:133-144).  ``handle_nans``: NaN inputs that
+        only meet zero coefficients are ignored, any other NaN raises ``ValueError``
+        (map/core.py:219-238); ``"safe"`` and ``True`` are equivalent here because the input
+        is never modified; ``False`` propagates NaNs like a plain product.
+        """
+        if hasattr(mapping, "detach"):
+            mapping = mapping.detach().cpu().numpy()
+        if isinstance(mapping, np.ndarray) and mapping.ndim == 2:
+            if n_fg_sites is not None:
+                raise ValueError(
+                    "Cannot specify n_fg_sites when mapping is ArrayLike. Let it be inferred."
+                )
+            matrix = mapping
+        elif hasattr(mapping, "__iter__"):
+            if n_fg_sites is None:
+                raise ValueError("n_fg_sites is required when mapping is a list of index lists.")
+            rows = [list(r) for r in mapping]
+            matrix = np.zeros((len(rows), n_fg_sites))
+            for site, members in enumerate(rows):
+                row = np.zeros(n_fg_sites)
+                row[members] = 1 / len(members)
+                matrix[site] = row
+        else:
+            raise ValueError(f"Cannot understand mapping {mapping}.")
+        self._standard_matrix = matrix
+        self.handle_nans = handle_nans
+        if self.handle_nans and not np.all(np.isfinite(matrix)):
+            raise ValueError("Nan checking can only be performed if standard_matrix is itself finite.")
+        self.nan_check_threshold = nan_check_threshold
+        self._dev_cache: Dict = {}
+        self._onehot = None
+
+    # ------------------------------------------------------------------ properties
+    @property
+    def standard_matrix(self) -> np.ndarray:
+        """The mapping in standard matrix format."""
+        return self._standard_matrix
+
+    @property
+    def n_cg_sites(self) -> int:
+        return self.standard_matrix.shape[0]
+
+    @property
+    def n_fg_sites(self) -> int:
+        return self.standard_matrix.shape[1]
+
+    @property
+    def participating_fg(self) -> List[List[int]]:
+        """For each cg site, the fg sites with a positive coefficient."""
+        table: List[List[int]] = [[] for _ in range(self.n_cg_sites)]
+        for cg, fg in zip(*np.nonzero(self.standard_matrix > 0)):
+            table[cg].append(fg)
+        return table
+
+    def close_to_identity(self, threshold: float = 1e-8) -> bool:
+        """True if square and within ``threshold`` (Frobenius norm) of the identity."""
+        m = self.standard_matrix
+        if m.shape[0] != m.shape[1]:
+            return False
+        return bool(np.sqrt(((np.identity(m.shape[0], dtype=m.dtype) - m) ** 2).sum()) <= threshold)
+
+    # ------------------------------------------------------------------ device side
+    def _device_matrix(self, tdtype, device):
+        key = (tdtype, str(device))
+        hit = self._dev_cache.get(key)
+        if hit is None or hit[0] is not self._standard_matrix:
+            import torch
+
+            t = torch.from_numpy(np.ascontiguousarray(self._standard_matrix)).to(device=device, dtype=tdtype)
+            self._dev_cache = {k: v for k, v in self._dev_cache.items() if v[0] is self._standard_matrix}
+            self._dev_cache[key] = (self._standard_matrix, t)
+            return t
+        return hit[1]
+
+    def _onehot_index(self):
+        """Atom index per row if every row is a unit vector (slice map), else None."""
+        if self._onehot is None or self._onehot[0] is not self._standard_matrix:
+            m = self._standard_matrix
+            idx = None
+            if m.size and np.all((m == 0) | (m == 1)) and np.all(m.sum(axis=1) == 1):
+                idx = np.argmax(m, axis=1).astype(np.int32)
+            self._onehot = (m, idx)
+        return self._onehot[1]
+
+    def _out_dtype(self, points) -> np.dtype:
+        dt = np.result_type(K.np_dtype_of(points), self.standard_matrix.dtype)
+        return dt if dt in (np.float32, np.float64) else np.dtype(np.float64)
+
+    def __call__(self, points):
+        """Map an array of shape (n_steps, n_fg_sites, 3); NaN policy per ``handle_nans``."""
+        shape = tuple(points.shape)
+        if len(shape) != 3 or shape[2] != self.n_dim or shape[1] != self.n_fg_sites:
+            raise ValueError(
+                f"points of shape {shape} cannot be mapped by a ({self.n_cg_sites},{self.n_fg_sites}) LinearMap"
+            )
+        import torch
+
+        out_t = K.torch_dtype(self._out_dtype(points))
+        p = K.as_device(points)
+        idx = self._onehot_index()
+        if idx is not None and self.handle_nans:
+            # slice map: a gather.  A NaN at a selected site is exactly the case in which the
+            # reference's NaN->0 / NaN->-1 products differ (map/core.py:226-236).
+            key = ("idx", str(p.device))
+            hit = self._dev_cache.get(key)
+            if hit is None or hit[0] is not self._standard_matrix:
+                hit = (self._standard_matrix, torch.from_numpy(idx).to(p.device))
+                self._dev_cache[key] = hit
+            out = K.slice_gather(p, hit[1], out_t)
+            if K.has_nan(out):
+                raise ValueError(
+                    "NaN handling is on and results seem to depend on NaN "
+                    "positions in input array. Check input and standard_matrix."
+                )
+            return K.like_input(out, points)
+        m = self._device_matrix(out_t, p.device)
+        if self.handle_nans and K.has_nan(p):
+            raw = K.linearmap_apply(p, m, nan_fill=0.0)
+            pushed = K.linearmap_apply(p, m, nan_fill=-1.0)
+            if not K.allclose(raw, pushed, rtol=1e-5, atol=self.nan_check_threshold):
+                raise ValueError(
+                    "NaN handling is on and results seem to depend on NaN "
+                    "positions in input array. Check input and standard_matrix."
+                )
+            return K.like_input(raw, points)
+        return K.like_input(K.linearmap_apply(p, m), points)
+
+    def flat_call(self, flattened):
+        """Apply to (n_frames, n_fg_sites*3) and return (n_frames, n_cg_sites*3)."""
+        shape = tuple(flattened.shape)
+        if len(shape) != 2:
+            raise ValueError(f"Expected array of rank 2; got array with shape {shape}.")
+        if shape[1] % self.n_dim != 0:
+            raise ValueError(f"Array of shape {shape} can't be reshaped with dim of {self.n_dim}.")
+        mapped = self(flattened.reshape((shape[0], shape[1] // self.n_dim, self.n_dim)))
+        return mapped.reshape((mapped.shape[0], mapped.shape[1] * mapped.shape[2]))
+
+    # ------------------------------------------------------------------ algebra
+    def _derive(self, matrix: np.ndarray) -> "LinearMap":
+        return self.__class__(
+            mapping=matrix, handle_nans=self.handle_nans, nan_check_threshold=self.nan_check_threshold
+        )
+
+    @property
+    def T(self) -> "LinearMap":
+        return self._derive(self.standard_matrix.T)
+
+    def __matmul__(self, lm: "LinearMap", /) -> "LinearMap":
+        return self._derive(self.standard_matrix @ lm.standard_matrix)
+
+    def __rmul__(self, c: float, /) -> "LinearMap":
+        return self._derive(c * self.standard_matrix)
+
+    def __add__(self, lm: "LinearMap", /) -> "LinearMap":
+        return self._derive(self.standard_matrix + lm.standard_matrix)
+
+    def astype(self, *args, **kwargs) -> "LinearMap":
+        """New map whose standard_matrix is ``standard_matrix.astype(*args, **kwargs)``."""
+        return self._derive(self.standard_matrix.astype(*args, **kwargs))
+
+
+class CLAMap(_Taggable):
+    """Co-local affine map  x_t -> A(y_t) x_t + b(y_t)  (reference map/core.py:320-430).
+
+    ``scale(copoints)`` returns (n_steps, n_cg_sites, n_fg_sites), ``trans(copoints)`` returns
+    (n_steps, n_cg_sites, 3).  Featurised force maps are of this type.  A map may carry a
+    fused ``apply(points, copoints)`` callable (used by ``qp_feat_linear_map`` so that the
+    per-frame matrix is never materialised); ``scale``/``trans`` remain available.
+    """
+
+    n_dim: Final = 3
+
+    def __init__(
+        self,
+        scale: Callable,
+        trans: Callable,
+        n_fg_sites: int,
+        n_cg_sites: Optional[int] = None,
+        zeroes_check: bool = True,
+        tags: Optional[Dict[str, str]] = None,
+        apply: Optional[Callable] = None,
+    ) -> None:
+        super().__init__(tags=tags)
+        if zeroes_check:
+            z = np.zeros((1, n_fg_sites, self.n_dim))
+            mapped = trjdot(z, scale(z)) + trans(z)
+            if n_cg_sites is None:
+                n_cg_sites = mapped.shape[1]
+            elif n_cg_sites != mapped.shape[1]:
+                raise ValueError("n_cg_sites did not match results from zero test")
+        elif n_cg_sites is None:
+            raise ValueError("If n_cg_sites is not set, zeroes_check must be truthy.")
+        self._n_cg_sites: Final = n_cg_sites
+        self._n_fg_sites: Final = n_fg_sites
+        self.scale: Final = scale
+        self.trans: Final = trans
+        self._apply = apply
+
+    @property
+    def n_cg_sites(self) -> int:
+        return self._n_cg_sites
+
+    @property
+    def n_fg_sites(self) -> int:
+        return self._n_fg_sites
+
+    def __call__(self, points, copoints):
+        if self._apply is not None:
+            return self._apply(points, copoints)
+        return trjdot(points, self.scale(copoints)) + self.trans(copoints)

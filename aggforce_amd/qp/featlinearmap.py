@@ -1,0 +1,285 @@
+"""Featurised (configuration-dependent) force maps (reference: qp/featlinearmap.py).
+
+The force map of cg site c is linear in user-provided per-atom features:
+``W_c(t)[a] = feat_c[t,a,:] . coef_c``.  For every site the reference builds
+    R[(t,d), f] = sum_a F[t,a,d] feat[t,a,f] + kbt * div[t,f,d],   P = R'R + l2 I
+(featlinearmap.py:361-372) and solves ``min 1/2 x'Px  s.t.  A x = b`` where the rows of A
+pin the mapped weights on a sample of frames (``_constr_arrays``, 397-459).
+
+Here R is produced directly in the (t, f, d) layout the Gram kernel K1 consumes, P comes
+from the same MFMA SYRK as the linear path, and K2 solves the constrained problem on the
+device (with a Tikhonov-regularised, iteratively refined Schur complement, because the
+sampled constraint rows are redundant by construction).  Any featuriser following the
+reference's protocol works (dense feature arrays, contracted with a batched GEMM); the
+built-in ``id_feat``/``gb_feat`` pair has a fused path that never materialises the one-hot
+feature tensor (see qp/gbfeat.py).
+"""
+from typing import Any, Callable, Generator, Iterable, List, Optional, Union
+
+import numpy as np
+from typing_extensions import TypedDict
+
+from .. import _kernels as K
+from ..constraints import Constraints, reduce_constraint_sets
+from ..distributed import all_reduce_sum_
+from ..map import CLAFTMap, CLAMap, LinearMap
+from ..trajectory import Trajectory
+from .qplinear import DEFAULT_SOLVER_OPTIONS, SolverOptions
+
+KNAME_FEATS = "feats"
+KNAME_DIVS = "divs"
+KNAME_NAMES = "names"
+
+Features = TypedDict(
+    "Features",
+    {"feats": Iterable[Any], "divs": Iterable[Any], "names": Union[Iterable[str], None]},
+)
+Featurizer = Callable[[Any, LinearMap, Constraints], Features]
+GeneralizedFeatures = Union[Features, "FeatZipper"]
+GeneralizedFeaturizer = Callable[[Any, LinearMap, Constraints], GeneralizedFeatures]
+
+
+def _cat(arrays, axis: int):
+    if any(hasattr(a, "detach") for a in arrays):
+        import torch
+
+        arrays = [K.as_device(a) for a in arrays]
+        dt = arrays[0].dtype
+        for a in arrays[1:]:
+            dt = torch.promote_types(dt, a.dtype)
+        return torch.cat([a.to(dt) for a in arrays], dim=axis)
+    return np.concatenate(arrays, axis=axis)
+
+
+class FeatZipper:
+    """Lazily concatenates the per-site output of several featurisers (featlinearmap.py:73-246).
+
+    Indexing with "feats"/"divs" gives a generator over cg sites whose items are the member
+    featurisers' arrays joined along the feature axis (axis 2 for feats, axis 1 for divs);
+    "names" gives None.  Member iterables are advanced only as items are requested.
+    """
+
+    generator_keys = frozenset([KNAME_FEATS, KNAME_DIVS])
+    name_key = KNAME_NAMES
+    _axis = {KNAME_FEATS: 2, KNAME_DIVS: 1}
+
+    def __init__(self, content: List[GeneralizedFeatures]) -> None:
+        self.reset(content)
+        self.names = None
+
+    def keys(self) -> frozenset:
+        return self.generator_keys | frozenset([KNAME_NAMES])
+
+    def reset(self, content: Iterable[GeneralizedFeatures]) -> None:
+        content = list(content)
+        self.source = {key: zip(*[member[key] for member in content]) for key in self.generator_keys}
+
+    def _generate(self, key: str) -> Generator[Any, None, None]:
+        for pieces in self.source[key]:
+            yield _cat(list(pieces), self._axis[key])
+
+    def __getitem__(self, key: str):
+        if key in self.generator_keys:
+            return self._generate(key)
+        if key == KNAME_NAMES:
+            return self.names
+        raise KeyError("Invalid key; valid keys are {}".format(self.keys()))
+
+
+def multifeaturize(featurizers: List[GeneralizedFeaturizer]) -> GeneralizedFeaturizer:
+    """Closure form of Multifeaturize (featlinearmap.py:630-671)."""
+
+    def composite(copoints, coord_map: LinearMap, constraints: Constraints) -> GeneralizedFeatures:
+        return FeatZipper(content=[f(copoints, coord_map, constraints) for f in featurizers])
+
+    return composite
+
+
+class Multifeaturize:
+    """Callable combining featurisers lazily into one (featlinearmap.py:674-745)."""
+
+    def __init__(self, featurizers: Iterable[GeneralizedFeaturizer]) -> None:
+        self.featurizers = featurizers
+
+    def __call__(self, *args, **kwargs) -> GeneralizedFeatures:
+        return FeatZipper(content=[f(*args, **kwargs) for f in self.featurizers])
+
+    def __repr__(self) -> str:
+        parts = ["{}():".format(self.__class__)]
+        for i, f in enumerate(self.featurizers):
+            parts += ["C{}:".format(i), repr(f)]
+        return " ".join(parts)
+
+    def __str__(self) -> str:
+        lines = ["{} instance:".format(self.__class__)]
+        for i, f in enumerate(self.featurizers):
+            lines.append("Callable {}:".format(i))
+            lines += ["    " + s for s in str(f).split("\n")]
+        return "\n".join(lines)
+
+
+def constraint_group_labels(n_fg_sites: int, constraints: Constraints) -> np.ndarray:
+    """int32 label of every fg site; constrained sites share a label.
+
+    Labels are numbered by the smallest member of each merged group, in ascending order.
+    (The reference's label order is CPython's set iteration order, featlinearmap.py:598-609 --
+    an arbitrary but fixed permutation of the feature columns, which does not change the
+    optimised map.)
+    """
+    groups = set(constraints) | {frozenset([x]) for x in range(n_fg_sites)}
+    ids = np.zeros(n_fg_sites, dtype=np.int32)
+    for label, members in enumerate(sorted(reduce_constraint_sets(groups), key=min)):
+        ids[list(members)] = label
+    return ids
+
+
+def id_feat(points, cmap: LinearMap, constraints: Constraints, return_ids: bool = False):
+    """One-hot constraint-group label of every fg site as features (featlinearmap.py:553-627).
+
+    Returns ``{"feats": [(T, N, G) float32] * n_cg, "divs": [(T, G, 3) zeros] * n_cg, "names":
+    None}`` -- the same array object for every cg site -- or the int32 labels if ``return_ids``.
+    """
+    ids = constraint_group_labels(cmap.n_fg_sites, constraints)
+    if return_ids:
+        return ids
+    n_frames = points.shape[0]
+    n_types = int(ids.max()) + 1 if ids.size else 0
+    feats = np.zeros((n_frames, cmap.n_fg_sites, n_types), dtype=np.float32)
+    feats[:, np.arange(cmap.n_fg_sites), ids] = 1
+    divs = np.zeros((n_frames, n_types, cmap.n_dim), dtype=np.float32)
+    return {KNAME_FEATS: [feats] * cmap.n_cg_sites, KNAME_DIVS: [divs] * cmap.n_cg_sites, KNAME_NAMES: None}
+
+
+# ----------------------------------------------------------------------------------------
+
+
+def _constraint_rows(feat_dev, cg_ind: int, M_dev, frame_idx):
+    """A[(s,c), f] = sum_a M[c,a] feat[s,a,f] on the sampled frames, and the one-hot target b
+    (reference _constr_arrays, featlinearmap.py:445-459)."""
+    import torch
+
+    sub = feat_dev[torch.as_tensor(np.asarray(frame_idx), device=feat_dev.device)].to(torch.float64)
+    mult = torch.matmul(M_dev.unsqueeze(0), sub)  # (s, n_cg, n_feat)
+    target = torch.zeros((sub.shape[0], M_dev.shape[0]), dtype=torch.float64, device=feat_dev.device)
+    target[:, cg_ind] = 1
+    return mult.reshape(-1, mult.shape[-1]).contiguous(), target.reshape(-1, 1).contiguous()
+
+
+def _site_regression(forces_dev, feat_dev, div_dev, kbt: float):
+    """R3[t,f,d] = sum_a feat[t,a,f] F[t,a,d] + kbt div[t,f,d]  -- (T, n_feat, 3), contiguous."""
+    import torch
+
+    dt = torch.promote_types(torch.promote_types(forces_dev.dtype, feat_dev.dtype), div_dev.dtype)
+    r3 = torch.bmm(feat_dev.to(dt).transpose(1, 2), forces_dev.to(dt))
+    r3.add_(div_dev.to(dt), alpha=float(kbt))
+    return r3.contiguous()
+
+
+def qp_feat_linear_map(
+    traj: Trajectory,
+    coord_map: LinearMap,
+    featurizer: Featurizer,
+    kbt: float,
+    n_constraint_frames: int = 20,
+    constraints: Union[None, Constraints] = None,
+    sparse: bool = True,  # noqa: ARG001  (matrices stay dense on the device)
+    solver_args: SolverOptions = DEFAULT_SOLVER_OPTIONS,  # noqa: ARG001  (exact solve)
+    l2_regularization: float = 1e1,
+    *,
+    frame_indices: Optional[List[np.ndarray]] = None,
+    rng=None,
+    comm=None,
+) -> CLAFTMap:
+    """Force map linear in features, minimising the mean squared mapped force
+    (reference featlinearmap.py:249-394; same arguments).
+
+    ``featurizer(coords, coord_map, constraints)`` returns {"feats": per-site (T, N, n_feat),
+    "divs": per-site (T, n_feat, 3), "names"}.  Extras: ``frame_indices`` (one index array per
+    cg site) or ``rng`` (numpy Generator) make the sampled constraint frames reproducible --
+    the reference draws them from an unseeded generator (featlinearmap.py:445); ``comm`` shards
+    frames over ranks (the sampled constraint frames are then taken from each rank's shard and
+    must be given identically on every rank through ``frame_indices`` of rank-local frames).
+
+    Returns ``CLAFTMap(coord_map, CLAMap)`` with tags {"feat_names", "coef_list"}.
+    """
+    import torch
+
+    if constraints is None:
+        constraints = set()
+    fused = getattr(featurizer, "fused_fit", None)
+    if fused is not None:
+        return fused(traj, coord_map, kbt, n_constraint_frames, constraints, l2_regularization,
+                     frame_indices, rng, comm)
+    feat_results = featurizer(traj.coords, coord_map, constraints)
+    feats, divs, names = (feat_results[k] for k in (KNAME_FEATS, KNAME_DIVS, KNAME_NAMES))
+    forces = K.as_device(traj.forces)
+    dev = forces.device
+    M_dev = torch.from_numpy(np.asarray(coord_map.standard_matrix, dtype=np.float64)).to(dev)
+    gen = np.random.default_rng() if rng is None else rng
+    coefs: List[np.ndarray] = []
+    used_frames: List[np.ndarray] = []
+    for ind, (feat, div) in enumerate(zip(feats, divs)):
+        feat_dev = K.as_device(feat)
+        div_dev = K.as_device(div)
+        if frame_indices is not None:
+            idx = np.asarray(frame_indices[ind])
+        else:
+            idx = gen.choice(feat_dev.shape[0], size=n_constraint_frames, replace=False)
+        used_frames.append(idx)
+        A, b = _constraint_rows(feat_dev, ind, M_dev, idx)
+        r3 = _site_regression(forces, feat_dev, div_dev, kbt)
+        G = K.gram(r3, None, None, r3.shape[1], r3.dtype)
+        all_reduce_sum_(G, comm)
+        X, stats = K.eq_qp_solve(G, float(l2_regularization), None, A, b, schur_reg=1e-12, n_refine=3)
+        st = stats.cpu().numpy()
+        if st[0] != 0 or not np.isfinite(st[1]):
+            raise ValueError("Map optimization failed.")
+        coefs.append(X[0].cpu().numpy())
+        del feat_dev, div_dev, r3, G
+    force_map = _feat_linear_mapping(
+        featurizer=featurizer,
+        coefs=coefs,
+        mapping=coord_map,
+        constraints=constraints,
+        tags={"feat_names": names, "coef_list": coefs, "constraint_frames": used_frames},
+    )
+    return CLAFTMap(coord_map=coord_map, force_map=force_map)
+
+
+def _feat_linear_mapping(featurizer, coefs: List[np.ndarray], mapping: LinearMap, constraints, **kwargs) -> CLAMap:
+    """CLAMap of a feature-linear map (reference featlinearmap.py:462-530).
+
+    ``scale``/``trans`` follow the reference (each re-runs the featuriser).  ``apply`` is the
+    fused form used when the map is called: per site
+    ``out[t,c,:] = coef_c . (feat_c[t]' F[t] + div_c[t])`` -- note: no kbt on the divergence
+    term here, exactly as in the reference's trans_f (featlinearmap.py:517-520).
+    """
+    import torch
+
+    def _weights(seq, coefs_, expr):
+        out = []
+        for arr, c in zip(seq, coefs_):
+            a = K.as_device(arr)
+            out.append(torch.einsum(expr, a.to(torch.float64), torch.from_numpy(np.asarray(c, dtype=np.float64)).to(a.device)))
+        return torch.stack(out, dim=1)
+
+    def scale_f(copoints):
+        feats = featurizer(copoints, mapping, constraints)[KNAME_FEATS]
+        return K.like_input(_weights(feats, coefs, "...ij,j->...i"), copoints)
+
+    def trans_f(copoints):
+        divs = featurizer(copoints, mapping, constraints)[KNAME_DIVS]
+        return K.like_input(_weights(divs, coefs, "tij,i->tj"), copoints)
+
+    def apply_f(points, copoints):
+        res = featurizer(copoints, mapping, constraints)
+        F = K.as_device(points)
+        cols = []
+        for feat, div, c in zip(res[KNAME_FEATS], res[KNAME_DIVS], coefs):
+            y = _site_regression(F, K.as_device(feat), K.as_device(div), 1.0).to(torch.float64)
+            cvec = torch.from_numpy(np.asarray(c, dtype=np.float64)).to(F.device)
+            cols.append(torch.einsum("tfd,f->td", y, cvec))
+        return K.like_input(torch.stack(cols, dim=1), points)
+
+    return CLAMap(scale=scale_f, trans=trans_f, n_fg_sites=mapping.n_fg_sites, zeroes_check=True,
+                  apply=apply_f, **kwargs)

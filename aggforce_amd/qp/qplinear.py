@@ -1,0 +1,128 @@
+"""Optimal linear force maps (reference: qp/qplinear.py).
+
+For every coarse-grained site i the reference solves, with OSQP,
+    x_i = argmin 1/2 x'(C'F'FC + l2 C'C) x   s.t.  (M C) x = e_i,      W_i = C x_i
+(qplinear.py:66-88).  All sites share P and A, so here the Gram matrix is built once on
+the GPU (K1, MFMA SYRK fused with the constraint-group sums), optionally summed over
+frame-sharded ranks with one all-reduce, and all n_cg problems are solved exactly by one
+on-device factorisation (K2).
+"""
+from typing import Optional, Union
+
+import numpy as np
+from typing_extensions import TypedDict
+
+from .. import _kernels as K
+from ..constraints import Constraints, group_layout, groups_csr, reduce_constraint_sets
+from ..constraints.tools import constraint_lookup_dict
+from ..distributed import all_reduce_sum_
+from ..map import LinearMap, SeperableTMap
+from ..trajectory import ForcesTrajectory
+
+SolverOptions = TypedDict(
+    "SolverOptions",
+    {"solver": str, "eps_abs": float, "max_iter": int, "polish": bool, "polish_refine_iter": int},
+    total=False,
+)
+# Kept for signature compatibility (qplinear.py:21-27).  The on-device solve is exact, so the
+# OSQP options are accepted and ignored.
+DEFAULT_SOLVER_OPTIONS: SolverOptions = {
+    "solver": "osqp",
+    "eps_abs": 1e-7,
+    "max_iter": int(1e3),
+    "polish": True,
+    "polish_refine_iter": 10,
+}
+
+
+def qp_form(target):
+    """(n_steps, n_sites, 3) -> (n_steps*3, n_sites), rows ordered (step, dim) (qplinear.py:91-103).
+
+    Host/array helper kept for API compatibility; the GPU path never materialises this copy.
+    """
+    if hasattr(target, "transpose") and hasattr(target, "detach"):
+        mixed = target.transpose(1, 2)
+        return mixed.reshape(mixed.shape[0] * mixed.shape[1], -1)
+    mixed = np.swapaxes(target, 1, 2)
+    return np.reshape(mixed, (mixed.shape[0] * mixed.shape[1], -1))
+
+
+def make_bond_constraint_matrix(n_sites: int, constraints: Constraints) -> np.ndarray:
+    """Dense (n_sites, n_reduced) 0/1 matrix expanding reduced coefficients (qplinear.py:106-164)."""
+    goa, n_red = group_layout(n_sites, constraints)
+    mat = np.zeros((n_sites, n_red))
+    mat[np.arange(n_sites), goa] = 1
+    return mat
+
+
+def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndarray, what: str = "Map optimization"):
+    """Run K2 for all rows of A at once; returns (X device (m, n), stats host)."""
+    import torch
+
+    dev = G.device
+    A = torch.from_numpy(np.ascontiguousarray(A_host, dtype=np.float64)).to(dev)
+    X, stats = K.eq_qp_solve(G, l2_regularization, l2_diag, A)
+    st = stats.cpu().numpy()
+    if st[0] != 0 or not np.isfinite(st[1]):
+        raise ValueError(
+            f"{what} failed: the shifted normal matrix is not positive definite "
+            f"(pivot {int(st[0])}, constraint residual {st[1]:.3e}). "
+            "The problem is under-determined; add frames or use l2_regularization > 0."
+        )
+    return X, st
+
+
+def qp_linear_map(
+    traj: ForcesTrajectory,
+    coord_map: LinearMap,
+    constraints: Union[None, Constraints] = None,
+    l2_regularization: float = 0.0,
+    solver_args: SolverOptions = DEFAULT_SOLVER_OPTIONS,  # noqa: ARG001  (exact solve: unused)
+    *,
+    gram_dtype=None,
+    comm=None,
+) -> SeperableTMap:
+    """Force map minimising the mean squared mapped force (reference qplinear.py:30-88).
+
+    Arguments as in the reference: ``traj`` supplies the forces (n_frames, n_fg, 3),
+    ``coord_map`` the configurational map, ``constraints`` a set of frozensets of
+    constrained fg indices (atoms of a merged group share one coefficient),
+    ``l2_regularization`` penalises the norm of the expanded map.  Extras:
+    ``gram_dtype`` (np.float32/np.float64; default: the dtype of the forces) is the
+    arithmetic type of the Gram products -- float64 reproduces the reference exactly for
+    float32 forces, float32 is the fast MFMA path; ``comm`` is a torch.distributed process
+    group (or True for the default group) over which frames are sharded.
+
+    Returns ``SeperableTMap(coord_map, LinearMap(W))`` with ``W`` float64 (n_cg, n_fg).
+    """
+    import torch
+
+    if constraints is None:
+        constraints = set()
+    forces = K.as_device(traj.forces)
+    dev = forces.device
+    n_fg = coord_map.n_fg_sites
+    if forces.shape[1] != n_fg:
+        raise ValueError(f"forces have {forces.shape[1]} sites but coord_map expects {n_fg}")
+    goa, n_red = group_layout(n_fg, constraints)
+    grp_ptr = grp_atoms = None
+    if n_red != n_fg:
+        ptr_h, atoms_h = groups_csr(goa, n_red)
+        grp_ptr = torch.from_numpy(ptr_h).to(dev)
+        grp_atoms = torch.from_numpy(atoms_h).to(dev)
+    cdt = forces.dtype if gram_dtype is None else K.torch_dtype(gram_dtype)
+    if forces.dtype == torch.float64:
+        cdt = torch.float64
+    G = K.gram(forces, grp_ptr, grp_atoms, n_red, cdt)
+    all_reduce_sum_(G, comm)
+    # A = M @ C and diag(C'C) without forming C
+    M = np.asarray(coord_map.standard_matrix, dtype=np.float64)
+    A = np.zeros((M.shape[0], n_red))
+    np.add.at(A.T, goa, M.T)
+    sizes = torch.from_numpy(np.bincount(goa, minlength=n_red).astype(np.float64)).to(dev)
+    X, _ = solve_constrained_maps(G, float(l2_regularization), sizes, A)
+    goa_dev = torch.from_numpy(goa).to(dev)
+    W = K.expand_map(X, goa_dev, n_fg)
+    force_map = LinearMap(W.cpu().numpy())
+    force_map._dev_cache[(torch.float64, str(dev))] = (force_map.standard_matrix, W)
+    return SeperableTMap(coord_map=coord_map, force_map=force_map)

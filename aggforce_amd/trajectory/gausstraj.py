@@ -1,0 +1,140 @@
+"""Gaussian augmenters with closed-form log-gradients, computed on the GPU.
+
+``CondNormal`` replaces the reference's JAX ``JCondNormal`` (trajectory/jaxgausstraj.py:
+99-402) for the case the noised maps use: scalar covariance ``cov = var * I`` and a linear
+premap ``M`` (``None`` = identity):
+    y = M x + sqrt(var) eps,   grad_y log g = -(y - M x)/var,   grad_x log g = M'(y - M x)/var.
+The JAX autodiff/vmap machinery reduces to these expressions (checked in the reference
+itself against SimpleCondNormal for M = I, tests/test_simplegausstraj.py:20-29).
+``SimpleCondNormal`` mirrors trajectory/simplegausstraj.py (identity premap).
+
+Random numbers: JAX's threefry stream cannot be reproduced without JAX, so parity of the
+noised path is defined conditional on the noise: tests inject ``eps``; production draws
+from Philox4x32-10 keyed by (seed, global frame index, site, dim) on the device, which is
+independent of how frames are sharded over GPUs.
+"""
+from typing import Optional, Tuple
+
+import numpy as np
+
+from .. import _kernels as K
+from ..map.core import LinearMap
+from .augment import Augmenter
+
+
+class CondNormal(Augmenter):
+    """y ~ N(M x, var I) with a LinearMap (or matrix) premap M."""
+
+    n_dim = 3
+
+    def __init__(
+        self,
+        var: float,
+        premap=None,
+        seed: Optional[int] = None,
+        dtype=np.float32,
+        frame_offset: int = 0,
+    ) -> None:
+        if not var > 0:
+            raise ValueError("var must be positive")
+        self.var = float(var)
+        if premap is None or isinstance(premap, LinearMap):
+            self.premap = premap
+        else:
+            self.premap = LinearMap(np.asarray(premap), handle_nans=False)
+        self.seed = int(np.random.default_rng().integers(0, int(1e6))) if seed is None else int(seed)
+        self.dtype = np.dtype(dtype)
+        self.frame_offset = int(frame_offset)
+        self._calls = 0       # every sample()/augment call uses a fresh Philox stream offset
+        self._noise_queue = []  # injected standard-normal noise (tests / reproducibility)
+
+    # ---- noise injection ------------------------------------------------------------
+    def inject_noise(self, *eps) -> "CondNormal":
+        """Queue standard-normal arrays (n_frames, n_generated, 3) used by the next draws."""
+        self._noise_queue.extend(eps)
+        return self
+
+    def _matrix(self, n_src: int) -> np.ndarray:
+        if self.premap is None:
+            return np.eye(n_src, dtype=self.dtype)
+        return self.premap.standard_matrix.astype(self.dtype, copy=False)
+
+    def _next_noise(self, device):
+        if self._noise_queue:
+            return K.as_device(self._noise_queue.pop(0), K.torch_dtype(self.dtype))
+        return None
+
+    def _mean(self, src, m_dev, M: np.ndarray):
+        import torch
+
+        tdt = K.torch_dtype(self.dtype)
+        if self.premap is not None and self.premap._onehot_index() is not None:
+            idx = torch.from_numpy(self.premap._onehot_index()).to(src.device)
+            return K.slice_gather(src, idx, tdt)
+        return K.linearmap_apply(src, m_dev)
+
+    # ---- Augmenter interface ----------------------------------------------------------
+    def augment_trajectory(self, coords, forces, kbt: float) -> Tuple:
+        """Fused K5 pass: returns ([x; y], [F + kbt M' r; -kbt r]) with r = (y - M x)/var."""
+        import torch
+
+        c = K.as_device(coords)
+        f = K.as_device(forces, c.dtype)
+        M = self._matrix(c.shape[1])
+        m_dev = torch.from_numpy(np.ascontiguousarray(M)).to(c.device)
+        mean = self._mean(c, m_dev, M)
+        noise = self._next_noise(c.device)
+        stream_seed = self.seed + 0x9E3779B97F4A7C15 * self._calls
+        self._calls += 1
+        oc, of = K.condnormal_augment(c, f, m_dev, mean, self.var, kbt, noise, stream_seed, self.frame_offset)
+        return K.like_input(oc, coords), K.like_input(of, coords)
+
+    def sample(self, source):
+        import torch
+
+        c = K.as_device(source)
+        M = self._matrix(c.shape[1])
+        m_dev = torch.from_numpy(np.ascontiguousarray(M)).to(c.device)
+        zeros = torch.zeros_like(c)
+        mean = self._mean(c, m_dev, M)
+        noise = self._next_noise(c.device)
+        stream_seed = self.seed + 0x9E3779B97F4A7C15 * self._calls
+        self._calls += 1
+        oc, _ = K.condnormal_augment(c, zeros, m_dev, mean, self.var, 0.0, noise, stream_seed, self.frame_offset)
+        return K.like_input(oc[:, c.shape[1]:, :].to(K.torch_dtype(self.dtype)).contiguous(), source)
+
+    def log_gradient(self, source, generated) -> Tuple:
+        import torch
+
+        tdt = K.torch_dtype(self.dtype)
+        c = K.as_device(source)
+        g = K.as_device(generated, tdt)
+        M = self._matrix(c.shape[1])
+        m_dev = torch.from_numpy(np.ascontiguousarray(M)).to(c.device)
+        mean = self._mean(c, m_dev, M)
+        r = (g - mean) / self.var
+        mt = torch.from_numpy(np.ascontiguousarray(M.T)).to(c.device)
+        d_src = K.linearmap_apply(r.contiguous(), mt)
+        return K.like_input(d_src, source), K.like_input(-r, source)
+
+    def astype(self, dtype, *args, **kwargs) -> "CondNormal":  # noqa: ARG002
+        new = self.__class__(var=self.var, premap=self.premap, seed=self.seed, dtype=dtype,
+                             frame_offset=self.frame_offset)
+        new._calls = self._calls
+        new._noise_queue = list(self._noise_queue)
+        return new
+
+    def to_SimpleCondNormal(self) -> "SimpleCondNormal":
+        if self.premap is not None and not self.premap.close_to_identity():
+            raise ValueError("Only can convert to SimpleCondNormal for identity premap.")
+        return SimpleCondNormal(var=self.var, dtype=self.dtype)
+
+
+class SimpleCondNormal(CondNormal):
+    """Identity-premap special case (reference trajectory/simplegausstraj.py:13-137)."""
+
+    def __init__(self, var: float, seed: Optional[int] = None, dtype=np.float32) -> None:
+        super().__init__(var=var, premap=None, seed=seed, dtype=dtype)
+
+    def astype(self, dtype, *args, **kwargs) -> "SimpleCondNormal":  # noqa: ARG002
+        return self.__class__(var=self.var, dtype=dtype)

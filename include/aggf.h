@@ -1,0 +1,174 @@
+/*
+ * libaggf -- C ABI of the MI355X (gfx950) implementation of the aggforce
+ * force-map optimisation hot path.
+ *
+ * The reference (noegroup/aggforce) is pure Python and has no FFI of its own: its
+ * boundary for this path is a set of NumPy call sites.  Each entry point below
+ * names the reference call site(s) it replaces (paths relative to
+ * /root/reference/src/aggforce).  INTEGRATION.md shows the ctypes stub a
+ * maintainer of the reference would add at each of those sites.
+ *
+ * Conventions
+ *  - every function returns 0 (AGGF_OK) or a negative AGGF_ERR_* code;
+ *    aggf_last_error() returns a thread-local message for the last failure;
+ *  - all array pointers are CALLER-OWNED DEVICE pointers (HBM), never retained
+ *    or freed by the library; arrays are dense, C-contiguous ("row-major");
+ *  - scratch memory is caller-provided: ask aggf_*_workspace_bytes() first;
+ *  - `stream` is a hipStream_t passed as void*; calls are asynchronous on it and
+ *    never synchronise the device; no hidden global state;
+ *  - dtype codes: AGGF_F32 / AGGF_F64.
+ */
+#ifndef AGGF_H
+#define AGGF_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define AGGF_VERSION 100 /* 0.1.0 */
+
+#define AGGF_OK 0
+#define AGGF_ERR_ARG (-1)       /* bad argument (shape, dtype, alignment, NULL) */
+#define AGGF_ERR_HIP (-2)       /* HIP runtime error */
+#define AGGF_ERR_WORKSPACE (-3) /* workspace too small */
+
+#define AGGF_F32 0
+#define AGGF_F64 1
+
+/* nan_mode of aggf_linearmap_apply */
+#define AGGF_NAN_PROPAGATE 0 /* plain product (LinearMap(handle_nans=False)) */
+#define AGGF_NAN_REPLACE 1   /* NaN inputs are read as `nan_fill` */
+
+int aggf_version(void);
+const char* aggf_last_error(void);
+/* number of compute units of the current device; free/total HBM bytes */
+int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes);
+
+/* ---------------------------------------------------------------------------
+ * K1  Gram / normal matrix of the constraint-reduced forces.
+ *
+ * Replaces qp/qplinear.py:66-71:  qp_form(forces) (91-103), reshaped_fs @ con_mat
+ * (70) and reg_mat.T @ reg_mat (71):
+ *     G[j,k] = sum_{t,d} (sum_{a in g_j} F[t,a,d]) (sum_{b in g_k} F[t,b,d])
+ * F: (T, N, 3) in `in_dtype`.  Constraint groups are given in CSR form
+ * (grp_ptr[n_red+1], grp_atoms[N]) -- column j of the reference's con_mat
+ * (make_bond_constraint_matrix, qplinear.py:147-164) has ones at
+ * grp_atoms[grp_ptr[j] .. grp_ptr[j+1]); pass NULL,NULL for no constraints
+ * (then n_red must equal N).  Products are formed in `compute_dtype`
+ * (AGGF_F64 reproduces the reference, whose con_mat is float64 even for float32
+ * forces; AGGF_F32 uses fp32 MFMA with partial sums combined in fp64).
+ * G: (n_red, n_red) float64, full symmetric matrix; accumulate != 0 adds to it
+ * (frame chunks, cross-validation folds).  Partial sums are combined in a fixed
+ * order: two runs are bit-identical.
+ * ------------------------------------------------------------------------- */
+size_t aggf_gram_workspace_bytes(int64_t T, int32_t N, int32_t n_red, int in_dtype,
+                                 int compute_dtype, int has_groups);
+int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+              const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red, double* G,
+              int accumulate, void* ws, size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K2  Equality-constrained least squares shared by all coarse-grained sites.
+ *
+ * Replaces the solver loop qp/qplinear.py:76-86 (and featlinearmap.py:370-381):
+ * for every right-hand side i
+ *     x_i = argmin 1/2 x'(G + l2*diag(l2_diag)) x   s.t.  A x = B[:, i]
+ * (what qpsolvers.solve_qp(P, q=0, A, b) is asked for).  One scaled, shifted
+ * Cholesky factorisation P~ = P/s + A'A serves all right-hand sides; the Schur
+ * complement A P~^-1 A' is factorised the same way; one refinement step on the
+ * constraint residual follows.
+ * G: (n, n) float64 (not modified).  l2_diag: n float64 or NULL (= ones).
+ * A: (m, n) float64.  B: (m, nrhs) float64 or NULL (= identity, nrhs must equal m).
+ * X: (nrhs, n) float64, row i = x_i.
+ * schur_reg: 0 for full-row-rank A; > 0 adds schur_reg * mean(diag) to the Schur
+ * complement so that redundant (consistent) constraint rows -- the sampled rows of
+ * featlinearmap._constr_arrays -- can be factorised; the n_refine refinement steps
+ * x -= P~^-1 A' S^-1 (A x - b) then remove the bias of that shift.
+ * stats (device, 4 doubles): [0] 0 if ok, else 1-based index of the first
+ * non-positive pivot (k for P~, n+k for the Schur complement); [1] max |A x - b|
+ * after refinement; [2] max |A x - b| before refinement; [3] scale s.
+ * ------------------------------------------------------------------------- */
+size_t aggf_eq_qp_workspace_bytes(int32_t n, int32_t m, int32_t nrhs);
+int aggf_eq_qp_solve(const double* G, int32_t n, double l2, const double* l2_diag,
+                     const double* A, int32_t m, const double* B, int32_t nrhs,
+                     double schur_reg, int32_t n_refine, double* X, double* stats, void* ws,
+                     size_t ws_bytes, void* stream);
+
+/* W[i, a] = X[i, group_of_atom[a]]  -- `con_mat @ gen_map`, qp/qplinear.py:86.
+ * X: (n_rows, n_red) float64; group_of_atom: N int32; W: (n_rows, N) float64. */
+int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
+                    const int32_t* group_of_atom, int32_t N, double* W, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K3  LinearMap apply:  out[t,c,d] = sum_a M[c,a] * P[t,a,d]
+ *
+ * Replaces util.trjdot (util.py:119-125) as called by LinearMap.__call__
+ * (map/core.py:219-240).  P: (T, N, 3) in `in_dtype`; M: (n_cg, N) and out:
+ * (T, n_cg, 3) in `out_dtype` (NumPy's promotion of points and matrix).
+ * nan_mode AGGF_NAN_REPLACE reads NaN inputs as nan_fill (the reference's two
+ * passes with NaN->0 and NaN->-1, map/core.py:226-229).  If sumsq != NULL the
+ * sum of squares of `out` is written there (float64; agg.force_smoothness,
+ * agg.py:297, is sumsq / (3 T n_cg)), combined in a fixed order.
+ * ------------------------------------------------------------------------- */
+size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg);
+int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype, const void* M,
+                         int32_t n_cg, int out_dtype, int nan_mode, double nan_fill, void* out,
+                         double* sumsq, void* ws, size_t ws_bytes, void* stream);
+
+/* K3b  one-hot rows (slice maps): out[t,c,:] = P[t, idx[c], :], converted to
+ * out_dtype.  Same call site as K3 when every row of M is a unit vector. */
+int aggf_slice_gather(const void* P, int64_t T, int32_t N, int in_dtype, const int32_t* idx,
+                      int32_t n_cg, int out_dtype, void* out, void* stream);
+
+/* flag[0] = 1 if any element of x is NaN (map/core.py:13-16 _has_nans); flag must be
+ * zeroed by the caller. */
+int aggf_has_nan(const void* x, int64_t count, int dtype, int32_t* flag, void* stream);
+/* flag[0] = 1 unless |a-b| <= atol + rtol*|b| everywhere (np.allclose, map/core.py:230-232);
+ * flag must be zeroed by the caller. */
+int aggf_not_close(const void* a, const void* b, int64_t count, int dtype, double rtol,
+                   double atol, int32_t* flag, void* stream);
+/* out[0] = sum of squares of x in float64, fixed summation order (agg.py:297).
+ * ws: at least aggf_sumsq_workspace_bytes() bytes. */
+size_t aggf_sumsq_workspace_bytes(void);
+int aggf_sumsq(const void* x, int64_t count, int dtype, double* out, void* ws, size_t ws_bytes,
+               void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K5  Gaussian augmentation of a trajectory (noised maps).
+ *
+ * Replaces JCondNormal.sample / .log_gradient with cov = var*I and a LinearMap
+ * premap (trajectory/jaxgausstraj.py:213-284, closed form of the autodiff) and
+ * AugmentedTrajectory._augment (trajectory/core.py:382-390):
+ *     y = M x + sqrt(var) eps,  r = (y - M x)/var,
+ *     out_coords = [x ; y],  out_forces = [F + kbt M' r ; -kbt r]   (T, N+n_cg, 3)
+ * coords/forces: (T, N, 3) in traj_dtype; M: (n_cg, N), mean = M x: (T, n_cg, 3) and
+ * noise: (T, n_cg, 3) in aug_dtype (the augmenter's dtype, float32 by default in
+ * the reference); noise == NULL draws eps from Philox4x32-10 keyed by
+ * (seed, frame_offset + t, site, dim), independent of sharding.  Outputs are in
+ * NumPy's promotion of the two dtypes.  `mean` comes from aggf_linearmap_apply /
+ * aggf_slice_gather with out_dtype = aug_dtype.
+ * ------------------------------------------------------------------------- */
+int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, int32_t N,
+                            int traj_dtype, const void* M, int32_t n_cg, int aug_dtype,
+                            const void* mean, const void* noise, uint64_t seed,
+                            int64_t frame_offset, double var, double kbt, void* out_coords,
+                            void* out_forces, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Synthetic trajectories for benchmarks and full-size property tests (no
+ * reference counterpart).  out[t,a,d] = mean + sigma * z(seed, frame_offset+t, a, d)
+ * with z a counter-based standard normal (Philox4x32-10 + Box-Muller), so any
+ * sharding of the frame axis reproduces the same data.  If lattice != 0 the mean
+ * of atom a is its position on a cubic lattice with that spacing (coordinates).
+ * ------------------------------------------------------------------------- */
+int aggf_synth_normal(void* out, int64_t T, int32_t N, int dtype, uint64_t seed,
+                      int64_t frame_offset, double mean, double sigma, double lattice,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* AGGF_H */

@@ -1,0 +1,194 @@
+"""CPU: host-side logic of the product (no compute kernels run here), the C ABI export check,
+and the frame-sharded all-reduce path under gloo with world_size 2."""
+import ctypes
+import os
+import re
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import aggforce_amd
+from aggforce_amd import LinearMap
+from aggforce_amd.constraints import group_layout, groups_csr, reduce_constraint_sets, constraint_lookup_dict
+from aggforce_amd.qp import make_bond_constraint_matrix, constraint_aware_uni_map, id_feat, FeatZipper, Multifeaturize
+from aggforce_amd.qp.featlinearmap import constraint_group_labels
+from aggforce_amd.map import smear_map
+from aggforce_amd.util import Curry, curry, flatten
+from aggforce_amd import _lib
+from oracle import aggforce_oracle as orc
+from conftest import ROOT, cons_from_array
+
+CONS_CASES = [
+    set(),
+    {frozenset([0, 1])},
+    {frozenset([0, 1]), frozenset([1, 2]), frozenset([2, 3]), frozenset([18, 20]), frozenset([20, 23])},
+    {frozenset([4, 5]), frozenset([5, 9]), frozenset([9, 4]), frozenset([10, 11, 14]), frozenset([14, 15])},
+    {frozenset([7, 3]), frozenset([22, 3]), frozenset([8, 21])},
+]
+
+
+@pytest.mark.parametrize("cons", CONS_CASES)
+def test_constraint_layout_matches_oracle(cons):
+    n = 24
+    assert reduce_constraint_sets(cons) == orc.reduce_constraint_sets(cons)
+    assert constraint_lookup_dict(reduce_constraint_sets(cons)) == orc.constraint_lookup_dict(
+        orc.reduce_constraint_sets(cons))
+    C = make_bond_constraint_matrix(n, cons)
+    assert np.array_equal(C, orc.make_bond_constraint_matrix(n, cons))
+    goa, n_red = group_layout(n, cons)
+    assert C.shape == (n, n_red) and np.all(C[np.arange(n), goa] == 1)
+    ptr, atoms = groups_csr(goa, n_red)
+    for g in range(n_red):
+        assert sorted(atoms[ptr[g]:ptr[g + 1]]) == list(np.nonzero(C[:, g])[0])
+
+
+def test_layout_rejects_bad_index():
+    with pytest.raises(ValueError):
+        group_layout(4, {frozenset([1, 9])})
+
+
+def test_linearmap_constructor_and_algebra(golden):
+    g = golden("g3_linearmap.npz")
+    lm = LinearMap(g["mat"])
+    assert lm.n_cg_sites == 5 and lm.n_fg_sites == 15
+    assert np.array_equal(LinearMap([[0, 2, 3], [4]], n_fg_sites=6).standard_matrix, g["list_ctor"])
+    other = LinearMap(g["other"])
+    assert np.allclose((lm @ other).standard_matrix, g["matmul"], rtol=0, atol=1e-14)
+    assert np.array_equal((2.5 * lm).standard_matrix, g["rmul"])
+    assert np.array_equal((lm + lm).standard_matrix, g["add"])
+    assert np.array_equal(lm.T.standard_matrix, g["T"])
+    a32 = lm.astype(np.float32)
+    assert a32.standard_matrix.dtype == np.float32 and np.array_equal(a32.standard_matrix, g["astype32"])
+    with pytest.raises(ValueError):
+        LinearMap(g["mat"], n_fg_sites=15)
+    with pytest.raises(ValueError):
+        LinearMap([[0], [1]])
+    with pytest.raises(ValueError):
+        LinearMap(np.array([[np.nan, 1.0]]))
+    LinearMap(np.array([[np.nan, 1.0]]), handle_nans=False)
+    assert LinearMap(np.eye(4)).close_to_identity() and not lm.close_to_identity()
+    assert LinearMap([[0, 2, 3], [4]], n_fg_sites=6).participating_fg == [[0, 2, 3], [4]]
+    with pytest.raises(ValueError):
+        lm.flat_call(np.zeros((2, 15, 3)))
+    with pytest.raises(ValueError):
+        lm.flat_call(np.zeros((2, 44)))
+
+
+def test_uni_map_matches_saved_cln025(golden):
+    g = golden("g4_cln025.npz")
+    cmap = LinearMap([[int(i)] for i in g["ca"]], n_fg_sites=int(g["n_atoms"]))
+    tm = constraint_aware_uni_map(traj=None, coord_map=cmap, constraints=cons_from_array(g["pairs"]))
+    assert ((tm.force_map.standard_matrix - g["basic"]) ** 2).sum() < 1e-5
+    assert np.array_equal(make_bond_constraint_matrix(175, cons_from_array(g["pairs"])), g["con_mat"])
+
+
+def test_id_feat_is_a_relabelling_of_the_reference(golden):
+    g = golden("g5_feat_id.npz")
+    cons = cons_from_array(g["cons"])
+    cmap = LinearMap(g["coord_matrix"])
+    ids = id_feat(g["coords"], cmap, cons, return_ids=True)
+    ref = g["ids"]
+    assert ids.dtype == np.int32 and len(set(zip(ids, ref))) == len(set(ids)) == len(set(ref))
+    out = id_feat(g["coords"], cmap, cons)
+    f = out["feats"]
+    assert len(f) == 4 and f[0] is f[3] and f[0].shape == (48, 12, len(set(ids))) and f[0].dtype == np.float32
+    assert np.all(f[0].sum(axis=2) == 1) and np.all(f[0][0, np.arange(12), ids] == 1)
+    assert np.array_equal(constraint_group_labels(5, {frozenset([3, 1])}), [0, 1, 2, 1, 3])
+    z = Multifeaturize([id_feat, id_feat])(g["coords"], cmap, cons)
+    assert isinstance(z, FeatZipper) and z["names"] is None
+    joined = list(z["feats"])
+    assert len(joined) == 4 and joined[0].shape == (48, 12, 2 * f[0].shape[2])
+    assert list(z["divs"])[0].shape == (48, 2 * f[0].shape[2], 3)
+    with pytest.raises(KeyError):
+        z["nope"]
+    assert np.array_equal(smear_map(reduce_constraint_sets(cons), 12, return_mapping_matrix=True), g["smear"])
+
+
+def test_curry_helpers():
+    def f(a, b, c=0, d=0):
+        return (a, b, c, d)
+
+    assert curry(f, 2, d=4)(1, c=3) == (1, 2, 3, 4)
+    cu = Curry(f, 2, d=4)
+    assert cu(1, c=3) == (1, 2, 3, 4) and "Kw:" in repr(cu) and "kwargs:" in str(cu)
+    assert flatten([[1, 2], [3]]) == [1, 2, 3]
+
+
+def test_c_abi_exports_every_declared_symbol():
+    """libaggf.so loads without a GPU and exports everything include/aggf.h declares."""
+    header = open(os.path.join(ROOT, "include", "aggf.h")).read()
+    declared = set(re.findall(r"\b(aggf_[a-z0-9_]+)\s*\(", header))
+    assert len(declared) >= 15
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), f"{name} declared in aggf.h but not exported"
+    assert declared == set(_lib.PROTOTYPES), "ctypes prototypes out of sync with aggf.h"
+    loaded = _lib.load()
+    assert loaded.aggf_version() == 100
+    assert loaded.aggf_gram_workspace_bytes(1000, 256, 256, _lib.F64, _lib.F64, 0) > 0
+    assert loaded.aggf_eq_qp_workspace_bytes(100, 10, 10) > 0
+
+
+@pytest.mark.skipif(torch.cuda.is_available(), reason="checks the no-GPU failure mode")
+def test_compute_fails_loudly_without_gpu():
+    lm = LinearMap(np.eye(3))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        lm(np.zeros((2, 3, 3)))
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        aggforce_amd.project_forces(np.zeros((4, 3, 3)), np.ones((4, 3, 3)), lm, constrained_inds=set())
+
+
+# ------------------------------------------------------------------ N > 1 path on CPU (gloo)
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _shard_worker(rank, world, port, T, N, seed, out_dir):
+    import torch.distributed as dist
+    from aggforce_amd.distributed import all_reduce_sum_, frame_shard, world_size
+
+    sys.path.insert(0, ROOT)
+    from oracle import aggforce_oracle as o
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    rng = np.random.default_rng(seed)
+    forces = rng.standard_normal((T, N, 3))
+    b, e = frame_shard(T, rank, world)
+    # per-shard Gram from the oracle (checker) -> product's reduction path
+    local = o.qp_form(forces[b:e])
+    G = torch.from_numpy(local.T @ local)
+    all_reduce_sum_(G, True)
+    assert world_size(True) == world
+    acc = torch.tensor([float((forces[b:e] ** 2).sum()), float(forces[b:e].size)], dtype=torch.float64)
+    all_reduce_sum_(acc, dist.group.WORLD)
+    np.save(os.path.join(out_dir, f"G{rank}.npy"), G.numpy())
+    np.save(os.path.join(out_dir, f"acc{rank}.npy"), acc.numpy())
+    dist.destroy_process_group()
+
+
+def test_frame_sharded_gram_allreduce_gloo(tmp_path):
+    import torch.multiprocessing as mp
+    from aggforce_amd.distributed import frame_shard
+
+    T, N, seed, world = 37, 6, 5, 2
+    shards = [frame_shard(T, r, world) for r in range(world)]
+    assert shards[0][0] == 0 and shards[-1][1] == T and shards[0][1] == shards[1][0]
+    assert [frame_shard(10, r, 3) for r in range(3)] == [(0, 4), (4, 7), (7, 10)]
+    mp.spawn(_shard_worker, args=(world, _free_port(), T, N, seed, str(tmp_path)), nprocs=world, join=True)
+    forces = np.random.default_rng(seed).standard_normal((T, N, 3))
+    full = orc.qp_form(forces)
+    G_full = full.T @ full
+    for r in range(world):
+        G = np.load(tmp_path / f"G{r}.npy")
+        assert np.allclose(G, G_full, rtol=1e-12, atol=1e-12)
+        acc = np.load(tmp_path / f"acc{r}.npy")
+        assert np.isclose(acc[0] / acc[1], np.mean(forces ** 2))
+    # replicated ranks hold bit-identical reduced matrices -> identical replicated solves
+    assert np.array_equal(np.load(tmp_path / "G0.npy"), np.load(tmp_path / "G1.npy"))

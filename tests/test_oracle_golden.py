@@ -1,0 +1,151 @@
+"""CPU: the NumPy oracle against the golden fixtures produced by the reference itself
+(oracle/gen_golden.py) and against the reference's own test data."""
+import numpy as np
+import pytest
+
+from oracle import aggforce_oracle as orc
+from conftest import cons_from_array
+
+
+def rel(a, b):
+    return np.max(np.abs(np.asarray(a, float) - np.asarray(b, float))) / max(1.0, np.max(np.abs(b)))
+
+
+def test_waterdimer_known_answer(golden):
+    """tests/test_agg.py:17-44 of the reference: optimal map ~ per-molecule aggregation."""
+    g = golden("g1_waterdimer.npz")
+    W = orc.qp_linear_map(g["forces"], g["coord_matrix"], set())
+    assert np.allclose(W, g["known_answer"], atol=5e-3)
+    # SURVEY 8(c) probe values of the exact optimum
+    assert abs(W[0, 1] - 1.000291) < 2e-6 and abs(W[1, 4] - 1.004972) < 2e-6
+
+
+@pytest.mark.parametrize("cname", ["none", "guessed"])
+@pytest.mark.parametrize("l2", [0.0, 1.0, 1e3])
+def test_waterdimer_golden(golden, cname, l2):
+    g = golden("g1_waterdimer.npz")
+    cons = set() if cname == "none" else cons_from_array(g["guessed_constraints"])
+    key = f"{cname}_l2_{l2:g}"
+    pr = orc.linear_problem(g["forces"], g["coord_matrix"], cons, l2)
+    assert rel(pr["qp_mat"], g[f"{key}__qp_mat"]) < 1e-12
+    assert np.array_equal(pr["con_mat"], g[f"{key}__con_mat"])
+    assert rel(pr["A"], g[f"{key}__A"]) < 1e-14
+    res = orc.project_forces(g["coords"], g["forces"], g["coord_matrix"], cons, l2)
+    assert rel(res["force_map"], g[f"{key}__W"]) < 1e-8
+    assert rel(res["mapped_forces"], g[f"{key}__mapped_forces"]) < 1e-8
+    assert abs(res["residual"] - float(g[f"{key}__residual"])) < 1e-8 * float(g[f"{key}__residual"])
+    # constraint residual of the exact solve
+    assert np.max(np.abs(g["coord_matrix"] @ res["force_map"].T - np.eye(2))) < 1e-10
+
+
+def test_guess_constraints_waterdimer(golden):
+    g = golden("g1_waterdimer.npz")
+    assert orc.guess_pairwise_constraints(g["coords"][:10]) == cons_from_array(g["guessed_constraints"])
+
+
+@pytest.mark.parametrize("mname", ["slice", "dense", "block"])
+@pytest.mark.parametrize("cname", ["none", "pairs", "chain", "overlap"])
+def test_synthetic_linear_golden(golden, mname, cname):
+    g = golden("g2_synthetic_linear.npz")
+    cons = cons_from_array(g[f"cons_{cname}"]) if g[f"cons_{cname}"].size else set()
+    cmat = g[f"map_{mname}"]
+    for dt in ("float64", "float32"):
+        for l2 in (0.0, 2.5):
+            key = f"{mname}_{cname}_{dt}_l2_{l2:g}"
+            f = g["forces"].astype(dt)
+            c = g["coords"].astype(dt)
+            res = orc.project_forces(c, f, cmat, cons, l2)
+            assert rel(res["force_map"], g[f"{key}__W"]) < 1e-7
+            assert rel(res["mapped_forces"], g[f"{key}__mapped_forces"]) < 1e-7
+            assert rel(res["mapped_coords"], g[f"{key}__mapped_coords"]) < 1e-12
+
+
+def test_linearmap_semantics_golden(golden):
+    g = golden("g3_linearmap.npz")
+    assert rel(orc.linearmap_apply(g["pos"], g["mat"]), g["call"]) < 1e-13
+    assert np.array_equal(orc.list_mapping_matrix([[0, 2, 3], [4]], 6), g["list_ctor"])
+    assert rel(orc.linearmap_apply(g["nan_pos"], g["nan_mat"]), g["nan_call"]) < 1e-13
+    with pytest.raises(ValueError):
+        orc.linearmap_apply(g["nan_bad_pos"], g["nan_mat"])
+    off = orc.linearmap_apply(g["nan_bad_pos"], g["nan_mat"], handle_nans=False)
+    assert np.array_equal(np.isnan(off), np.isnan(g["nan_off_call"]))
+
+
+def test_cln025_saved_maps(golden):
+    """tests/test_forces.py:132-185: saved basic map reproduced exactly; structural invariants
+    of the saved optimum (its trajectory is absent from the mount)."""
+    g = golden("g4_cln025.npz")
+    pairs = cons_from_array(g["pairs"])
+    W = orc.constraint_aware_uni_map(g["coord_matrix"], pairs)
+    assert ((W - g["basic"]) ** 2).sum() < 1e-5
+    C = orc.make_bond_constraint_matrix(int(g["n_atoms"]), pairs)
+    assert np.array_equal(C, g["con_mat"]) and C.shape == (175, 97)
+    opt = g["opt"]
+    assert np.max(np.abs(g["coord_matrix"] @ opt.T - np.eye(10))) < 1e-12  # M W' = I
+    x = np.linalg.lstsq(C, opt.T, rcond=None)[0]
+    assert np.max(np.abs(C @ x - opt.T)) < 1e-12  # W in range(C)
+
+
+def test_feat_id_golden(golden):
+    g = golden("g5_feat_id.npz")
+    cons = cons_from_array(g["cons"])
+    ids = orc.id_feat_ids(12, cons)
+    assert np.array_equal(ids, g["ids"])
+    feats, divs = orc.id_feat(48, 12, cons)
+    for l2 in (10.0, 0.5):
+        frames = list(g[f"l2_{l2:g}__frames"])
+        coefs = orc.qp_feat_linear_map(g["forces"], g["coord_matrix"], [feats] * 4, [divs] * 4, float(g["kbt"]),
+                                       frames, l2)
+        assert rel(np.stack(coefs), g[f"l2_{l2:g}__coefs"]) < 1e-7
+        mapped = orc.cla_apply(g["forces"], [feats] * 4, [divs] * 4, coefs)
+        assert rel(mapped, g[f"l2_{l2:g}__mapped_forces"]) < 1e-6
+    assert np.array_equal(orc.smear_matrix(orc.reduce_constraint_sets(cons), 12), g["smear"])
+
+
+def test_augmented_golden(golden):
+    g = golden("g6_augmented.npz")
+    cons = cons_from_array(g["cons"])
+    oc, of = orc.augment(g["coords"], g["forces"], g["coord_matrix"], float(g["var"]), float(g["kbt"]), g["eps_fit"])
+    assert rel(oc, g["aug_coords"]) < 1e-6 and rel(of, g["aug_forces"]) < 1e-6
+    o = orc.joptgauss_force_map(g["coords"], g["forces"], g["coord_matrix"], float(g["var"]), float(g["kbt"]),
+                                g["eps_fit"], cons)
+    assert rel(o["force_map"], g["W"]) < 1e-6
+    ds, dg = orc.condnormal_log_gradient(g["scn_src"], g["scn_gen"], np.eye(5), 0.3)
+    assert np.allclose(ds, g["scn_dsrc"], atol=2e-6) and np.allclose(dg, g["scn_dgen"], atol=2e-6)
+
+
+def test_gb_feat_divergence_matches_finite_differences():
+    """gb_feat is parity-unpinned (JAX absent): self-check the closed-form divergence against
+    central differences of the summed features, in float64."""
+    rng = np.random.default_rng(7)
+    T, N = 3, 7
+    pts = 3 * rng.random((T, N, 3)) + 1.0
+    cons = {frozenset([1, 2]), frozenset([4, 5, 6])}
+    ids = orc.id_feat_ids(N, cons)
+    smear = orc.smear_matrix(orc.reduce_constraint_sets(cons), N).astype(np.float64)
+    cg = pts[:, 0, :] + 0.37
+    kw = dict(outer=6.0, inner=0.0, n_basis=4, width=1.0, dist_power=0.5, dtype=np.float64)
+    nch = int(ids.max()) + 1
+    feats, divs = orc.gb_feat_site(pts, cg, ids, smear, n_channels=nch, **kw)
+    assert feats.shape == (T, N, 4 * nch) and divs.shape == (T, 4 * nch, 3)
+    h = 1e-6
+    num = np.zeros_like(divs)
+    for a in range(N):
+        for d in range(3):
+            p1, p2 = pts.copy(), pts.copy()
+            p1[:, a, d] += h
+            p2[:, a, d] -= h
+            f1, _ = orc.gb_feat_site(p1, cg, ids, smear, n_channels=nch, **kw)
+            f2, _ = orc.gb_feat_site(p2, cg, ids, smear, n_channels=nch, **kw)
+            # d/dx_a of sum over atoms a' of feature columns; attribute to the channel of atom a
+            dsum = (f1.sum(axis=1) - f2.sum(axis=1)) / (2 * h)  # (T, n_feat): all channels' sums
+            # jacrev(sum_{t,a'} gauss)[k, t, a, d] then channel_allocate puts it in channel(a)
+            g1 = np.zeros((T, 4))
+            for ch in range(nch):
+                g1 += dsum[:, 4 * ch:4 * ch + 4]
+            num[:, 4 * ids[a]:4 * ids[a] + 4, d] += g1
+    assert np.max(np.abs(num - divs)) < 1e-5 * max(1.0, np.max(np.abs(divs)))
+    # quirk A: default n_channels = max(ids) drops the last label's channel
+    f_q, d_q = orc.gb_feat_site(pts, cg, ids, smear, **kw)
+    assert f_q.shape[2] == 4 * (nch - 1)
+    assert np.array_equal(f_q, feats[:, :, : 4 * (nch - 1)])
