@@ -18,6 +18,43 @@ from ._lib import F32, F64, check, dtype_code, lib, ptr, stream_ptr, workspace
 _TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
 _NP_OF = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64)}
 
+# ------------------------------------------------------------------ per-stage HIP-event timers
+
+_timers: Optional[dict] = None
+
+
+def start_timers() -> None:
+    """Bracket every libaggf stage with HIP events on the launching stream (bench.py)."""
+    global _timers
+    _timers = {}
+
+
+def stop_timers() -> dict:
+    """{stage: {"ms": total, "calls": n}}; synchronises the device."""
+    global _timers
+    out = {}
+    if _timers is not None:
+        torch.cuda.synchronize()
+        for name, pairs in _timers.items():
+            out[name] = {"ms": float(sum(a.elapsed_time(b) for a, b in pairs)), "calls": len(pairs)}
+    _timers = None
+    return out
+
+
+@contextlib.contextmanager
+def _timed(name: str):
+    if _timers is None:
+        yield
+        return
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    try:
+        yield
+    finally:
+        b.record()
+        _timers.setdefault(name, []).append((a, b))
+
+
 # ------------------------------------------------------------------ containers
 
 _cache_stack: list = []
@@ -116,11 +153,12 @@ def gram(
     if ws_limit_bytes is not None:
         need = min(need, int(ws_limit_bytes))
     ws = workspace(need, dev, "gram")
-    check(
-        l.aggf_gram(ptr(forces), T, N, ind, cd, ptr(grp_ptr), ptr(grp_atoms), n_red, ptr(out),
-                    1 if accumulate else 0, ptr(ws), need, stream_ptr()),
-        "aggf_gram",
-    )
+    with _timed("gram"):
+        check(
+            l.aggf_gram(ptr(forces), T, N, ind, cd, ptr(grp_ptr), ptr(grp_atoms), n_red, ptr(out),
+                        1 if accumulate else 0, ptr(ws), need, stream_ptr()),
+            "aggf_gram",
+        )
     return out
 
 
@@ -146,11 +184,12 @@ def eq_qp_solve(
     stats = torch.empty(4, dtype=torch.float64, device=dev)
     need = l.aggf_eq_qp_workspace_bytes(n, m, nrhs)
     ws = workspace(need, dev, "solve")
-    check(
-        l.aggf_eq_qp_solve(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), m, ptr(B), nrhs, float(schur_reg), int(n_refine), ptr(X), ptr(stats),
-                           ptr(ws), need, stream_ptr()),
-        "aggf_eq_qp_solve",
-    )
+    with _timed("solve"):
+        check(
+            l.aggf_eq_qp_solve(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), m, ptr(B), nrhs, float(schur_reg),
+                               int(n_refine), ptr(X), ptr(stats), ptr(ws), need, stream_ptr()),
+            "aggf_eq_qp_solve",
+        )
     return X, stats
 
 
@@ -184,13 +223,15 @@ def linearmap_apply(
     sumsq = torch.empty(1, dtype=torch.float64, device=dev) if want_sumsq else None
     need = l.aggf_linearmap_apply_workspace_bytes(T, N, n_cg) if want_sumsq else 0
     ws = workspace(need, dev, "apply") if want_sumsq else None
-    check(
-        l.aggf_linearmap_apply(ptr(points), T, N, dtype_code(points.dtype), ptr(matrix), n_cg,
-                               dtype_code(matrix.dtype), _lib.NAN_REPLACE if nan_fill is not None else _lib.NAN_PROPAGATE,
-                               0.0 if nan_fill is None else float(nan_fill), ptr(out), ptr(sumsq), ptr(ws), need,
-                               stream_ptr()),
-        "aggf_linearmap_apply",
-    )
+    with _timed("apply"):
+        check(
+            l.aggf_linearmap_apply(ptr(points), T, N, dtype_code(points.dtype), ptr(matrix), n_cg,
+                                   dtype_code(matrix.dtype),
+                                   _lib.NAN_REPLACE if nan_fill is not None else _lib.NAN_PROPAGATE,
+                                   0.0 if nan_fill is None else float(nan_fill), ptr(out), ptr(sumsq), ptr(ws), need,
+                                   stream_ptr()),
+            "aggf_linearmap_apply",
+        )
     return (out, sumsq) if want_sumsq else out
 
 
@@ -201,11 +242,12 @@ def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype
     out = torch.empty((T, n_cg, 3), dtype=out_dtype, device=points.device)
     if T == 0:
         return out
-    check(
-        l.aggf_slice_gather(ptr(points), T, N, dtype_code(points.dtype), ptr(idx), n_cg, dtype_code(out_dtype),
-                            ptr(out), stream_ptr()),
-        "aggf_slice_gather",
-    )
+    with _timed("gather"):
+        check(
+            l.aggf_slice_gather(ptr(points), T, N, dtype_code(points.dtype), ptr(idx), n_cg, dtype_code(out_dtype),
+                                ptr(out), stream_ptr()),
+            "aggf_slice_gather",
+        )
     return out
 
 

@@ -63,7 +63,10 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(
 // ---------------------------------------------------------------------------
 // X: (rows, ld) with ld = 3*n_pad elements, n_pad % 128 == 0, 16-byte aligned rows.
 // grid.x = ksplit * n_tiles, tile fastest (co-running workgroups share a frame range).
-template <typename T>
+// ABL (ablation switches, tools/gram_ablate.hip only; the library always uses 0):
+//   1 = no global loads after the first stage, 2 = additionally no LDS refill/barrier,
+//   3 = additionally operands read from LDS once (MFMA only).
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles,
     int64_t frames_per_split, T* __restrict__ slabs) {
@@ -163,28 +166,32 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
   }
   __syncthreads();
 
+  T a[4], bb[4];
   for (int it = 0; it < n_it; ++it) {
-    const int cur = it & 1;
-    if (it + 1 < n_it) load_stage(it + 1);
+    const int cur = (ABL >= 2) ? 0 : (it & 1);
+    if (ABL == 0 && it + 1 < n_it) load_stage(it + 1);
     const T* pa = smem + cur * BUF_ELEMS;
     const T* pb = diag ? pa : pa + PANEL_ELEMS;
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        T a[4], bb[4];
+        if (ABL < 3 || it == 0) {
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
+          for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bb[n] = pb[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+          for (int n = 0; n < 4; ++n) bb[n] = pb[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
       }
     }
-    if (it + 1 < n_it) store_stage(cur ^ 1);
-    __syncthreads();
+    if (ABL < 2) {
+      if (it + 1 < n_it) store_stage(cur ^ 1);
+      __syncthreads();
+    }
   }
 
   // partial tile -> slab [(tile_lin * ksplit + ks)][128][128]
@@ -257,25 +264,25 @@ struct GramPlan {
 };
 
 static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t max_splits) {
-  // enough workgroups for ~6 rounds over the chip, with the last round as full as possible
+  // Minimise a simple time model over the split count k: workgroups run in rounds of `slots`
+  // (2 per CU); a workgroup costs its frames plus a fixed prologue/epilogue, and every
+  // workgroup writes (and the reducer re-reads) one 128x128 slab.
   int64_t hi = ceil_div(frames, (int64_t)kb * 8);  // at least 8 stages per split
   if (hi < 1) hi = 1;
   if (hi > max_splits) hi = max_splits;
-  int64_t want = ceil_div((int64_t)slots * 6, n_tiles);
-  if (want > hi) want = hi;
-  if (want < 1) want = 1;
-  int64_t lo = want * 3 / 4;
-  if (lo < 1) lo = 1;
-  int64_t up = want * 5 / 4 + 1;
-  if (up > hi) up = hi;
-  double best_eff = -1;
-  int64_t best = want;
-  for (int64_t k = lo; k <= up; ++k) {
-    const double blocks = (double)k * n_tiles;
-    const double rounds = (double)ceil_div((int64_t)blocks, slots);
-    const double eff = blocks / (rounds * slots);
-    if (eff > best_eff + 1e-9) {
-      best_eff = eff;
+  if (hi > 1024) hi = 1024;
+  const double us_per_frame = 0.64 * 4.0 / kb;     // one LDS stage = 48 MFMAs per wave, 2 waves per SIMD
+  const double fixed_frames = 48.0;                // pipeline fill + slab store, in frame units
+  const double slab_us = 2.0 * TILE * TILE * (kb == 4 ? 8 : 4) / 2.0e6;  // write + read at ~2 TB/s
+  double best_cost = 1e300;
+  int64_t best = 1;
+  for (int64_t k = 1; k <= hi; ++k) {
+    const int64_t blocks = k * n_tiles;
+    const double rounds = (double)ceil_div(blocks, slots);
+    const double fpb = (double)round_up(ceil_div(frames, k), kb);
+    const double cost = rounds * (fpb + fixed_frames) * us_per_frame + blocks * slab_us;
+    if (cost < best_cost * (1.0 - 1e-6)) {
+      best_cost = cost;
       best = k;
     }
   }
@@ -387,7 +394,7 @@ extern "C" size_t aggf_gram_workspace_bytes(int64_t T, int32_t N, int32_t n_red,
   if (T <= 0 || N <= 0 || n_red <= 0) return 0;
   GramPlan p;
   make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups != 0, true, 0, true, &p);
-  return (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 256;
+  return (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 1024;
 }
 
 extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,

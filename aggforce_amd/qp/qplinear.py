@@ -117,8 +117,10 @@ def qp_linear_map(
     all_reduce_sum_(G, comm)
     # A = M @ C and diag(C'C) without forming C
     M = np.asarray(coord_map.standard_matrix, dtype=np.float64)
-    A = np.zeros((M.shape[0], n_red))
-    np.add.at(A.T, goa, M.T)
+    if n_red == n_fg:
+        A = M
+    else:
+        A = np.add.reduceat(M[:, atoms_h], ptr_h[:-1], axis=1)
     sizes = torch.from_numpy(np.bincount(goa, minlength=n_red).astype(np.float64)).to(dev)
     X, _ = solve_constrained_maps(G, float(l2_regularization), sizes, A)
     goa_dev = torch.from_numpy(goa).to(dev)

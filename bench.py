@@ -1,0 +1,214 @@
+"""Benchmark of the aggforce force-map hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+One step = one full ``project_forces`` (Gram build -> [all-reduce] -> constrained solve ->
+map coordinates and forces -> residual) over a synthetic trajectory that is already resident
+in HBM.  Default workload = the configuration BASELINE.json's metric is quoted on: 1e6 frames
+x 4096 atoms x 256 CG beads, linear map, fp64 (configs[2]); it fits one MI355X (2 x 98.3 GB of
+coordinates and forces + 12 GB of outputs).  With N > 1 ranks (torch.distributed.run, one
+process per GPU) the SAME 1e6 frames are sharded over the ranks ("scaling": "strong"), each
+rank builds the Gram matrix of its shard and one RCCL all-reduce combines them.
+
+Rank 0 prints ONE JSON line: metric / value (frames/s, whole job) / roofline of the dominant
+kernel (MFMA SYRK, HIP-event timed inside this run) / cpu_baseline (the NumPy oracle = a port
+of the reference's qplinear.py operation sequence, timed on this box's host cores on a bounded
+frame sample, N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+WORKLOADS = {
+    # name: (frames, atoms, cg beads, dtype)
+    "c3": (1_000_000, 4096, 256, "f64"),   # BASELINE.json configs[2] -- the metric's configuration
+    "c2": (100_000, 1024, 64, "f32"),      # configs[1]
+    "tiny": (4096, 256, 16, "f64"),        # plumbing check
+}
+PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (MI355X_MICROARCH.md / SURVEY 8(d))
+SEED = 42100
+
+
+def parse():
+    p = argparse.ArgumentParser()
+    p.add_argument("--gpus", type=int, default=1)
+    p.add_argument("--steps", type=int, default=3)
+    p.add_argument("--warmup", type=int, default=1)
+    p.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
+    p.add_argument("--frames", type=int, default=None, help="override the total frame count")
+    p.add_argument("--cpu-frames", type=int, default=2000, help="frame sample of the CPU baseline")
+    p.add_argument("--no-cpu-baseline", action="store_true")
+    return p.parse_args()
+
+
+def blas_threads():
+    try:
+        from threadpoolctl import threadpool_info
+
+        n = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
+        return max(n) if n else 1
+    except Exception:
+        return 1
+
+
+def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores):
+    """Reference operation sequence (qplinear.py:66-88, util.py:119-125, agg.py:120-136) in NumPy
+    on a frame sample; T-linear stages are scaled to T_total, the solve is counted once."""
+    from oracle import aggforce_oracle as orc
+
+    rng = np.random.default_rng(SEED)
+    forces = (30 * rng.standard_normal((T_cpu, N, 3))).astype(np_dtype)
+    coords = rng.random((T_cpu, N, 3)).astype(np_dtype)
+    cmat = orc.list_mapping_matrix([[i * (N // n_cg)] for i in range(n_cg)], N)
+    t0 = time.perf_counter()
+    pr = orc.linear_problem(forces, cmat, set(), 0.0)           # qp_form, @con_mat, Gram
+    t1 = time.perf_counter()
+    X = orc.eq_qp_solve(pr["qp_mat"], None, pr["A"], np.eye(n_cg))  # exact solve in place of OSQP
+    W = (pr["con_mat"] @ X).T
+    t2 = time.perf_counter()
+    mc = orc.linearmap_apply(coords, cmat)
+    mf = orc.linearmap_apply(forces, W)
+    res = orc.force_smoothness(mf)
+    t3 = time.perf_counter()
+    lin = (t1 - t0) + (t3 - t2)
+    full = lin * (T_total / T_cpu) + (t2 - t1)
+    return {
+        "value": T_total / full,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"{T_cpu} of {T_total} frames x {N} atoms on the host ({os.cpu_count()} logical cores, BLAS threads "
+                   f"= cores field; the einsum apply is single-threaded as in the reference): gram {t1 - t0:.2f}s, "
+                   f"solve {t2 - t1:.2f}s (exact direct solve instead of {n_cg} OSQP runs), "
+                   f"apply+residual {t3 - t2:.2f}s; T-linear stages scaled to {T_total} frames, "
+                   f"solve counted once"),
+        "_check": float(res + mc.sum() * 0),
+    }
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local_rank)
+    comm = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        comm = dist.group.WORLD
+
+    from aggforce_amd import LinearMap, project_forces
+    from aggforce_amd import _kernels as K
+    from aggforce_amd.distributed import frame_shard
+
+    T_total, N, n_cg, dt = WORKLOADS[args.workload]
+    if args.frames:
+        T_total = args.frames
+    tdt = torch.float64 if dt == "f64" else torch.float32
+    begin, end = frame_shard(T_total, rank, world)
+    T_local = end - begin
+    # synthetic, counter-based: identical data for any GPU count
+    forces = K.synth_normal(T_local, N, tdt, SEED, frame_offset=begin, sigma=30.0)
+    coords = K.synth_normal(T_local, N, tdt, SEED + 1, frame_offset=begin, sigma=0.3, lattice=1.5)
+    cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
+    kwargs = {"comm": comm} if comm is not None else {}
+
+    def step():
+        return project_forces(coords=coords, forces=forces, coord_map=cmap, constrained_inds=set(), **kwargs)
+
+    def barrier():
+        if comm is not None:
+            import torch.distributed as dist
+
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    out = None
+    for _ in range(args.warmup):
+        out = step()
+    barrier()
+    K.start_timers()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    stages = K.stop_timers()
+    if comm is not None:
+        import torch.distributed as dist
+
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = tmax.item()
+    W = out["tmap"].force_map.standard_matrix
+    cons_resid = float(np.max(np.abs(cmap.standard_matrix @ W.T - np.eye(n_cg))))
+
+    if rank == 0:
+        gram = stages.get("gram", {"ms": float("nan"), "calls": 1})
+        gram_ms = gram["ms"] / max(1, gram["calls"])
+        flops = 3.0 * T_local * N * (N + 1)  # SYRK, upper triangle, per launch
+        achieved = flops / (gram_ms * 1e-3) / 1e12
+        line = {
+            "metric": "frames/sec through project_forces (Gram+solve), 1e6x4096-atom traj, 1/2/4/8 GPU",
+            "value": T_total * args.steps / elapsed,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps,
+            "higher_is_better": True,
+            "scaling": "strong",
+            "vs_baseline": None,
+            "dtype": dt,
+            "data": "synthetic",
+            "config": {
+                "workload": (f"{args.workload}: {T_total} frames x {N} atoms x {n_cg} CG beads, linear qp_linear_map, "
+                             f"{dt}, slice coord map, no constraints, frames sharded over {world} GPU(s)"),
+                "frames_per_gpu": T_local,
+                "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
+                "constraint_residual": cons_resid,
+                "residual": out["residual"],
+            },
+            "roofline": {
+                "kernel": "gram_tile_kernel (+ slab reduce) = aggf_gram",
+                "bound": "mfma",
+                "achieved": achieved,
+                "peak": PEAK_TFLOPS[dt],
+                "unit": "TFLOP/s",
+                "frac": achieved / PEAK_TFLOPS[dt],
+                "traffic": None,
+                "ms_per_launch": gram_ms,
+                "flops_per_launch": flops,
+            },
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            del out
+            cb = cpu_baseline(N, n_cg, np.float64 if dt == "f64" else np.float32, T_total,
+                              min(args.cpu_frames, T_total), blas_threads())
+            cb.pop("_check")
+            line["cpu_baseline"] = cb
+        print(json.dumps(line), flush=True)
+    if comm is not None:
+        import torch.distributed as dist
+
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -132,10 +132,13 @@ def qp_form(target: np.ndarray) -> np.ndarray:
 
 def trjdot(points: np.ndarray, factor: np.ndarray) -> np.ndarray:
     """einsum('tfd,cf->tcd') or per-frame factor; util.py:119-125."""
+    # same einsum call (incl. the explicit contraction path) as the reference, so that the
+    # CPU baseline in bench.py times what the reference would execute
+    opt_path = ["einsum_path", (0, 1)]
     if factor.ndim == 2:
-        return np.einsum("tfd,cf->tcd", points, factor)
+        return np.einsum("tfd,cf->tcd", points, factor, optimize=opt_path)
     if factor.ndim == 3:
-        return np.einsum("...fd,...cf->...cd", points, factor)
+        return np.einsum("...fd,...cf->...cd", points, factor, optimize=opt_path)
     raise ValueError("Factor matrix is an incompatible shape.")
 
 

@@ -1,0 +1,58 @@
+// Ablation bench of the Gram tile kernel (GPU box): where do the cycles go?
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/gram_ablate.hip aggforce_amd/csrc/aggf_util.hip -o /tmp/gram_ablate
+#include "../aggforce_amd/csrc/aggf_gram.hip"
+
+using namespace aggf;
+
+template <typename T, int ABL>
+static double run(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs) {
+  constexpr int KB = GramCfg<T>::KB;
+  const int nt1 = n_pad / TILE, n_tiles = nt1 * (nt1 + 1) / 2;
+  int64_t fps = round_up(ceil_div(rows, ksplit), KB);
+  const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((gram_tile_kernel<T, ABL>), dim3(ksplit * n_tiles), dim3(GRAM_THREADS), lds, 0, X, rows,
+                       (int64_t)n_pad * 3, nt1, n_tiles, fps, slabs);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+
+template <typename T>
+static void sweep(int64_t rows, int n_pad, double peak) {
+  const int nt1 = n_pad / TILE, n_tiles = nt1 * (nt1 + 1) / 2;
+  T* X;
+  hipMalloc(&X, (size_t)rows * n_pad * 3 * sizeof(T));
+  aggf_synth_normal(X, rows, n_pad, sizeof(T) == 8 ? AGGF_F64 : AGGF_F32, 1, 0, 0.0, 30.0, 0.0, nullptr);
+  const double flops_exec = (double)n_tiles * TILE * TILE * 2.0 * 3.0 * rows;
+  for (int ksplit : {8, 32}) {
+    T* slabs;
+    hipMalloc(&slabs, (size_t)ksplit * n_tiles * TILE * TILE * sizeof(T));
+    double t0 = run<T, 0>(X, rows, n_pad, ksplit, slabs);
+    double t1 = run<T, 1>(X, rows, n_pad, ksplit, slabs);
+    double t2 = run<T, 2>(X, rows, n_pad, ksplit, slabs);
+    double t3 = run<T, 3>(X, rows, n_pad, ksplit, slabs);
+    printf("%s N=%d T=%ld ksplit=%d blocks=%d: full %.2f ms (%.1f TF exec, %.0f%%) | no-gload %.2f (%.1f TF) | no-refill/barrier %.2f (%.1f TF) | mfma-only %.2f (%.1f TF)\n",
+           sizeof(T) == 8 ? "f64" : "f32", n_pad, (long)rows, ksplit, ksplit * n_tiles, t0, flops_exec / t0 / 1e9,
+           100 * flops_exec / t0 / 1e9 / peak, t1, flops_exec / t1 / 1e9, t2, flops_exec / t2 / 1e9, t3,
+           flops_exec / t3 / 1e9);
+    hipFree(slabs);
+  }
+  hipFree(X);
+}
+
+int main() {
+  sweep<double>(200000, 4096, 78.6);
+  sweep<float>(400000, 4096, 157.3);
+  sweep<float>(100000, 1024, 157.3);
+  return 0;
+}
