@@ -12,6 +12,8 @@
 //                        full copy for (qp_form) is done by the LDS read pattern;
 //   gram_reduce_kernel   fixed-order fp64 sum of the split-K slabs into G (both
 //                        triangles) -- no float atomics, bit-reproducible.
+#include <stdlib.h>
+
 #include "aggf_common.h"
 
 namespace aggf {
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(
 // ABL (ablation switches, tools/gram_ablate.hip only; the library always uses 0):
 //   1 = no global loads after the first stage, 2 = additionally no LDS refill/barrier,
 //   3 = additionally operands read from LDS once (MFMA only).
-template <typename T, int ABL = 0>
+template <typename T, int ABL = 0, bool STAGGER = true>
 __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles,
     int64_t frames_per_split, T* __restrict__ slabs) {
@@ -106,6 +108,16 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
   const int tj = ti + tile;
   const bool diag = (ti == tj);
   const int tile_lin = b - ks * n_tiles;
+
+  // De-phase the two workgroups that share a CU.  All workgroups do identical work, so two
+  // co-resident ones that start together stay in lock-step and hit their refill/barrier
+  // phases at the same time, leaving the MFMA pipe idle (tools/gram_ablate.hip: 12 %).  A
+  // pseudo-random start delay of up to one stage (conserved for the life of the pair) makes
+  // one of them compute while the other refills.
+  if (STAGGER) {
+    const unsigned h = ((unsigned)b * 2654435761u) >> 25;  // 0..127
+    for (unsigned i = 0; i < h; ++i) __builtin_amdgcn_s_sleep(1);  // 64 clocks each
+  }
 
   const int64_t t_begin = (int64_t)ks * frames_per_split;
   int64_t t_end = t_begin + frames_per_split;
@@ -168,7 +180,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
 
   T a[4], bb[4];
   for (int it = 0; it < n_it; ++it) {
-    const int cur = (ABL >= 2) ? 0 : (it & 1);
+    const int cur = (ABL == 2 || ABL == 3) ? 0 : (it & 1);
     if (ABL == 0 && it + 1 < n_it) load_stage(it + 1);
     const T* pa = smem + cur * BUF_ELEMS;
     const T* pb = diag ? pa : pa + PANEL_ELEMS;
@@ -176,7 +188,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        if (ABL < 3 || it == 0) {
+        if (ABL != 3 || it == 0) {
 #pragma unroll
           for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
 #pragma unroll
@@ -188,14 +200,189 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
           for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
       }
     }
-    if (ABL < 2) {
-      if (it + 1 < n_it) store_stage(cur ^ 1);
-      __syncthreads();
+    if (ABL < 2 || ABL == 4 || ABL == 5) {
+      if (ABL != 5 && it + 1 < n_it) store_stage(cur ^ 1);   // 5: barrier without LDS refill
+      if (ABL != 4) __syncthreads();                         // 4: LDS refill without barrier (racy, timing only)
     }
   }
 
   // partial tile -> slab [(tile_lin * ksplit + ks)][128][128]
   const int ksplit = gridDim.x / n_tiles;
+  T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + m * 16 + M::row(lane, r);
+        const int col = wn * 64 + n * 16 + (lane & 15);
+        slab[row * TILE + col] = acc[m][n][r];
+      }
+}
+
+// ---------------------------------------------------------------------------
+// Same tiling as gram_tile_kernel, but the panels travel HBM/L2 -> LDS by LDS-DMA
+// (global_load_lds_dwordx4: no VGPR round trip, no ds_write -- the register-staged refill
+// costs 6-12 % of the MFMA time, tools/gram_ablate.hip) through a 3-stage LDS ring with a
+// counted vmcnt, so the DMAs of stage s+2 stay in flight across the barrier of stage s.
+// One DMA piece = one wave-instruction = 64 lanes x 16 B = 1 KiB contiguous in LDS; a panel
+// row (384 elements) is 3 pieces (f64) or 1.5 pieces (f32: the second one uses lanes 0-31),
+// so no piece crosses an LDS row and the padded row stride of the read pattern is kept.
+template <typename T>
+struct DmaCfg;
+template <>
+struct DmaCfg<double> {
+  static constexpr int ROW_PIECES = 3;       // pieces per panel row
+  static constexpr int PIECE_ELEMS = 128;    // elements per full piece
+};
+template <>
+struct DmaCfg<float> {
+  static constexpr int ROW_PIECES = 2;
+  static constexpr int PIECE_ELEMS = 256;
+};
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+  else static_assert(N == 0, "unsupported vmcnt");
+}
+
+template <typename T>
+__global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
+    const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_sel,
+    int64_t frames_per_split, T* __restrict__ slabs) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  constexpr int KB = GramCfg<T>::KB;
+  constexpr int RP = DmaCfg<T>::ROW_PIECES;
+  constexpr int PE = DmaCfg<T>::PIECE_ELEMS;
+  constexpr int PANELS = 2;  // diagonal tiles stage their panel twice (one code path, fixed vmcnt)
+  constexpr int PIECES = PANELS * KB * RP;           // per stage: 24/12 (f64), 32/16 (f32)
+  constexpr int PPW = PIECES / 4;                    // per wave: 6/3, 8/4
+  static_assert(PIECES % 4 == 0, "piece split");
+  constexpr int PANEL_ELEMS = KB * ROW_STRIDE;
+  constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
+  constexpr int NBUF = 3;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // workgroup -> (split, tile): tile index fastest so that co-running workgroups share frames
+  const int b = blockIdx.x;
+  const int ks = b / n_sel;
+  const int tile_lin = b - ks * n_sel;  // row-major upper-triangle index
+  int idx = tile_lin, ti = 0;
+  {
+    int rowlen = nt1;
+    while (idx >= rowlen) {
+      idx -= rowlen;
+      --rowlen;
+      ++ti;
+    }
+  }
+  const int tj = ti + idx;
+
+  const int64_t t_begin = (int64_t)ks * frames_per_split;
+  int64_t t_end = t_begin + frames_per_split;
+  if (t_end > n_rows) t_end = n_rows;
+  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KB - 1) / KB) : 0;
+
+  // this wave's DMA pieces: global element offset within a stage and LDS element offset
+  int64_t g_off[PPW];
+  int l_off[PPW], p_row[PPW];
+  bool p_half[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int p = wave + 4 * q;
+    const int panel = p / (KB * RP);
+    const int r = (p - panel * KB * RP) / RP;
+    const int cp = p % RP;
+    p_row[q] = r;
+    p_half[q] = (sizeof(T) == 4) && (cp == 1);
+    const int64_t col = (int64_t)(panel ? tj : ti) * ROW_ELEMS + cp * PE;
+    g_off[q] = (int64_t)r * ld + col + lane * (16 / (int)sizeof(T));
+    l_off[q] = panel * PANEL_ELEMS + r * ROW_STRIDE + cp * PE;
+  }
+
+  auto issue_stage = [&](int s) {
+    const int64_t t0 = t_begin + (int64_t)s * KB;
+    const T* gbase = X + t0 * ld;
+    T* lbase = smem + (s % NBUF) * BUF_ELEMS;
+    const bool partial = t0 + KB > t_end;
+    if (partial) {
+      // rows past the end of this split's frame range must read as zeros
+      const int first = (int)(t_end - t0);
+      for (int e = tid; e < PANELS * (KB - first) * ROW_ELEMS; e += GRAM_THREADS) {
+        const int panel = e / ((KB - first) * ROW_ELEMS);
+        const int rem = e - panel * (KB - first) * ROW_ELEMS;
+        const int r = first + rem / ROW_ELEMS, c = rem % ROW_ELEMS;
+        lbase[panel * PANEL_ELEMS + r * ROW_STRIDE + c] = 0;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const bool row_ok = t0 + p_row[q] < t_end;
+      const bool lane_ok = !p_half[q] || lane < 32;
+      if (row_ok && lane_ok) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(gbase + g_off[q]),
+            (__attribute__((address_space(3))) void*)(lbase + l_off[q]), 16, 0, 0);
+      }
+    }
+  };
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = acc_zero<T>();
+
+  const int offA = (lane >> 4) * ROW_STRIDE + 3 * (wm * 64 + (lane & 15));
+  const int offB = PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wn * 64 + (lane & 15));
+
+  if (n_it > 0) issue_stage(0);
+  if (n_it > 1) issue_stage(1);
+  if (n_it > 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int it = 0; it < n_it; ++it) {
+    if (it + 2 < n_it) issue_stage(it + 2);
+    const T* pa = smem + (it % NBUF) * BUF_ELEMS;
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        T a[4], bb[4];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
+#pragma unroll
+        for (int n = 0; n < 4; ++n) bb[n] = pa[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+      }
+    }
+    // stage it+1 must have landed (this wave's pieces), stage it+2 may stay in flight
+    if (it + 2 < n_it) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  const int ksplit = gridDim.x / n_sel;
   T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -346,12 +533,27 @@ static int launch_gram(const T* X, int64_t rows, const GramPlan& p, T* slabs, do
   const int ksplit = p.ksplit;
   int64_t fps = round_up(ceil_div(rows, ksplit), KB);
   if (fps < KB) fps = KB;
-  const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T);
   const int64_t nblocks = (int64_t)ksplit * p.n_tiles;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
-  hipLaunchKernelGGL((gram_tile_kernel<T>), dim3((unsigned)nblocks), dim3(GRAM_THREADS), lds,
-                     stream, X, rows, (int64_t)p.n_pad * 3, p.nt1, p.n_tiles, fps, slabs);
-  AGGF_LAUNCH_OK();
+  const int64_t ld = (int64_t)p.n_pad * 3;
+  static const bool use_dma = getenv("AGGF_GRAM_NO_DMA") == nullptr;
+  if (use_dma) {
+    const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);  // 3-stage ring, 76.8 KB
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL((gram_tile_dma_kernel<T>), dim3((unsigned)nblocks), dim3(GRAM_THREADS), lds3,
+                       stream, X, rows, ld, p.nt1, p.n_tiles, fps, slabs);
+    AGGF_LAUNCH_OK();
+  } else {
+    const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T);
+    hipLaunchKernelGGL((gram_tile_kernel<T>), dim3((unsigned)nblocks), dim3(GRAM_THREADS), lds,
+                       stream, X, rows, ld, p.nt1, p.n_tiles, fps, slabs);
+    AGGF_LAUNCH_OK();
+  }
   hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                      slabs, p.nt1, ksplit, n_red, accumulate, G);
   AGGF_LAUNCH_OK();

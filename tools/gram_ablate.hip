@@ -4,19 +4,20 @@
 
 using namespace aggf;
 
-template <typename T, int ABL>
-static double run(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs) {
+template <typename T, int ABL, bool STAG = false>
+static double run(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs, size_t extra_lds = 0) {
   constexpr int KB = GramCfg<T>::KB;
   const int nt1 = n_pad / TILE, n_tiles = nt1 * (nt1 + 1) / 2;
   int64_t fps = round_up(ceil_div(rows, ksplit), KB);
-  const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T);
+  const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T) + extra_lds;
+  if (extra_lds) hipFuncSetAttribute((const void*)gram_tile_kernel<T, ABL, STAG>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(a);
-    hipLaunchKernelGGL((gram_tile_kernel<T, ABL>), dim3(ksplit * n_tiles), dim3(GRAM_THREADS), lds, 0, X, rows,
+    hipLaunchKernelGGL((gram_tile_kernel<T, ABL, STAG>), dim3(ksplit * n_tiles), dim3(GRAM_THREADS), lds, 0, X, rows,
                        (int64_t)n_pad * 3, nt1, n_tiles, fps, slabs);
     hipEventRecord(b);
     hipEventSynchronize(b);
@@ -34,13 +35,23 @@ static void sweep(int64_t rows, int n_pad, double peak) {
   hipMalloc(&X, (size_t)rows * n_pad * 3 * sizeof(T));
   aggf_synth_normal(X, rows, n_pad, sizeof(T) == 8 ? AGGF_F64 : AGGF_F32, 1, 0, 0.0, 30.0, 0.0, nullptr);
   const double flops_exec = (double)n_tiles * TILE * TILE * 2.0 * 3.0 * rows;
-  for (int ksplit : {8, 32}) {
+  for (int ksplit : {32}) {
     T* slabs;
     hipMalloc(&slabs, (size_t)ksplit * n_tiles * TILE * TILE * sizeof(T));
     double t0 = run<T, 0>(X, rows, n_pad, ksplit, slabs);
     double t1 = run<T, 1>(X, rows, n_pad, ksplit, slabs);
     double t2 = run<T, 2>(X, rows, n_pad, ksplit, slabs);
     double t3 = run<T, 3>(X, rows, n_pad, ksplit, slabs);
+    double t4 = run<T, 4>(X, rows, n_pad, ksplit, slabs);
+    double t5 = run<T, 5>(X, rows, n_pad, ksplit, slabs);
+    double t1b = run<T, 1>(X, rows, n_pad, ksplit, slabs, 40 * 1024);
+    double t0b = run<T, 0>(X, rows, n_pad, ksplit, slabs, 40 * 1024);
+    printf("   no-gload: refill w/o barrier %.2f (%.1f TF) | barrier w/o refill %.2f (%.1f TF) || ONE block/CU: no-gload %.2f (%.1f TF) full %.2f (%.1f TF)\n",
+           t4, flops_exec / t4 / 1e9, t5, flops_exec / t5 / 1e9, t1b, flops_exec / t1b / 1e9, t0b, flops_exec / t0b / 1e9);
+    double ts = run<T, 0, true>(X, rows, n_pad, ksplit, slabs);
+    double ts1 = run<T, 1, true>(X, rows, n_pad, ksplit, slabs);
+    printf("   staggered: full %.2f ms (%.1f TF exec, %.0f%%) | no-gload %.2f (%.1f TF)\n", ts, flops_exec / ts / 1e9,
+           100 * flops_exec / ts / 1e9 / peak, ts1, flops_exec / ts1 / 1e9);
     printf("%s N=%d T=%ld ksplit=%d blocks=%d: full %.2f ms (%.1f TF exec, %.0f%%) | no-gload %.2f (%.1f TF) | no-refill/barrier %.2f (%.1f TF) | mfma-only %.2f (%.1f TF)\n",
            sizeof(T) == 8 ? "f64" : "f32", n_pad, (long)rows, ksplit, ksplit * n_tiles, t0, flops_exec / t0 / 1e9,
            100 * flops_exec / t0 / 1e9 / peak, t1, flops_exec / t1 / 1e9, t2, flops_exec / t2 / 1e9, t3,
@@ -50,8 +61,9 @@ static void sweep(int64_t rows, int n_pad, double peak) {
   hipFree(X);
 }
 
-int main() {
+int main(int argc, char** argv) {
   sweep<double>(200000, 4096, 78.6);
+  if (argc > 1) return 0;  // "quick" mode for PMC passes
   sweep<float>(400000, 4096, 157.3);
   sweep<float>(100000, 1024, 157.3);
   return 0;
