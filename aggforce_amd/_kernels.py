@@ -330,3 +330,70 @@ def synth_normal(T: int, N: int, dtype: torch.dtype, seed: int, frame_offset: in
         "aggf_synth_normal",
     )
     return out
+
+
+# ------------------------------------------------------------------ K4 gb_feat
+
+
+def group_reduce(x: torch.Tensor, grp_ptr: torch.Tensor, grp_atoms: torch.Tensor, n_groups: int, mean: bool,
+                 out_dtype: torch.dtype) -> torch.Tensor:
+    """(T, n_groups, 3): per-group sums (or means) of x (T, N, 3); see aggf_group_reduce."""
+    l = lib()
+    T, N, _ = x.shape
+    out = torch.empty((T, n_groups, 3), dtype=out_dtype, device=x.device)
+    if T == 0:
+        return out
+    check(
+        l.aggf_group_reduce(ptr(x), T, N, dtype_code(x.dtype), ptr(grp_ptr), ptr(grp_atoms), n_groups,
+                            1 if mean else 0, dtype_code(out_dtype), ptr(out), stream_ptr()),
+        "aggf_group_reduce",
+    )
+    return out
+
+
+def gb_channels(Pg, cg, site: int, sizes, n_ch: int, centers, width: float, clip: float):
+    l = lib()
+    T, G, _ = Pg.shape
+    nb = centers.numel()
+    gauss = torch.empty((T, n_ch, nb), dtype=torch.float32, device=Pg.device)
+    grad = torch.empty((T, n_ch, nb, 3), dtype=torch.float32, device=Pg.device)
+    if T == 0 or n_ch == 0:
+        return gauss, grad
+    check(
+        l.aggf_gb_channels(ptr(Pg), ptr(cg), T, G, cg.shape[1], site, ptr(sizes), n_ch, ptr(centers), nb,
+                           float(width), float(clip), ptr(gauss), ptr(grad), stream_ptr()),
+        "aggf_gb_channels",
+    )
+    return gauss, grad
+
+
+def gb_regmat(Fg, Pg, cg, site: int, sizes, n_id: int, n_ch: int, centers, width: float, clip: float, kbt: float,
+              out: torch.Tensor) -> torch.Tensor:
+    """Fill out (T, ld_feat, 3) with the regression matrix of one cg site; see aggf_gb_regmat."""
+    l = lib()
+    T, G, _ = Fg.shape
+    with _timed("gb_regmat"):
+        check(
+            l.aggf_gb_regmat(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, cg.shape[1], site, ptr(sizes),
+                             n_id, n_ch, ptr(centers), centers.numel(), float(width), float(clip), float(kbt),
+                             out.shape[1], ptr(out), stream_ptr()),
+            "aggf_gb_regmat",
+        )
+    return out
+
+
+def gb_apply(Fg, Pg, cg, sizes, n_id: int, n_ch: int, centers, width: float, clip: float, coef: torch.Tensor):
+    l = lib()
+    T, G, _ = Fg.shape
+    n_cg = cg.shape[1]
+    out = torch.empty((T, n_cg, 3), dtype=torch.float64, device=Fg.device)
+    if T == 0:
+        return out
+    with _timed("gb_apply"):
+        check(
+            l.aggf_gb_apply(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, n_cg, ptr(sizes), n_id, n_ch,
+                            ptr(centers), centers.numel(), float(width), float(clip), ptr(coef), coef.shape[1],
+                            ptr(out), stream_ptr()),
+            "aggf_gb_apply",
+        )
+    return out

@@ -1,0 +1,289 @@
+// K4: Gaussian-basis distance featuriser (gb_feat) and the featurised regression matrix,
+// without ever materialising the one-hot (T, N, n_feat) feature tensor.
+//
+// Reference: qp/jaxfeat.py (gb_feat 20-184, gaussian_dist_basis 187-240, clipped_gauss
+// 243-276, channel_allocate 279-368, gb_subfeat 371-464, gb_subfeat_jac 467-567),
+// map/tools.py:63-104 (smear_map), qp/featlinearmap.py:361-369 (regression matrix) and
+// 512-520 (map application).  Facts used: every atom of a constraint group is
+// replaced by the group mean before the distance is taken, so all atoms of a channel share
+// one distance r[t,ch] = |p[t,ch] - cg[t,c]| and one Gaussian row, and
+//   feat[t,a,(ch,k)]  = [ch == channel(a)] * g_k(r[t,ch])
+//   div [t,(ch,k),:]  = |ch| * g_k'(r[t,ch]) * (p[t,ch] - cg[t,c]) / r[t,ch]        (closed form of
+//                       the reference's jacrev; cg is a constant of the differentiation)
+//   R3[t,(ch,k),d]    = g_k(r) * Fg[t,ch,d] + kbt * div[t,(ch,k),d],  Fg = group force sums
+// with g_k(r) = max(exp(-((r-c_k)/w)^2), clip) - clip.  The float32 arithmetic of the
+// reference (JAX default) is kept for positions, distances and Gaussians.
+#include "aggf_common.h"
+
+namespace aggf {
+
+// out[t,g,d] = sum (or mean: each term multiplied by 1/|g| first, like the smear matrix
+// product) of X[t,a,d] over the atoms of group g
+template <typename TIn, typename TO>
+__global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict__ X, int64_t T, int32_t N,
+                                                           const int32_t* __restrict__ grp_ptr,
+                                                           const int32_t* __restrict__ grp_atoms,
+                                                           int32_t G, int mean, TO* __restrict__ out) {
+  const int64_t row_in = (int64_t)N * 3, row_out = (int64_t)G * 3;
+  for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+    const TIn* src = X + t * row_in;
+    TO* dst = out + t * row_out;
+    for (int e = threadIdx.x; e < (int)row_out; e += blockDim.x) {
+      const int g = e / 3, d = e - 3 * g;
+      const int b = grp_ptr[g], en = grp_ptr[g + 1];
+      const TO w = mean ? (TO)1 / (TO)(en - b) : (TO)1;
+      TO acc = 0;
+      for (int j = b; j < en; ++j) acc += w * (TO)src[(int64_t)grp_atoms[j] * 3 + d];
+      dst[e] = acc;
+    }
+  }
+}
+
+struct GbParams {
+  const float* centers;  // n_basis grid centres
+  int32_t n_basis;
+  float width, clip;
+};
+
+// distance, unit vector and Gaussian row of channel ch at frame t
+__device__ __forceinline__ void gb_geometry(const float* __restrict__ Pg, const float* __restrict__ cg,
+                                            int64_t t, int32_t G, int32_t ch, int32_t n_cg, int32_t site,
+                                            float& r, float u[3]) {
+  const float* p = Pg + (t * G + ch) * 3;
+  const float* c = cg + (t * n_cg + site) * 3;
+  const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+  r = sqrtf(dx * dx + dy * dy + dz * dz);
+  u[0] = dx / r;  // NaN at r == 0, like the gradient of jnp.linalg.norm
+  u[1] = dy / r;
+  u[2] = dz / r;
+}
+
+__device__ __forceinline__ void gb_gauss(const GbParams& gp, float r, int k, float& g, float& dg) {
+  const float arg = (r - gp.centers[k]) / gp.width;
+  const float raw = expf(-(arg * arg));
+  g = fmaxf(raw, gp.clip) - gp.clip;
+  dg = raw > gp.clip ? -2.0f * arg / gp.width * raw : 0.0f;
+}
+
+// compact per-channel features: gauss[t,ch,k], grad[t,ch,k,:] = |ch| g_k'(r) u
+__global__ __launch_bounds__(256) void gb_channels_kernel(const float* __restrict__ Pg,
+                                                          const float* __restrict__ cg, int64_t T, int32_t G,
+                                                          int32_t n_cg, int32_t site,
+                                                          const float* __restrict__ sizes, int32_t n_ch,
+                                                          GbParams gp, float* __restrict__ gauss,
+                                                          float* __restrict__ grad) {
+  const int64_t total = T * n_ch;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / n_ch;
+    const int ch = (int)(i - t * n_ch);
+    float r, u[3];
+    gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
+    const float m = sizes[ch];
+    for (int k = 0; k < gp.n_basis; ++k) {
+      float g, dg;
+      gb_gauss(gp, r, k, g, dg);
+      const int64_t o = i * gp.n_basis + k;
+      gauss[o] = g;
+      grad[o * 3 + 0] = m * dg * u[0];
+      grad[o * 3 + 1] = m * dg * u[1];
+      grad[o * 3 + 2] = m * dg * u[2];
+    }
+  }
+}
+
+// R3 (T, ld_feat, 3): columns [0, n_id) = group force sums (id_feat block, optional), then
+// n_ch * n_basis Gaussian columns; columns up to ld_feat are left untouched (ignored by K1).
+template <typename TF>
+__global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
+                                                        const float* __restrict__ cg, int64_t T, int32_t G,
+                                                        int32_t n_cg, int32_t site,
+                                                        const float* __restrict__ sizes, int32_t n_id,
+                                                        int32_t n_ch, GbParams gp, TF kbt, int32_t ld_feat,
+                                                        TF* __restrict__ R3) {
+  const int per_frame = n_id + n_ch;  // work items per frame: id columns, then channels
+  const int64_t total = T * per_frame;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / per_frame;
+    const int j = (int)(i - t * per_frame);
+    TF* row = R3 + t * (int64_t)ld_feat * 3;
+    if (j < n_id) {
+      const TF* f = Fg + (t * G + j) * 3;
+      row[j * 3 + 0] = f[0];
+      row[j * 3 + 1] = f[1];
+      row[j * 3 + 2] = f[2];
+      continue;
+    }
+    const int ch = j - n_id;
+    float r, u[3];
+    gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
+    const TF* f = Fg + (t * G + ch) * 3;
+    const TF f0 = f[0], f1 = f[1], f2 = f[2];
+    const float m = sizes[ch];
+    TF* o = row + ((int64_t)n_id + (int64_t)ch * gp.n_basis) * 3;
+    for (int k = 0; k < gp.n_basis; ++k) {
+      float g, dg;
+      gb_gauss(gp, r, k, g, dg);
+      const float s = m * dg;
+      o[k * 3 + 0] = (TF)g * f0 + kbt * (TF)(s * u[0]);
+      o[k * 3 + 1] = (TF)g * f1 + kbt * (TF)(s * u[1]);
+      o[k * 3 + 2] = (TF)g * f2 + kbt * (TF)(s * u[2]);
+    }
+  }
+}
+
+// CLAMap application of the [id | gb] feature-linear map (featlinearmap.py:512-520,
+// map/core.py:428-430): out[t,c,:] = sum_f coef[c,f] * (feat_c[t]' F[t] + div_c[t])[f,:]
+// -- the divergence enters WITHOUT kbt, exactly as in the reference's trans_f.
+template <typename TF>
+__global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
+                                                       const float* __restrict__ cg, int64_t T, int32_t G,
+                                                       int32_t n_cg, const float* __restrict__ sizes,
+                                                       int32_t n_id, int32_t n_ch, GbParams gp,
+                                                       const double* __restrict__ coef, int32_t n_feat,
+                                                       double* __restrict__ out) {
+  // one wave per (frame, site); lanes stride over id columns and channels
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  for (int64_t i = wid; i < T * n_cg; i += nw) {
+    const int64_t t = i / n_cg;
+    const int site = (int)(i - t * n_cg);
+    const double* cf = coef + (int64_t)site * n_feat;
+    double a0 = 0, a1 = 0, a2 = 0;
+    for (int g = lane; g < n_id; g += 64) {
+      const TF* f = Fg + (t * G + g) * 3;
+      const double c = cf[g];
+      a0 += c * (double)f[0];
+      a1 += c * (double)f[1];
+      a2 += c * (double)f[2];
+    }
+    for (int ch = lane; ch < n_ch; ch += 64) {
+      float r, u[3];
+      gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
+      const TF* f = Fg + (t * G + ch) * 3;
+      const float m = sizes[ch];
+      for (int k = 0; k < gp.n_basis; ++k) {
+        float g, dg;
+        gb_gauss(gp, r, k, g, dg);
+        const double c = cf[n_id + ch * gp.n_basis + k];
+        const float s = m * dg;
+        a0 += c * ((double)((TF)g * f[0]) + (double)(s * u[0]));
+        a1 += c * ((double)((TF)g * f[1]) + (double)(s * u[1]));
+        a2 += c * ((double)((TF)g * f[2]) + (double)(s * u[2]));
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      a0 += __shfl_down(a0, off, 64);
+      a1 += __shfl_down(a1, off, 64);
+      a2 += __shfl_down(a2, off, 64);
+    }
+    if (lane == 0) {
+      out[i * 3 + 0] = a0;
+      out[i * 3 + 1] = a1;
+      out[i * 3 + 2] = a2;
+    }
+  }
+}
+
+static inline dim3 feat_grid(int64_t n) {
+  int64_t g = ceil_div(n, 256);
+  if (g > 16384) g = 16384;
+  if (g < 1) g = 1;
+  return dim3((unsigned)g);
+}
+
+static int check_gb(const void* centers, int32_t n_basis, double width) {
+  if (!centers || n_basis <= 0 || n_basis > 64) return fail(AGGF_ERR_ARG, "gb_feat: bad n_basis / centres");
+  if (!(width > 0.0)) return fail(AGGF_ERR_ARG, "gb_feat: width must be positive");
+  return AGGF_OK;
+}
+
+}  // namespace aggf
+
+using namespace aggf;
+
+extern "C" int aggf_group_reduce(const void* X, int64_t T, int32_t N, int in_dtype,
+                                 const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_groups,
+                                 int mean, int out_dtype, void* out, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!X || !grp_ptr || !grp_atoms || !out) return fail(AGGF_ERR_ARG, "aggf_group_reduce: NULL pointer");
+  if (T <= 0 || N <= 0 || n_groups <= 0) return fail(AGGF_ERR_ARG, "aggf_group_reduce: empty problem");
+  const dim3 grid((unsigned)(T < 8192 ? T : 8192)), block(256);
+  if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((group_reduce_kernel<float, float>), grid, block, 0, stream, (const float*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (float*)out);
+  else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((group_reduce_kernel<double, double>), grid, block, 0, stream, (const double*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (double*)out);
+  else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((group_reduce_kernel<double, float>), grid, block, 0, stream, (const double*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (float*)out);
+  else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((group_reduce_kernel<float, double>), grid, block, 0, stream, (const float*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (double*)out);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_group_reduce: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
+                                int32_t site, const float* sizes, int32_t n_ch, const float* centers,
+                                int32_t n_basis, double width, double clip, float* gauss, float* grad,
+                                void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Pg || !cg || !sizes || !gauss || !grad) return fail(AGGF_ERR_ARG, "aggf_gb_channels: NULL pointer");
+  if (T <= 0 || G <= 0 || n_ch <= 0 || n_ch > G || site < 0 || site >= n_cg)
+    return fail(AGGF_ERR_ARG, "aggf_gb_channels: bad shape");
+  int rc = check_gb(centers, n_basis, width);
+  if (rc) return rc;
+  GbParams gp{centers, n_basis, (float)width, (float)clip};
+  hipLaunchKernelGGL(gb_channels_kernel, feat_grid(T * n_ch), dim3(256), 0, stream, Pg, cg, T, G, n_cg, site, sizes, n_ch, gp, gauss, grad);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+                              int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
+                              int32_t n_ch, const float* centers, int32_t n_basis, double width,
+                              double clip, double kbt, int32_t ld_feat, void* R3, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Fg || !Pg || !cg || !sizes || !R3) return fail(AGGF_ERR_ARG, "aggf_gb_regmat: NULL pointer");
+  if (T <= 0 || G <= 0 || n_ch < 0 || n_ch > G || n_id < 0 || n_id > G || site < 0 || site >= n_cg ||
+      ld_feat < n_id + n_ch * n_basis)
+    return fail(AGGF_ERR_ARG, "aggf_gb_regmat: bad shape");
+  int rc = check_gb(centers, n_basis, width);
+  if (rc) return rc;
+  GbParams gp{centers, n_basis, (float)width, (float)clip};
+  const dim3 grid = feat_grid(T * (n_id + n_ch));
+  if (f_dtype == AGGF_F32)
+    hipLaunchKernelGGL(gb_regmat_kernel<float>, grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (float)kbt, ld_feat, (float*)R3);
+  else if (f_dtype == AGGF_F64)
+    hipLaunchKernelGGL(gb_regmat_kernel<double>, grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (double)kbt, ld_feat, (double*)R3);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_gb_regmat: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+                             int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, int32_t n_ch,
+                             const float* centers, int32_t n_basis, double width, double clip,
+                             const double* coef, int32_t n_feat, double* out, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Fg || !Pg || !cg || !sizes || !coef || !out) return fail(AGGF_ERR_ARG, "aggf_gb_apply: NULL pointer");
+  if (T <= 0 || G <= 0 || n_cg <= 0 || n_ch < 0 || n_ch > G || n_id < 0 || n_id > G ||
+      n_feat != n_id + n_ch * n_basis)
+    return fail(AGGF_ERR_ARG, "aggf_gb_apply: bad shape");
+  int rc = check_gb(centers, n_basis, width);
+  if (rc) return rc;
+  GbParams gp{centers, n_basis, (float)width, (float)clip};
+  const dim3 grid = feat_grid(T * n_cg * 64);
+  if (f_dtype == AGGF_F32)
+    hipLaunchKernelGGL(gb_apply_kernel<float>, grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat, out);
+  else if (f_dtype == AGGF_F64)
+    hipLaunchKernelGGL(gb_apply_kernel<double>, grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat, out);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_gb_apply: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}

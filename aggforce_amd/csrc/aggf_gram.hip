@@ -527,7 +527,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
 }
 
 template <typename T>
-static int launch_gram(const T* X, int64_t rows, const GramPlan& p, T* slabs, double* G,
+static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs, double* G,
                        int32_t n_red, int accumulate, hipStream_t stream) {
   constexpr int KB = GramCfg<T>::KB;
   const int ksplit = p.ksplit;
@@ -535,7 +535,6 @@ static int launch_gram(const T* X, int64_t rows, const GramPlan& p, T* slabs, do
   if (fps < KB) fps = KB;
   const int64_t nblocks = (int64_t)ksplit * p.n_tiles;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
-  const int64_t ld = (int64_t)p.n_pad * 3;
   static const bool use_dma = getenv("AGGF_GRAM_NO_DMA") == nullptr;
   if (use_dma) {
     const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);  // 3-stage ring, 76.8 KB
@@ -567,8 +566,8 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   TC* slabs = reinterpret_cast<TC*>(ws);
   if (p.direct) {
     // only reachable with TIn == TC
-    return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, p, slabs, G, n_red, accumulate,
-                           stream);
+    return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, G, n_red,
+                           accumulate, stream);
   }
   TC* pack = reinterpret_cast<TC*>(ws + round_up((int64_t)p.slab_bytes, 256));
   const TIn* F = reinterpret_cast<const TIn*>(Fv);
@@ -580,7 +579,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
                        F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad,
                        pack);
     AGGF_LAUNCH_OK();
-    int rc = launch_gram<TC>(pack, rows, p, slabs, G, n_red, acc, stream);
+    int rc = launch_gram<TC>(pack, rows, (int64_t)p.n_pad * 3, p, slabs, G, n_red, acc, stream);
     if (rc) return rc;
     acc = 1;
   }
@@ -613,8 +612,6 @@ extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int 
   const bool has_groups = grp_ptr != nullptr;
   if (has_groups != (grp_atoms != nullptr))
     return fail(AGGF_ERR_ARG, "aggf_gram: grp_ptr and grp_atoms must be given together");
-  if (!has_groups && n_red != N)
-    return fail(AGGF_ERR_ARG, "aggf_gram: n_red must equal N without constraint groups");
   if (n_red > N) return fail(AGGF_ERR_ARG, "aggf_gram: n_red > N");
   if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram: workspace not 256-byte aligned");
   const bool aligned = ((uintptr_t)F & 15) == 0;

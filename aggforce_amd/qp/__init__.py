@@ -10,6 +10,7 @@ from .featlinearmap import (
     qp_feat_linear_map,
     id_feat,
 )
+from .gbfeat import gb_feat
 from .gauss import joptgauss_map
 
 __all__ = [
@@ -24,5 +25,6 @@ __all__ = [
     "GeneralizedFeaturizer",
     "qp_feat_linear_map",
     "id_feat",
+    "gb_feat",
     "joptgauss_map",
 ]

@@ -104,6 +104,23 @@ class Multifeaturize:
     def __call__(self, *args, **kwargs) -> GeneralizedFeatures:
         return FeatZipper(content=[f(*args, **kwargs) for f in self.featurizers])
 
+    @property
+    def fused_fit(self):
+        """Fused fitting routine if the members are [id_feat], [gb_feat bound with Curry] or
+        [id_feat, gb_feat bound with Curry] (see qp/gbfeat.py); None otherwise."""
+        from .gbfeat import fit_id_gb, recognise
+
+        rec = recognise(self.featurizers)
+        if rec is None:
+            return None
+        use_id, gb_kwargs = rec
+
+        def fit(traj, coord_map, kbt, n_constraint_frames, constraints, l2, frame_indices, rng, comm):
+            return fit_id_gb(traj, coord_map, kbt, n_constraint_frames, constraints, l2, frame_indices, rng,
+                             comm, use_id, gb_kwargs, self)
+
+        return fit
+
     def __repr__(self) -> str:
         parts = ["{}():".format(self.__class__)]
         for i, f in enumerate(self.featurizers):
@@ -189,6 +206,7 @@ def qp_feat_linear_map(
     frame_indices: Optional[List[np.ndarray]] = None,
     rng=None,
     comm=None,
+    fused: bool = True,
 ) -> CLAFTMap:
     """Force map linear in features, minimising the mean squared mapped force
     (reference featlinearmap.py:249-394; same arguments).
@@ -198,7 +216,8 @@ def qp_feat_linear_map(
     cg site) or ``rng`` (numpy Generator) make the sampled constraint frames reproducible --
     the reference draws them from an unseeded generator (featlinearmap.py:445); ``comm`` shards
     frames over ranks (the sampled constraint frames are then taken from each rank's shard and
-    must be given identically on every rank through ``frame_indices`` of rank-local frames).
+    must be given identically on every rank through ``frame_indices`` of rank-local frames);
+    ``fused=False`` forces the generic dense-feature path even for the built-in featurisers.
 
     Returns ``CLAFTMap(coord_map, CLAMap)`` with tags {"feat_names", "coef_list"}.
     """
@@ -206,10 +225,10 @@ def qp_feat_linear_map(
 
     if constraints is None:
         constraints = set()
-    fused = getattr(featurizer, "fused_fit", None)
-    if fused is not None:
-        return fused(traj, coord_map, kbt, n_constraint_frames, constraints, l2_regularization,
-                     frame_indices, rng, comm)
+    fused_fit = getattr(featurizer, "fused_fit", None) if fused else None
+    if fused_fit is not None:
+        return fused_fit(traj, coord_map, kbt, n_constraint_frames, constraints, l2_regularization,
+                         frame_indices, rng, comm)
     feat_results = featurizer(traj.coords, coord_map, constraints)
     feats, divs, names = (feat_results[k] for k in (KNAME_FEATS, KNAME_DIVS, KNAME_NAMES))
     forces = K.as_device(traj.forces)

@@ -1,0 +1,247 @@
+"""Gaussian-basis distance featuriser ``gb_feat`` on the GPU (reference: qp/jaxfeat.py).
+
+Every fine-grained site is characterised by its distance to the mapped (coarse-grained) site,
+expanded in clipped Gaussians, one block of ``n_basis`` features per constraint group
+("channel"); atoms of a constraint group are first replaced by the group mean, so they share
+one feature row (jaxfeat.py:20-184).  The reference builds this with JAX (jit, jacrev); here
+the distances, Gaussians and the closed-form divergence come from the HIP kernels K4
+(``aggf_gb_channels`` / ``aggf_gb_regmat`` / ``aggf_gb_apply``).
+
+Two ways to use it, both drop-in:
+
+* ``gb_feat(points, cmap, constraints, outer=..., ...)`` returns the reference's featuriser
+  dictionary {"feats": per-site (T, N, n_feat), "divs": per-site (T, n_feat, 3), "names": None}
+  (dense arrays, float32) -- the generic protocol of ``qp_feat_linear_map``.
+* ``Multifeaturize([id_feat, Curry(gb_feat, ...)])`` (or ``[Curry(gb_feat, ...)]``, or
+  ``[id_feat]``) is recognised by ``qp_feat_linear_map`` and fitted by the fused path
+  (``fit_id_gb``): the regression matrix of each site is written directly in the Gram kernel's
+  layout from per-group force sums, never materialising the one-hot feature tensor (which is
+  754 GB per site at BASELINE config 4).
+
+Reference quirk kept by default (``drop_last_channel=True``): the reference allocates
+``max(ids)`` channels (jaxfeat.py:115), one fewer than the number of labels, so the
+last-labelled constraint group gets no Gaussian features (Quirk A).  Labels here
+are numbered by smallest member (``constraint_group_labels``); the reference's order is
+CPython's set order, an arbitrary permutation.
+"""
+from functools import partial
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from .. import _kernels as K
+from ..constraints import Constraints
+from ..distributed import all_reduce_sum_
+from ..map import CLAFTMap, CLAMap, LinearMap
+from ..util import Curry
+from .featlinearmap import KNAME_DIVS, KNAME_FEATS, KNAME_NAMES, constraint_group_labels, id_feat
+
+DIVMETHOD_REORDER = "reorder"
+DIVMETHOD_BASIC = "basic"
+CLIP = 1e-3  # clipped_gauss default (jaxfeat.py:243-276)
+
+
+def gb_centers(outer: float, inner: float, n_basis: int, dist_power: float) -> np.ndarray:
+    """Gaussian grid centres, uniform in r**dist_power (jaxfeat.py:235-236), float32."""
+    grid = np.linspace(inner**dist_power, outer**dist_power, n_basis).astype(np.float32)
+    return (grid ** np.float32(1 / dist_power)).astype(np.float32)
+
+
+class _Geometry:
+    """Device-side per-trajectory quantities shared by all cg sites."""
+
+    def __init__(self, coords, cmap: LinearMap, constraints: Constraints, drop_last_channel: bool):
+        import torch
+
+        self.ids = constraint_group_labels(cmap.n_fg_sites, constraints)
+        self.G = int(self.ids.max()) + 1
+        order = np.argsort(self.ids, kind="stable").astype(np.int32)
+        counts = np.bincount(self.ids, minlength=self.G)
+        ptr = np.zeros(self.G + 1, dtype=np.int32)
+        np.cumsum(counts, out=ptr[1:])
+        c = K.as_device(coords)
+        self.dev = c.device
+        self.T = c.shape[0]
+        self.grp_ptr = torch.from_numpy(ptr).to(self.dev)
+        self.grp_atoms = torch.from_numpy(order).to(self.dev)
+        self.sizes = torch.from_numpy(counts.astype(np.float32)).to(self.dev)
+        self.n_ch = self.G - 1 if drop_last_channel else self.G
+        # group-mean ("smeared") positions and mapped sites, float32 like the reference's JAX arrays
+        self.Pg = K.group_reduce(c, self.grp_ptr, self.grp_atoms, self.G, True, torch.float32)
+        self.cg = K.as_device(cmap(c)).to(torch.float32).contiguous()
+        # group-summed coordinate map: sum_a M[c,a] [label(a) == g]
+        M = np.asarray(cmap.standard_matrix, dtype=np.float64)
+        self.Mg = np.add.reduceat(M[:, order], ptr[:-1], axis=1) if self.G < M.shape[1] else M[:, order]
+
+    def group_forces(self, forces):
+        f = K.as_device(forces)
+        return K.group_reduce(f, self.grp_ptr, self.grp_atoms, self.G, False, f.dtype)
+
+
+def gb_feat(
+    points,
+    cmap: LinearMap,
+    constraints: Constraints,
+    outer: float,
+    inner: float = 0,
+    n_basis: int = 10,
+    width: float = 1.0,
+    dist_power: float = 0.5,
+    batch_size: Optional[int] = None,  # noqa: ARG001  (frames are streamed by the kernel)
+    lazy: bool = True,
+    div_method: str = DIVMETHOD_REORDER,
+    drop_last_channel: bool = True,
+):
+    """Featurise each site by its distance to every mapped site (reference jaxfeat.py:20-184).
+
+    Same arguments as the reference (``batch_size`` is accepted and unused; both ``div_method``
+    values give the same closed-form divergence).  Returns the featuriser dictionary with
+    per-site dense float32 arrays: feats (n_frames, n_fg, n_basis*n_channels) and divs
+    (n_frames, n_basis*n_channels, 3); generators if ``lazy``.
+    """
+    import torch
+
+    if div_method not in (DIVMETHOD_REORDER, DIVMETHOD_BASIC):
+        raise ValueError("Unknown method for jacobian calculation.")
+    geo = _Geometry(points, cmap, constraints, drop_last_channel)
+    centers = torch.from_numpy(gb_centers(outer, inner, n_basis, dist_power)).to(geo.dev)
+    ids_dev = torch.from_numpy(geo.ids.astype(np.int64)).to(geo.dev)
+    keep = torch.nonzero(ids_dev < geo.n_ch).flatten()
+
+    def site_arrays(site: int):
+        gauss, grad = K.gb_channels(geo.Pg, geo.cg, site, geo.sizes, geo.n_ch, centers, width, CLIP)
+        feats = torch.zeros((geo.T, cmap.n_fg_sites, geo.n_ch, n_basis), dtype=torch.float32, device=geo.dev)
+        if keep.numel():
+            feats[:, keep, ids_dev[keep], :] = gauss[:, ids_dev[keep], :]
+        return feats.reshape(geo.T, cmap.n_fg_sites, geo.n_ch * n_basis), grad.reshape(geo.T, geo.n_ch * n_basis, 3)
+
+    def feat_of(site):
+        return K.like_input(site_arrays(site)[0], points)
+
+    def div_of(site):
+        return K.like_input(site_arrays(site)[1], points)
+
+    sites = range(cmap.n_cg_sites)
+    if lazy:
+        feats = (feat_of(s) for s in sites)
+        divs = (div_of(s) for s in sites)
+    else:
+        feats = [feat_of(s) for s in sites]
+        divs = [div_of(s) for s in sites]
+    return {KNAME_FEATS: feats, KNAME_DIVS: divs, KNAME_NAMES: None}
+
+
+# ----------------------------------------------------------------------------------------
+# fused fit of the [id_feat | gb_feat] featuriser pair
+
+
+def _bound_gb_kwargs(f) -> Optional[dict]:
+    """kwargs of a gb_feat bound with Curry / util.curry / functools.partial, else None."""
+    func = getattr(f, "func", None)
+    if func is not gb_feat:
+        return None
+    if getattr(f, "args", ()):
+        return None
+    kw = dict(getattr(f, "kwargs", None) or getattr(f, "keywords", None) or {})
+    allowed = {"outer", "inner", "n_basis", "width", "dist_power", "batch_size", "lazy", "div_method",
+               "drop_last_channel"}
+    if "outer" not in kw or not set(kw) <= allowed:
+        return None
+    return kw
+
+
+def recognise(featurizers) -> Optional[Tuple[bool, Optional[dict]]]:
+    """(use_id, gb kwargs or None) if the list is [id_feat], [gb] or [id_feat, gb]; else None."""
+    fs = list(featurizers)
+    if len(fs) == 1 and fs[0] is id_feat:
+        return True, None
+    if len(fs) == 1:
+        kw = _bound_gb_kwargs(fs[0])
+        return (False, kw) if kw is not None else None
+    if len(fs) == 2 and fs[0] is id_feat:
+        kw = _bound_gb_kwargs(fs[1])
+        return (True, kw) if kw is not None else None
+    return None
+
+
+def fit_id_gb(
+    traj,
+    coord_map: LinearMap,
+    kbt: float,
+    n_constraint_frames: int,
+    constraints: Constraints,
+    l2_regularization: float,
+    frame_indices,
+    rng,
+    comm,
+    use_id: bool,
+    gb_kwargs: Optional[dict],
+    dense_featurizer,
+) -> CLAFTMap:
+    """qp_feat_linear_map (featlinearmap.py:249-394) for id_feat and/or gb_feat features, fused."""
+    import torch
+
+    kw = dict(gb_kwargs or {})
+    drop_last = kw.pop("drop_last_channel", True)
+    geo = _Geometry(traj.coords, coord_map, constraints, drop_last)
+    n_basis = int(kw.get("n_basis", 10)) if gb_kwargs is not None else 1
+    width = float(kw.get("width", 1.0))
+    centers_h = (gb_centers(kw["outer"], kw.get("inner", 0), n_basis, kw.get("dist_power", 0.5))
+                 if gb_kwargs is not None else np.zeros(1, dtype=np.float32))
+    centers = torch.from_numpy(centers_h).to(geo.dev)
+    n_id = geo.G if use_id else 0
+    n_ch = geo.n_ch if gb_kwargs is not None else 0
+    n_feat = n_id + n_ch * n_basis
+    if n_feat == 0:
+        raise ValueError("featuriser produces no features")
+    Fg = geo.group_forces(traj.forces)
+    ld = -(-n_feat // 128) * 128
+    R3 = torch.empty((geo.T, ld, 3), dtype=Fg.dtype, device=geo.dev)
+    if ld > n_feat:
+        R3[:, n_feat:, :] = 0
+    Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).to(geo.dev)  # (n_cg, G) float64
+    n_cg = coord_map.n_cg_sites
+    gen = np.random.default_rng() if rng is None else rng
+    coefs: List[np.ndarray] = []
+    used: List[np.ndarray] = []
+    for site in range(n_cg):
+        K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
+        Gm = K.gram(R3, None, None, n_feat, R3.dtype)
+        all_reduce_sum_(Gm, comm)
+        idx = np.asarray(frame_indices[site]) if frame_indices is not None else gen.choice(
+            geo.T, size=n_constraint_frames, replace=False)
+        used.append(idx)
+        sel = torch.as_tensor(idx, device=geo.dev)
+        S = len(idx)
+        A = torch.zeros((S, n_cg, n_feat), dtype=torch.float64, device=geo.dev)
+        if n_id:
+            A[:, :, :n_id] = Mg.unsqueeze(0)
+        if n_ch:
+            gauss, _ = K.gb_channels(geo.Pg[sel].contiguous(), geo.cg[sel].contiguous(), site, geo.sizes, n_ch,
+                                     centers, width, CLIP)
+            A[:, :, n_id:] = (Mg[:, :n_ch].unsqueeze(0).unsqueeze(-1) * gauss.to(torch.float64).unsqueeze(1)).reshape(
+                S, n_cg, n_ch * n_basis)
+        b = torch.zeros((S, n_cg), dtype=torch.float64, device=geo.dev)
+        b[:, site] = 1
+        X, stats = K.eq_qp_solve(Gm, float(l2_regularization), None, A.reshape(S * n_cg, n_feat).contiguous(),
+                                 b.reshape(-1, 1).contiguous(), schur_reg=1e-12, n_refine=3)
+        st = stats.cpu().numpy()
+        if st[0] != 0 or not np.isfinite(st[1]):
+            raise ValueError("Map optimization failed.")
+        coefs.append(X[0].cpu().numpy())
+    coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
+
+    def apply_f(points, copoints):
+        g2 = _Geometry(copoints, coord_map, constraints, drop_last)
+        out = K.gb_apply(g2.group_forces(points), g2.Pg, g2.cg, g2.sizes, n_id, n_ch, centers, width, CLIP,
+                         coef_dev.to(g2.dev))
+        return K.like_input(out, points)
+
+    from .featlinearmap import _feat_linear_mapping
+
+    dense = _feat_linear_mapping(featurizer=dense_featurizer, coefs=coefs, mapping=coord_map,
+                                 constraints=constraints)
+    force_map = CLAMap(scale=dense.scale, trans=dense.trans, n_fg_sites=coord_map.n_fg_sites,
+                       n_cg_sites=n_cg, zeroes_check=False, apply=apply_f,
+                       tags={"feat_names": None, "coef_list": coefs, "constraint_frames": used})
+    return CLAFTMap(coord_map=coord_map, force_map=force_map)

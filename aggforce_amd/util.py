@@ -78,6 +78,7 @@ def curry(func: Callable[..., T], *args, **kwargs) -> Callable[..., T]:
     def bound(*a, **k) -> T:
         return func(*a, *args, **k, **kwargs)
 
+    bound.func, bound.args, bound.kwargs = func, args, kwargs  # introspection (fused featurisers)
     return bound
 
 

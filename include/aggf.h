@@ -57,7 +57,8 @@ int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes)
  * (grp_ptr[n_red+1], grp_atoms[N]) -- column j of the reference's con_mat
  * (make_bond_constraint_matrix, qplinear.py:147-164) has ones at
  * grp_atoms[grp_ptr[j] .. grp_ptr[j+1]); pass NULL,NULL for no constraints
- * (then n_red must equal N).  Products are formed in `compute_dtype`
+ * (then column j is atom j and n_red <= N: only the first n_red atoms are used, the
+ * rest of each frame row is ignored -- row padding).  Products are formed in `compute_dtype`
  * (AGGF_F64 reproduces the reference, whose con_mat is float64 even for float32
  * forces; AGGF_F32 uses fp32 MFMA with partial sums combined in fp64).
  * G: (n_red, n_red) float64, full symmetric matrix; accumulate != 0 adds to it
@@ -156,6 +157,48 @@ int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, i
                             const void* mean, const void* noise, uint64_t seed,
                             int64_t frame_offset, double var, double kbt, void* out_coords,
                             void* out_forces, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K4  Gaussian-basis distance featuriser (gb_feat) and the featurised regression
+ *     matrix, without the one-hot (T, N, n_feat) feature tensor.
+ *
+ * Replaces qp/jaxfeat.py:20-567 (gb_feat, gaussian_dist_basis, clipped_gauss,
+ * channel_allocate, gb_subfeat, gb_subfeat_jac; the JAX jacrev is replaced by its
+ * closed form), map/tools.py:63-104 (smear_map product) and the dense einsum of
+ * qp/featlinearmap.py:361-369 / 512-520.  "Groups" are the constraint groups in
+ * id_feat label order (featlinearmap.py:598-609): group g = feature channel g.
+ * All atoms of a group share the group-mean position, hence one distance
+ * r[t,ch] = |Pg[t,ch] - cg[t,site]| and one Gaussian row
+ * g_k(r) = max(exp(-((r - centers[k])/width)^2), clip) - clip  (float32, as JAX).
+ * ------------------------------------------------------------------------- */
+/* out[t,g,:] = sum (mean != 0: mean) over the atoms of group g of X[t,a,:];
+ * X: (T, N, 3) in in_dtype; out: (T, n_groups, 3) in out_dtype; CSR groups. */
+int aggf_group_reduce(const void* X, int64_t T, int32_t N, int in_dtype, const int32_t* grp_ptr,
+                      const int32_t* grp_atoms, int32_t n_groups, int mean, int out_dtype,
+                      void* out, void* stream);
+/* compact features of cg site `site`: gauss (T, n_ch, n_basis) and
+ * grad (T, n_ch, n_basis, 3) = |ch| g_k'(r) (Pg - cg)/r  (the per-channel divergence,
+ * jaxfeat.py:544-565).  Pg: (T, G, 3) group means, cg: (T, n_cg, 3), sizes: G. */
+int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
+                     int32_t site, const float* sizes, int32_t n_ch, const float* centers,
+                     int32_t n_basis, double width, double clip, float* gauss, float* grad,
+                     void* stream);
+/* R3 (T, ld_feat, 3) in f_dtype, the regression matrix of featlinearmap.py:361-369 in the
+ * layout aggf_gram consumes: columns [0, n_id) = Fg (id_feat block, n_id = 0 or G), then
+ * R3[t, n_id + ch*n_basis + k, d] = g_k(r) Fg[t,ch,d] + kbt |ch| g_k'(r) u_d for ch < n_ch.
+ * Fg: (T, G, 3) group force sums in f_dtype.  Columns beyond n_id + n_ch*n_basis are not
+ * written (pass n_red = that count to aggf_gram, which ignores the rest). */
+int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+                   int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
+                   int32_t n_ch, const float* centers, int32_t n_basis, double width, double clip,
+                   double kbt, int32_t ld_feat, void* R3, void* stream);
+/* out (T, n_cg, 3) float64: application of the feature-linear force map
+ * (featlinearmap.py:512-520 + map/core.py:428-430) for all sites;
+ * coef: (n_cg, n_feat) float64, n_feat = n_id + n_ch*n_basis. */
+int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+                  int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, int32_t n_ch,
+                  const float* centers, int32_t n_basis, double width, double clip,
+                  const double* coef, int32_t n_feat, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Synthetic trajectories for benchmarks and full-size property tests (no

@@ -1,0 +1,143 @@
+"""GPU: gb_feat (K4) and the featurised fit against the CPU oracle.  gb_feat is parity-unpinned
+(the reference needs JAX); the oracle restates jaxfeat.py and is self-checked by finite
+differences in tests/test_oracle_golden.py."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from aggforce_amd import LinearMap, Trajectory, project_forces  # noqa: E402
+from aggforce_amd.qp import Multifeaturize, gb_feat, id_feat, qp_feat_linear_map  # noqa: E402
+from aggforce_amd.qp.featlinearmap import constraint_group_labels  # noqa: E402
+from aggforce_amd.util import Curry  # noqa: E402
+from oracle import aggforce_oracle as orc  # noqa: E402
+
+KBT = 0.6955215
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def system(T=40, N=14, seed=0, dtype=np.float32):
+    rng = np.random.default_rng(seed)
+    coords = (6 * rng.random((T, N, 3)) + 1).astype(dtype)
+    forces = (25 * rng.standard_normal((T, N, 3))).astype(dtype)
+    cons = {frozenset([1, 2]), frozenset([4, 5]), frozenset([5, 6]), frozenset([10, 13])}
+    # two-atom sites: no cg site coincides with a (smeared) atom, so r > 0 everywhere (at r == 0 the
+    # reference's norm gradient is NaN and poisons the whole site)
+    cmat = orc.list_mapping_matrix([[0, 1], [4, 7], [8, 9], [12, 13]], N)
+    return coords, forces, cons, cmat
+
+
+def oracle_feats(coords, cmat, cons, ids, n_channels, **kw):
+    N = coords.shape[1]
+    smear = orc.smear_matrix(orc.reduce_constraint_sets(cons), N) if cons else np.eye(N, dtype=np.float32)
+    cg = orc.linearmap_apply(coords, cmat)
+    out = [orc.gb_feat_site(coords, cg[:, c, :], ids, smear, n_channels=n_channels, **kw)
+           for c in range(cmat.shape[0])]
+    return [o[0] for o in out], [o[1] for o in out]
+
+
+@pytest.mark.parametrize("with_cons", [True, False])
+@pytest.mark.parametrize("drop_last", [True, False])
+def test_gb_feat_dense_matches_oracle(with_cons, drop_last):
+    coords, forces, cons, cmat = system()
+    if not with_cons:
+        cons = set()
+    cmap = LinearMap(cmat)
+    ids = constraint_group_labels(coords.shape[1], cons)
+    kw = dict(outer=8.0, inner=0.0, n_basis=5, width=1.0, dist_power=0.5)
+    res = gb_feat(coords, cmap, cons, lazy=False, drop_last_channel=drop_last, **kw)
+    n_ch = int(ids.max()) + (0 if drop_last else 1)
+    of, od = oracle_feats(coords, cmat, cons, ids, n_ch, **kw)
+    assert res["names"] is None and len(res["feats"]) == 4
+    for c in range(4):
+        f, d = res["feats"][c], res["divs"][c]
+        assert f.dtype == np.float32 and f.shape == of[c].shape and d.shape == od[c].shape
+        assert np.max(np.abs(f - of[c])) < 2e-6
+        assert np.isfinite(od[c]).all() and np.isfinite(d).all()
+        assert np.max(np.abs(d - od[c])) < 2e-5
+    lazy = gb_feat(coords, cmap, cons, drop_last_channel=drop_last, **kw)
+    assert rel(next(iter(lazy["feats"])), of[0]) < 1e-5
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+def test_fused_feat_fit_matches_dense_path_and_oracle(dtype):
+    coords, forces, cons, cmat = system(T=60, dtype=dtype)
+    cmap = LinearMap(cmat)
+    kw = dict(outer=8.0, inner=0.0, n_basis=4, width=1.0)
+    feat = Multifeaturize([id_feat, Curry(gb_feat, **kw)])
+    rng = np.random.default_rng(3)
+    frames = [rng.choice(60, size=6, replace=False) for _ in range(4)]
+    traj = Trajectory(coords=coords, forces=forces)
+    fused = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=frames, l2_regularization=10.0)
+    dense = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=frames, l2_regularization=10.0,
+                               fused=False)
+    cf = np.stack(fused.force_map.tags["coef_list"])
+    cd = np.stack(dense.force_map.tags["coef_list"])
+    assert rel(cf, cd) < 2e-4
+    mf, md = fused(traj), dense(traj)
+    assert rel(mf.forces, md.forces) < 2e-4 and rel(mf.coords, md.coords) < 1e-6
+    # oracle: dense features in our label order, exact solve.  With several sampled frames the constraint
+    # rows are nearly dependent (smallest singular value ~1e-3 of the largest) and the optimum moves with
+    # float32-level feature differences, so the end-to-end comparison uses ONE constraint frame per site
+    # (well conditioned); K4's regression matrix, the Gram and the solve are compared piecewise below.
+    ids = constraint_group_labels(coords.shape[1], cons)
+    G = int(ids.max()) + 1
+    onehot = np.zeros((60, coords.shape[1], G), dtype=np.float32)
+    onehot[:, np.arange(coords.shape[1]), ids] = 1
+    gf, gd = oracle_feats(coords.astype(np.float32), cmat, cons, ids, G - 1, dist_power=0.5, **kw)
+    feats = [np.concatenate([onehot, g], axis=2) for g in gf]
+    divs = [np.concatenate([np.zeros((60, G, 3), np.float32), d], axis=1) for d in gd]
+    one = [f[:1] for f in frames]
+    fused1 = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=one, l2_regularization=10.0)
+    ocoef = orc.qp_feat_linear_map(forces, cmat, feats, divs, KBT, one, 10.0)
+    cf1 = np.stack(fused1.force_map.tags["coef_list"])
+    assert rel(cf1, np.stack(ocoef)) < 1e-3
+    assert rel(fused1(traj).forces, orc.cla_apply(forces, feats, divs, ocoef)) < 1e-3
+    # piecewise: regression matrix and Gram of site 1 against the oracle's
+    from aggforce_amd import _kernels as K
+    from aggforce_amd.qp.gbfeat import CLIP, _Geometry, gb_centers
+
+    geo = _Geometry(coords, cmap, cons, True)
+    Fg = geo.group_forces(forces)
+    n_feat = G + 4 * (G - 1)
+    R3 = torch.zeros((60, 128, 3), dtype=Fg.dtype, device="cuda")
+    K.gb_regmat(Fg, geo.Pg, geo.cg, 1, geo.sizes, G, G - 1, torch.from_numpy(gb_centers(8.0, 0.0, 4, 0.5)).cuda(), 1.0,
+                CLIP, KBT, R3)
+    reg_o, qp_o = orc.feat_site_problem(forces, feats[1], divs[1], KBT, 0.0)
+    assert rel(np.swapaxes(R3.cpu().numpy()[:, :n_feat, :], 1, 2).reshape(-1, n_feat), reg_o) < 2e-6
+    assert rel(K.gram(R3, None, None, n_feat, R3.dtype).cpu().numpy(), qp_o) < 1e-5
+    # constraint rows are satisfied on the sampled frames: sum_a W_c(t)[a] M[c',a] = delta_cc'
+    scale = fused.force_map.scale(coords[frames[1]])
+    assert np.max(np.abs(np.einsum("tca,da->tcd", scale, cmat)[:, 1, :] - np.eye(4)[1])) < 1e-5
+    # through project_forces, gb only and id only
+    res = project_forces(coords, forces, cmap, constrained_inds=cons, method=qp_feat_linear_map,
+                         featurizer=Multifeaturize([Curry(gb_feat, **kw)]), kbt=KBT, frame_indices=frames)
+    assert res["mapped_forces"].shape == (60, 4, 3) and np.isfinite(res["residual"])
+    only_id = qp_feat_linear_map(traj, cmap, Multifeaturize([id_feat]), KBT, constraints=cons, frame_indices=frames)
+    ref_id = qp_feat_linear_map(traj, cmap, id_feat, KBT, constraints=cons, frame_indices=frames)
+    assert rel(only_id(traj).forces, ref_id(traj).forces) < 2e-4
+
+
+def test_fused_fit_larger_system_runs_and_reduces_residual():
+    """512 atoms, 16 sites, n_basis 8: the dense feature tensor would be 512*4104*T floats per
+    site; the fused path never forms it.  Featurised maps must not be worse than the linear map
+    on the training set (their feature space contains the linear maps' id features)."""
+    rng = np.random.default_rng(11)
+    T, N, n_cg = 1500, 512, 16
+    base = np.stack(np.meshgrid(np.arange(8), np.arange(8), np.arange(8), indexing="ij"), -1).reshape(-1, 3) * 1.5
+    coords = (base[None] + 0.3 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    forces = (30 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    forces += 3.0 * (coords - coords.mean(axis=1, keepdims=True))  # configuration-dependent part
+    cmap = LinearMap([[i * 32, i * 32 + 5] for i in range(n_cg)], n_fg_sites=N)
+    cons = {frozenset([3 * i, 3 * i + 1]) for i in range(0, 60)}
+    feat = Multifeaturize([id_feat, Curry(gb_feat, outer=8.0, n_basis=8)])
+    res = project_forces(coords, forces, cmap, constrained_inds=cons, method=qp_feat_linear_map, featurizer=feat,
+                         kbt=KBT, rng=np.random.default_rng(0), l2_regularization=10.0)
+    lin = project_forces(coords, forces, cmap, constrained_inds=cons, l2_regularization=0.0)
+    assert np.isfinite(res["residual"]) and res["residual"] < lin["residual"] * 1.02
+    assert len(res["tmap"].force_map.tags["coef_list"]) == n_cg
