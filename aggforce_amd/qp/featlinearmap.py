@@ -247,12 +247,15 @@ def qp_feat_linear_map(
         used_frames.append(idx)
         A, b = _constraint_rows(feat_dev, ind, M_dev, idx)
         r3 = _site_regression(forces, feat_dev, div_dev, kbt)
-        G = K.gram(r3, None, None, r3.shape[1], r3.dtype)
+        G = K.gram(r3, None, None, r3.shape[1], torch.float64)  # exact Gram of R (see qp/gbfeat.py)
         all_reduce_sum_(G, comm)
         X, stats = K.eq_qp_solve(G, float(l2_regularization), None, A, b, schur_reg=1e-12, n_refine=3)
         st = stats.cpu().numpy()
         if st[0] != 0 or not np.isfinite(st[1]):
-            raise ValueError("Map optimization failed.")
+            raise ValueError(
+                f"Map optimization failed. (site {site if 'site' in dir() else ind}: pivot {int(st[0])}, "
+                f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
+            )
         coefs.append(X[0].cpu().numpy())
         del feat_dev, div_dev, r3, G
     force_map = _feat_linear_mapping(

@@ -206,7 +206,10 @@ def fit_id_gb(
     used: List[np.ndarray] = []
     for site in range(n_cg):
         K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
-        Gm = K.gram(R3, None, None, n_feat, R3.dtype)
+        # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
+        # exceeds l2 = 10 relative to force-squared sums of ~1e8 and P is no longer numerically positive
+        # definite; the exact Gram of the float32 regression matrix always is
+        Gm = K.gram(R3, None, None, n_feat, torch.float64)
         all_reduce_sum_(Gm, comm)
         idx = np.asarray(frame_indices[site]) if frame_indices is not None else gen.choice(
             geo.T, size=n_constraint_frames, replace=False)
@@ -227,7 +230,10 @@ def fit_id_gb(
                                  b.reshape(-1, 1).contiguous(), schur_reg=1e-12, n_refine=3)
         st = stats.cpu().numpy()
         if st[0] != 0 or not np.isfinite(st[1]):
-            raise ValueError("Map optimization failed.")
+            raise ValueError(
+                f"Map optimization failed. (site {site if 'site' in dir() else ind}: pivot {int(st[0])}, "
+                f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
+            )
         coefs.append(X[0].cpu().numpy())
     coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
 

@@ -33,6 +33,8 @@ WORKLOADS = {
     "c3": (1_000_000, 4096, 256, "f64"),   # BASELINE.json configs[2] -- the metric's configuration
     "c2": (100_000, 1024, 64, "f32"),      # configs[1]
     "tiny": (4096, 256, 16, "f64"),        # plumbing check
+    "c4": (20_000, 1024, 64, "f32"),       # configs[3]: featurised id_feat + gb_feat (n_basis 8, cutoff 8)
+    "c5": (500_000, 2048, 128, "f32"),     # configs[4]: joptgauss_map, var 0.01 (4 GPUs in BASELINE)
 }
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (MI355X_MICROARCH.md / SURVEY 8(d))
 SEED = 42100
@@ -128,9 +130,26 @@ def main():
     coords = K.synth_normal(T_local, N, tdt, SEED + 1, frame_offset=begin, sigma=0.3, lattice=1.5)
     cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
     kwargs = {"comm": comm} if comm is not None else {}
+    constraints = set()
+    KBT = 0.6955215
+    if args.workload == "c4":
+        # bond-pair constraints {3i, 3i+1}; every cg site is a constrained atom (its smeared position
+        # differs from the site, r > 0 -- as for CLN025's CA/HA; with r == 0 the reference is NaN)
+        from aggforce_amd.qp import Multifeaturize, gb_feat, id_feat, qp_feat_linear_map
+        from aggforce_amd.util import Curry
+
+        constraints = {frozenset([3 * i, 3 * i + 1]) for i in range(N // 3)}
+        cmap = LinearMap([[3 * (i * (N // n_cg) // 3)] for i in range(n_cg)], n_fg_sites=N)
+        kwargs.update(method=qp_feat_linear_map, kbt=KBT, l2_regularization=10.0, n_constraint_frames=20,
+                      featurizer=Multifeaturize([id_feat, Curry(gb_feat, outer=8.0, inner=0.0, n_basis=8, width=1.0)]),
+                      rng=np.random.default_rng(SEED))
+    elif args.workload == "c5":
+        from aggforce_amd import joptgauss_map
+
+        kwargs.update(method=joptgauss_map, var=0.01, kbt=KBT, seed=SEED, frame_offset=begin)
 
     def step():
-        return project_forces(coords=coords, forces=forces, coord_map=cmap, constrained_inds=set(), **kwargs)
+        return project_forces(coords=coords, forces=forces, coord_map=cmap, constrained_inds=constraints, **kwargs)
 
     def barrier():
         if comm is not None:
@@ -156,13 +175,22 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
-    W = out["tmap"].force_map.standard_matrix
-    cons_resid = float(np.max(np.abs(cmap.standard_matrix @ W.T - np.eye(n_cg))))
+    fmap = getattr(out["tmap"], "force_map", None)
+    if hasattr(fmap, "standard_matrix"):
+        W = fmap.standard_matrix
+        cons_resid = float(np.max(np.abs(cmap.standard_matrix @ W.T - np.eye(n_cg))))
+    else:
+        cons_resid = None
 
     if rank == 0:
         gram = stages.get("gram", {"ms": float("nan"), "calls": 1})
         gram_ms = gram["ms"] / max(1, gram["calls"])
-        flops = 3.0 * T_local * N * (N + 1)  # SYRK, upper triangle, per launch
+        n_gram = N
+        if args.workload == "c4":
+            n_gram = (N - N // 3) * 9 - 8   # G id columns + 8 (G - 1) Gaussian columns, G = N - N/3 groups
+        elif args.workload == "c5":
+            n_gram = N + n_cg
+        flops = 3.0 * T_local * n_gram * (n_gram + 1)  # SYRK, upper triangle, per launch
         achieved = flops / (gram_ms * 1e-3) / 1e12
         line = {
             "metric": "frames/sec through project_forces (Gram+solve), 1e6x4096-atom traj, 1/2/4/8 GPU",
