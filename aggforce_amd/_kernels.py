@@ -209,8 +209,11 @@ def linearmap_apply(
     matrix: torch.Tensor,
     nan_fill: Optional[float] = None,
     want_sumsq: bool = False,
+    nan_probe: Optional[torch.Tensor] = None,
 ):
-    """out (T, n_cg, 3) in matrix.dtype; optional device scalar sum of squares."""
+    """out (T, n_cg, 3) in matrix.dtype; optional device scalar sum of squares.
+
+    ``nan_probe``: zeroed int32 device scalar that is set to 1 if ``points`` holds a NaN."""
     l = lib()
     T, N, D = points.shape
     n_cg, N2 = matrix.shape
@@ -228,8 +231,8 @@ def linearmap_apply(
             l.aggf_linearmap_apply(ptr(points), T, N, dtype_code(points.dtype), ptr(matrix), n_cg,
                                    dtype_code(matrix.dtype),
                                    _lib.NAN_REPLACE if nan_fill is not None else _lib.NAN_PROPAGATE,
-                                   0.0 if nan_fill is None else float(nan_fill), ptr(out), ptr(sumsq), ptr(ws), need,
-                                   stream_ptr()),
+                                   0.0 if nan_fill is None else float(nan_fill), ptr(out), ptr(sumsq), ptr(nan_probe),
+                                   ptr(ws), need, stream_ptr()),
             "aggf_linearmap_apply",
         )
     return (out, sumsq) if want_sumsq else out

@@ -34,7 +34,7 @@ PROTOTYPES = {
     "aggf_eq_qp_solve": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_expand_map": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aggf_linearmap_apply_workspace_bytes": (_sz, [_i64, _i32, _i32]),
-    "aggf_linearmap_apply": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_linearmap_apply": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
     "aggf_slice_gather": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, _vp, _vp]),
     "aggf_has_nan": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "aggf_not_close": (C.c_int, [_vp, _vp, _i64, C.c_int, _dbl, _dbl, _vp, _vp]),

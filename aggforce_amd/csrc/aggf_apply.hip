@@ -26,7 +26,7 @@ template <typename TIn, typename TC, bool NANREP>
 __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
     int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
-    double* __restrict__ sumsq_partials) {
+    double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
   using MF = Mfma<TC>;
   using acc_t = typename MF::acc_t;
   constexpr int VI = 16 / sizeof(TIn);   // input elements per 16-byte chunk
@@ -56,6 +56,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
 
   TIn rp[P_PER_THREAD][VI];
   TC rm[M_PER_THREAD][VM];
+  bool saw_nan = false;  // any NaN among the P values this thread staged (fused _has_nans scan)
 
   auto load_stage = [&](int s) {
     const int a0 = s * AP_KA;
@@ -112,7 +113,10 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       const int c = tid + q * AP_THREADS;
       const int r = c / P_CH_ROW, col = (c - r * P_CH_ROW) * VI;
 #pragma unroll
-      for (int e = 0; e < VI; ++e) x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[q][e], NANREP, nan_fill);
+      for (int e = 0; e < VI; ++e) {
+        saw_nan |= (rp[q][e] != rp[q][e]);
+        x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[q][e], NANREP, nan_fill);
+      }
     }
 #pragma unroll
     for (int q = 0; q < M_PER_THREAD; ++q) {
@@ -155,6 +159,8 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
     if (s + 1 < n_stage) store_stage(cur ^ 1);
     __syncthreads();
   }
+
+  if (nan_seen && cb == 0 && __any(saw_nan) && lane == 0) atomicOr(nan_seen, 1);
 
   // epilogue: out[t, c, d]; optional sum of squares (fixed order: lane tree, then waves)
   double ss = 0.0;
@@ -217,8 +223,8 @@ __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict
 
 template <typename TIn, typename TC>
 static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
-                       int nan_mode, double nan_fill, void* out, double* sumsq, void* ws,
-                       size_t ws_bytes, hipStream_t stream) {
+                       int nan_mode, double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
+                       void* ws, size_t ws_bytes, hipStream_t stream) {
   const int ncb = (int)ceil_div(n_cg, AP_TC);
   const int64_t nfb = ceil_div(T, AP_TF);
   const int64_t nblocks = nfb * ncb;
@@ -235,11 +241,11 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   if (nan_mode == AGGF_NAN_REPLACE)
     hipLaunchKernelGGL((apply_kernel<TIn, TC, true>), dim3((unsigned)nblocks), dim3(AP_THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)nan_fill, p_vec_ok,
-                       m_vec_ok, (TC*)out, partials);
+                       m_vec_ok, (TC*)out, partials, nan_seen);
   else
     hipLaunchKernelGGL((apply_kernel<TIn, TC, false>), dim3((unsigned)nblocks), dim3(AP_THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)0, p_vec_ok,
-                       m_vec_ok, (TC*)out, partials);
+                       m_vec_ok, (TC*)out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, sumsq);
@@ -260,21 +266,21 @@ extern "C" size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int
 
 extern "C" int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype,
                                     const void* Mx, int32_t n_cg, int out_dtype, int nan_mode,
-                                    double nan_fill, void* out, double* sumsq, void* ws,
-                                    size_t ws_bytes, void* stream_v) {
+                                    double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
+                                    void* ws, size_t ws_bytes, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!P || !Mx || !out) return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: NULL pointer");
   if (T <= 0 || N <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: empty problem");
   if (nan_mode != AGGF_NAN_PROPAGATE && nan_mode != AGGF_NAN_REPLACE)
     return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: bad nan_mode");
   if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    return apply_typed<double, double>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+    return apply_typed<double, double>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    return apply_typed<float, double>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+    return apply_typed<float, double>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    return apply_typed<float, float>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+    return apply_typed<float, float>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
-    return apply_typed<double, float>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, ws, ws_bytes, stream);
+    return apply_typed<double, float>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   return fail(AGGF_ERR_ARG, "aggf_linearmap_apply: unsupported dtype combination (in %d, out %d)",
               in_dtype, out_dtype);
 }

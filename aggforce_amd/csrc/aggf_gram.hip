@@ -252,10 +252,10 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "unsupported vmcnt");
 }
 
-template <typename T>
+template <typename T, int ABL = 0>
 __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
-    const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_sel,
-    int64_t frames_per_split, T* __restrict__ slabs) {
+    const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
+    const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   constexpr int KB = GramCfg<T>::KB;
@@ -277,20 +277,18 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  // workgroup -> (split, tile): tile index fastest so that co-running workgroups share frames
+  // workgroup -> (split, tile), XCD-aware.  Workgroups b and b+8 land on the same XCD (observed
+  // round-robin dispatch; only speed depends on it), and an XCD runs 64 of them at a time (32 CUs x
+  // 2).  Give each XCD 64 CONSECUTIVE entries of the (split, tile) list, whose tile order walks
+  // 8x8 super-blocks of the tile grid (tile_table): those 64 workgroups then share 16 panels in
+  // their XCD's L2 instead of streaming 128 panels past it (FETCH_SIZE: 2.9 TB per launch before).
   const int b = blockIdx.x;
-  const int ks = b / n_sel;
-  const int tile_lin = b - ks * n_sel;  // row-major upper-triangle index
-  int idx = tile_lin, ti = 0;
-  {
-    int rowlen = nt1;
-    while (idx >= rowlen) {
-      idx -= rowlen;
-      --rowlen;
-      ++ti;
-    }
-  }
-  const int tj = ti + idx;
+  const int v = (((b >> 3) >> 6) * 8 + (b & 7)) * 64 + ((b >> 3) & 63);
+  if (v >= ksplit * n_tiles) return;  // grid is padded to a multiple of 512
+  const int ks = v / n_tiles;
+  const int packed = tile_table[v - ks * n_tiles];
+  const int ti = packed >> 16, tj = packed & 0xffff;
+  const int tile_lin = ti * nt1 - ti * (ti - 1) / 2 + (tj - ti);  // row-major upper-triangle index
 
   const int64_t t_begin = (int64_t)ks * frames_per_split;
   int64_t t_end = t_begin + frames_per_split;
@@ -314,13 +312,11 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
     l_off[q] = panel * PANEL_ELEMS + r * ROW_STRIDE + cp * PE;
   }
 
-  auto issue_stage = [&](int s) {
+  // rows past the end of this split's frame range must read as zeros (last stage only)
+  auto prep_stage = [&](int s) {
     const int64_t t0 = t_begin + (int64_t)s * KB;
-    const T* gbase = X + t0 * ld;
-    T* lbase = smem + (s % NBUF) * BUF_ELEMS;
-    const bool partial = t0 + KB > t_end;
-    if (partial) {
-      // rows past the end of this split's frame range must read as zeros
+    if (t0 + KB > t_end) {
+      T* lbase = smem + (s % NBUF) * BUF_ELEMS;
       const int first = (int)(t_end - t0);
       for (int e = tid; e < PANELS * (KB - first) * ROW_ELEMS; e += GRAM_THREADS) {
         const int panel = e / ((KB - first) * ROW_ELEMS);
@@ -329,16 +325,21 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
         lbase[panel * PANEL_ELEMS + r * ROW_STRIDE + c] = 0;
       }
     }
-#pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-      const bool row_ok = t0 + p_row[q] < t_end;
-      const bool lane_ok = !p_half[q] || lane < 32;
-      if (row_ok && lane_ok) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(gbase + g_off[q]),
-            (__attribute__((address_space(3))) void*)(lbase + l_off[q]), 16, 0, 0);
-      }
+  };
+  auto issue_piece = [&](int s, int q) {
+    const int64_t t0 = t_begin + (int64_t)s * KB;
+    const bool row_ok = t0 + p_row[q] < t_end;
+    const bool lane_ok = !p_half[q] || lane < 32;
+    if (row_ok && lane_ok) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(X + t0 * ld + g_off[q]),
+          (__attribute__((address_space(3))) void*)(smem + (s % NBUF) * BUF_ELEMS + l_off[q]), 16, 0, 0);
     }
+  };
+  auto issue_stage = [&](int s) {
+    prep_stage(s);
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) issue_piece(s, q);
   };
 
   acc_t acc[4][4];
@@ -358,8 +359,10 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
   asm volatile("" ::: "memory");
 
   for (int it = 0; it < n_it; ++it) {
-    if (it + 2 < n_it) issue_stage(it + 2);
-    const T* pa = smem + (it % NBUF) * BUF_ELEMS;
+    // DMAs of stage it+2 first (placing them between the MFMA groups instead, or raising the
+    // wave priority around the MFMA groups, measured no better: tools/gram_ablate.hip history)
+    if (ABL == 0 && it + 2 < n_it) issue_stage(it + 2);
+    const T* pa = smem + ((ABL ? it % 2 : it % NBUF)) * BUF_ELEMS;
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
@@ -376,13 +379,14 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
       }
     }
     // stage it+1 must have landed (this wave's pieces), stage it+2 may stay in flight
-    if (it + 2 < n_it) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
+    if (ABL < 2) {
+      if (it + 2 < n_it) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
   }
 
-  const int ksplit = gridDim.x / n_sel;
   T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
 #pragma unroll
   for (int m = 0; m < 4; ++m)
@@ -394,6 +398,18 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
         const int col = wn * 64 + n * 16 + (lane & 15);
         slab[row * TILE + col] = acc[m][n][r];
       }
+}
+
+// tile_table[k] = (ti << 16) | tj of the k-th upper-triangle tile in 8x8 super-block order
+__global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int nsb = (nt1 + 7) / 8;
+  int k = 0;
+  for (int si = 0; si < nsb; ++si)
+    for (int sj = si; sj < nsb; ++sj)
+      for (int ti = si * 8; ti < si * 8 + 8 && ti < nt1; ++ti)
+        for (int tj = sj * 8; tj < sj * 8 + 8 && tj < nt1; ++tj)
+          if (tj >= ti) table[k++] = (ti << 16) | tj;
 }
 
 // ---------------------------------------------------------------------------
@@ -477,6 +493,7 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
 }
 
 static size_t dtype_size(int dt) { return dt == AGGF_F64 ? 8 : 4; }
+static size_t table_bytes(const GramPlan& p) { return (size_t)round_up((int64_t)p.n_tiles * 4, 256); }
 
 static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
                      bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p) {
@@ -506,6 +523,8 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   // fit into the given workspace: pack chunk gets at most half of it
   p->pack_bytes = 0;
   p->chunk_frames = T;
+  if (ws_bytes < table_bytes(*p) + 1024) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
+  ws_bytes -= table_bytes(*p);
   size_t avail = ws_bytes;
   if (!p->direct) {
     int64_t cf = (int64_t)(ws_bytes / 2 / row_bytes);
@@ -527,15 +546,18 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
 }
 
 template <typename T>
-static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs, double* G,
-                       int32_t n_red, int accumulate, hipStream_t stream) {
+static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs,
+                       int32_t* tile_table, double* G, int32_t n_red, int accumulate, hipStream_t stream) {
   constexpr int KB = GramCfg<T>::KB;
   const int ksplit = p.ksplit;
   int64_t fps = round_up(ceil_div(rows, ksplit), KB);
   if (fps < KB) fps = KB;
   const int64_t nblocks = (int64_t)ksplit * p.n_tiles;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
-  static const bool use_dma = getenv("AGGF_GRAM_NO_DMA") == nullptr;
+  // fp64: LDS-DMA ring (+4 % over register staging); fp32: register staging is faster (its panel
+  // rows are 1.5 DMA pieces, i.e. 8 DMA instructions per wave and stage instead of 6)
+  static const char* force = getenv("AGGF_GRAM_STAGING");  // "dma" | "reg" (benchmarks)
+  const bool use_dma = force ? (force[0] == 'd') : (sizeof(T) == 8);
   if (use_dma) {
     const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);  // 3-stage ring, 76.8 KB
     static thread_local bool attr_done = false;
@@ -544,8 +566,10 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       attr_done = true;
     }
-    hipLaunchKernelGGL((gram_tile_dma_kernel<T>), dim3((unsigned)nblocks), dim3(GRAM_THREADS), lds3,
-                       stream, X, rows, ld, p.nt1, p.n_tiles, fps, slabs);
+    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table);
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_tile_dma_kernel<T>), dim3((unsigned)round_up(nblocks, 512)), dim3(GRAM_THREADS),
+                       lds3, stream, X, rows, ld, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs);
     AGGF_LAUNCH_OK();
   } else {
     const size_t lds = (size_t)2 * 2 * KB * ROW_STRIDE * sizeof(T);
@@ -563,11 +587,14 @@ template <typename TIn, typename TC>
 static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_ptr,
                       const int32_t* grp_atoms, int32_t n_red, double* G, int accumulate,
                       const GramPlan& p, char* ws, hipStream_t stream) {
+  // workspace: [tile table | slabs | pack chunk]
+  int32_t* tile_table = reinterpret_cast<int32_t*>(ws);
+  ws += table_bytes(p);
   TC* slabs = reinterpret_cast<TC*>(ws);
   if (p.direct) {
     // only reachable with TIn == TC
-    return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, G, n_red,
-                           accumulate, stream);
+    return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,
+                           n_red, accumulate, stream);
   }
   TC* pack = reinterpret_cast<TC*>(ws + round_up((int64_t)p.slab_bytes, 256));
   const TIn* F = reinterpret_cast<const TIn*>(Fv);
@@ -579,7 +606,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
                        F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad,
                        pack);
     AGGF_LAUNCH_OK();
-    int rc = launch_gram<TC>(pack, rows, (int64_t)p.n_pad * 3, p, slabs, G, n_red, acc, stream);
+    int rc = launch_gram<TC>(pack, rows, (int64_t)p.n_pad * 3, p, slabs, tile_table, G, n_red, acc, stream);
     if (rc) return rc;
     acc = 1;
   }
@@ -595,7 +622,7 @@ extern "C" size_t aggf_gram_workspace_bytes(int64_t T, int32_t N, int32_t n_red,
   if (T <= 0 || N <= 0 || n_red <= 0) return 0;
   GramPlan p;
   make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups != 0, true, 0, true, &p);
-  return (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 1024;
+  return table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 1024;
 }
 
 extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
@@ -618,7 +645,7 @@ extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int 
   GramPlan p;
   int rc = make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups, aligned, ws_bytes, false, &p);
   if (rc) return rc;
-  if ((size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes > ws_bytes)
+  if (table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes > ws_bytes)
     return fail(AGGF_ERR_WORKSPACE, "aggf_gram: workspace too small");
   char* w = reinterpret_cast<char*>(ws);
   if (in_dtype == AGGF_F64)

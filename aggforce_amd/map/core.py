@@ -157,16 +157,22 @@ class LinearMap:
                 )
             return K.like_input(out, points)
         m = self._device_matrix(out_t, p.device)
-        if self.handle_nans and K.has_nan(p):
-            raw = K.linearmap_apply(p, m, nan_fill=0.0)
-            pushed = K.linearmap_apply(p, m, nan_fill=-1.0)
-            if not K.allclose(raw, pushed, rtol=1e-5, atol=self.nan_check_threshold):
-                raise ValueError(
-                    "NaN handling is on and results seem to depend on NaN "
-                    "positions in input array. Check input and standard_matrix."
-                )
-            return K.like_input(raw, points)
-        return K.like_input(K.linearmap_apply(p, m), points)
+        if not self.handle_nans:
+            return K.like_input(K.linearmap_apply(p, m), points)
+        # plain product with the NaN scan of the input fused into the same pass; only if a NaN was seen
+        # (rare) are the reference's two extra products formed (map/core.py:226-236)
+        probe = torch.zeros(1, dtype=torch.int32, device=p.device)
+        out = K.linearmap_apply(p, m, nan_probe=probe)
+        if not bool(probe.item()):
+            return K.like_input(out, points)
+        raw = K.linearmap_apply(p, m, nan_fill=0.0)
+        pushed = K.linearmap_apply(p, m, nan_fill=-1.0)
+        if not K.allclose(raw, pushed, rtol=1e-5, atol=self.nan_check_threshold):
+            raise ValueError(
+                "NaN handling is on and results seem to depend on NaN "
+                "positions in input array. Check input and standard_matrix."
+            )
+        return K.like_input(raw, points)
 
     def flat_call(self, flattened):
         """Apply to (n_frames, n_fg_sites*3) and return (n_frames, n_cg_sites*3)."""

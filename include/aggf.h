@@ -112,12 +112,14 @@ int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
  * nan_mode AGGF_NAN_REPLACE reads NaN inputs as nan_fill (the reference's two
  * passes with NaN->0 and NaN->-1, map/core.py:226-229).  If sumsq != NULL the
  * sum of squares of `out` is written there (float64; agg.force_smoothness,
- * agg.py:297, is sumsq / (3 T n_cg)), combined in a fixed order.
+ * agg.py:297, is sumsq / (3 T n_cg)), combined in a fixed order.  If nan_seen != NULL,
+ * nan_seen[0] is set to 1 when P contains a NaN (the _has_nans scan of map/core.py:13-16
+ * fused into the pass that reads P anyway; the caller zeroes it).
  * ------------------------------------------------------------------------- */
 size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg);
 int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype, const void* M,
                          int32_t n_cg, int out_dtype, int nan_mode, double nan_fill, void* out,
-                         double* sumsq, void* ws, size_t ws_bytes, void* stream);
+                         double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, void* stream);
 
 /* K3b  one-hot rows (slice maps): out[t,c,:] = P[t, idx[c], :], converted to
  * out_dtype.  Same call site as K3 when every row of M is a unit vector. */

@@ -28,6 +28,34 @@ static double run(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs, siz
   return best;
 }
 
+static int32_t* g_table = nullptr;
+
+template <typename T, int ABL>
+static double run_dma(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs) {
+  constexpr int KB = GramCfg<T>::KB;
+  const int nt1 = n_pad / TILE, n_tiles = nt1 * (nt1 + 1) / 2;
+  int64_t fps = round_up(ceil_div(rows, ksplit), KB);
+  const size_t lds = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);
+  if (!g_table) hipMalloc(&g_table, 1 << 20);
+  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, 0, nt1, g_table);
+  hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipEvent_t a, b;
+  hipEventCreate(&a);
+  hipEventCreate(&b);
+  float best = 1e30f;
+  for (int rep = 0; rep < 3; ++rep) {
+    hipEventRecord(a);
+    hipLaunchKernelGGL((gram_tile_dma_kernel<T, ABL>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(GRAM_THREADS), lds, 0, X, rows,
+                       (int64_t)n_pad * 3, nt1, n_tiles, ksplit, g_table, fps, slabs);
+    hipEventRecord(b);
+    hipEventSynchronize(b);
+    float ms;
+    hipEventElapsedTime(&ms, a, b);
+    if (ms < best) best = ms;
+  }
+  return best;
+}
+
 template <typename T>
 static void sweep(int64_t rows, int n_pad, double peak) {
   const int nt1 = n_pad / TILE, n_tiles = nt1 * (nt1 + 1) / 2;
@@ -48,6 +76,11 @@ static void sweep(int64_t rows, int n_pad, double peak) {
     double t0b = run<T, 0>(X, rows, n_pad, ksplit, slabs, 40 * 1024);
     printf("   no-gload: refill w/o barrier %.2f (%.1f TF) | barrier w/o refill %.2f (%.1f TF) || ONE block/CU: no-gload %.2f (%.1f TF) full %.2f (%.1f TF)\n",
            t4, flops_exec / t4 / 1e9, t5, flops_exec / t5 / 1e9, t1b, flops_exec / t1b / 1e9, t0b, flops_exec / t0b / 1e9);
+    double d0 = run_dma<T, 0>(X, rows, n_pad, ksplit, slabs);
+    double d1 = run_dma<T, 1>(X, rows, n_pad, ksplit, slabs);
+    double d2 = run_dma<T, 2>(X, rows, n_pad, ksplit, slabs);
+    printf("   LDS-DMA ring: full %.2f ms (%.1f TF exec, %.0f%%) | no DMA in loop %.2f (%.1f TF) | + no barrier %.2f (%.1f TF)\n",
+           d0, flops_exec / d0 / 1e9, 100 * flops_exec / d0 / 1e9 / peak, d1, flops_exec / d1 / 1e9, d2, flops_exec / d2 / 1e9);
     double ts = run<T, 0, true>(X, rows, n_pad, ksplit, slabs);
     double ts1 = run<T, 1, true>(X, rows, n_pad, ksplit, slabs);
     printf("   staggered: full %.2f ms (%.1f TF exec, %.0f%%) | no-gload %.2f (%.1f TF)\n", ts, flops_exec / ts / 1e9,
