@@ -291,10 +291,21 @@ def sumsq(x: torch.Tensor) -> torch.Tensor:
 # ------------------------------------------------------------------ K5 augment
 
 
+def premap_columns(matrix_host: np.ndarray, dtype: torch.dtype, device):
+    """Columns of the premap M (n_cg, N) in compressed form for aggf_condnormal_augment."""
+    mt = np.ascontiguousarray(matrix_host.T)  # (N, n_cg)
+    rows, cols = np.nonzero(mt)
+    ptr_h = np.zeros(mt.shape[0] + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=mt.shape[0]), out=ptr_h[1:])
+    return (torch.from_numpy(ptr_h).to(device), torch.from_numpy(cols.astype(np.int32)).to(device),
+            torch.from_numpy(mt[rows, cols]).to(device=device, dtype=dtype))
+
+
 def condnormal_augment(
     coords: torch.Tensor,
     forces: torch.Tensor,
-    matrix: torch.Tensor,
+    columns,
+    n_cg: int,
     mean: torch.Tensor,
     var: float,
     kbt: float,
@@ -304,18 +315,20 @@ def condnormal_augment(
 ):
     l = lib()
     T, N, _ = coords.shape
-    n_cg = matrix.shape[0]
-    out_dtype = torch.promote_types(coords.dtype, matrix.dtype)
+    mt_ptr, mt_idx, mt_val = columns
+    out_dtype = torch.promote_types(coords.dtype, mt_val.dtype)
     oc = torch.empty((T, N + n_cg, 3), dtype=out_dtype, device=coords.device)
     of = torch.empty((T, N + n_cg, 3), dtype=out_dtype, device=coords.device)
     if T == 0:
         return oc, of
-    check(
-        l.aggf_condnormal_augment(ptr(coords), ptr(forces), T, N, dtype_code(coords.dtype), ptr(matrix), n_cg,
-                                  dtype_code(matrix.dtype), ptr(mean), ptr(noise), int(seed) & (2**64 - 1),
-                                  int(frame_offset), float(var), float(kbt), ptr(oc), ptr(of), stream_ptr()),
-        "aggf_condnormal_augment",
-    )
+    with _timed("augment"):
+        check(
+            l.aggf_condnormal_augment(ptr(coords), ptr(forces), T, N, dtype_code(coords.dtype), ptr(mt_ptr),
+                                      ptr(mt_idx), ptr(mt_val), n_cg, dtype_code(mt_val.dtype), ptr(mean), ptr(noise),
+                                      int(seed) & (2**64 - 1), int(frame_offset), float(var), float(kbt), ptr(oc),
+                                      ptr(of), stream_ptr()),
+            "aggf_condnormal_augment",
+        )
     return oc, of
 
 

@@ -6,38 +6,44 @@
 // dimension, walked in chunks of 16 atoms.  Frame rows are staged in LDS as they lie
 // in HBM ((atom, xyz) interleaved); the three xyz components are three accumulator
 // sets fed from the same staged tile, so P is read exactly once per site block.
+#include <stdlib.h>
+
 #include "aggf_common.h"
 
 namespace aggf {
 
-constexpr int AP_TF = 64;   // frames per workgroup
-constexpr int AP_TC = 64;   // cg sites per workgroup
+// Two tilings of a workgroup: 4 waves = 64 frames x 64 sites (n_cg <= 64), and 8 waves = 64 frames x
+// 128 sites (two wave columns share the staged P tile: P is re-read half as often from L2/HBM and
+// each thread stages 5 instead of 8 sixteen-byte chunks per 48 MFMAs).
 constexpr int AP_KA = 16;   // atoms per stage
 constexpr int AP_XS = AP_KA * 3 + 2;  // LDS row stride of the P tile (elements)
 constexpr int AP_MS = AP_KA + 2;      // LDS row stride of the M tile
-constexpr int AP_THREADS = 256;
 
 template <typename TC>
 __device__ __forceinline__ TC fix_nan(TC v, bool replace, TC fill) {
   return (replace && v != v) ? fill : v;
 }
 
-template <typename TIn, typename TC, bool NANREP>
+template <typename TIn, typename TC, bool NANREP, int AP_THREADS, int AP_TC>
 __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
     int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
     double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
   using MF = Mfma<TC>;
   using acc_t = typename MF::acc_t;
+  constexpr int NWAVE = AP_THREADS / 64;
+  constexpr int WF = 4;                  // waves along the frame axis; the others split the site axis
+  constexpr int WC = NWAVE / WF;
+  constexpr int AP_TF = 16 * WF;         // frames per workgroup (one 16-frame MFMA row block per wave row)
+  constexpr int NCT = AP_TC / 16 / WC;   // 16-site column tiles per wave
   constexpr int VI = 16 / sizeof(TIn);   // input elements per 16-byte chunk
   constexpr int VM = 16 / sizeof(TC);
   constexpr int P_CH_ROW = AP_KA * 3 / VI;                 // chunks per P tile row
   constexpr int P_CH = P_CH_ROW * AP_TF;
-  constexpr int P_PER_THREAD = P_CH / AP_THREADS;
+  constexpr int P_PER_THREAD = (P_CH + AP_THREADS - 1) / AP_THREADS;
   constexpr int M_CH_ROW = AP_KA / VM;
   constexpr int M_CH = M_CH_ROW * AP_TC;
-  constexpr int M_PER_THREAD = M_CH / AP_THREADS;
-  static_assert(P_CH % AP_THREADS == 0 && M_CH % AP_THREADS == 0, "staging split");
+  constexpr int M_PER_THREAD = (M_CH + AP_THREADS - 1) / AP_THREADS;
   constexpr int XBUF = AP_TF * AP_XS;
   constexpr int MBUF = AP_TC * AP_MS;
 
@@ -68,7 +74,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       const int64_t e0 = (int64_t)a0 * 3 + col;                    // element in the frame row
 #pragma unroll
       for (int e = 0; e < VI; ++e) rp[q][e] = 0;
-      if (t < T) {
+      if (c < P_CH && t < T) {
         const TIn* src = P + t * rowP + e0;
         if (p_vec_ok && e0 + VI <= rowP) {
           typedef TIn __attribute__((ext_vector_type(VI))) vin_t;
@@ -90,7 +96,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       const int a = a0 + col;
 #pragma unroll
       for (int e = 0; e < VM; ++e) rm[q][e] = 0;
-      if (cg < n_cg) {
+      if (c < M_CH && cg < n_cg) {
         const TC* src = Mx + (int64_t)cg * N + a;
         if (m_vec_ok && a + VM <= N) {
           typedef TC __attribute__((ext_vector_type(VM))) vm_t;
@@ -112,29 +118,34 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
     for (int q = 0; q < P_PER_THREAD; ++q) {
       const int c = tid + q * AP_THREADS;
       const int r = c / P_CH_ROW, col = (c - r * P_CH_ROW) * VI;
+      if (c < P_CH) {
 #pragma unroll
-      for (int e = 0; e < VI; ++e) {
-        saw_nan |= (rp[q][e] != rp[q][e]);
-        x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[q][e], NANREP, nan_fill);
+        for (int e = 0; e < VI; ++e) {
+          saw_nan |= (rp[q][e] != rp[q][e]);
+          x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[q][e], NANREP, nan_fill);
+        }
       }
     }
 #pragma unroll
     for (int q = 0; q < M_PER_THREAD; ++q) {
       const int c = tid + q * AP_THREADS;
       const int r = c / M_CH_ROW, col = (c - r * M_CH_ROW) * VM;
+      if (c < M_CH) {
 #pragma unroll
-      for (int e = 0; e < VM; ++e) m[r * AP_MS + col + e] = rm[q][e];
+        for (int e = 0; e < VM; ++e) m[r * AP_MS + col + e] = rm[q][e];
+      }
     }
   };
 
-  acc_t acc[4][3];
+  acc_t acc[NCT][3];
 #pragma unroll
-  for (int n = 0; n < 4; ++n)
+  for (int n = 0; n < NCT; ++n)
 #pragma unroll
     for (int d = 0; d < 3; ++d) acc[n][d] = acc_zero<TC>();
 
-  const int offX = (16 * wave + (lane & 15)) * AP_XS + 3 * (lane >> 4);
-  const int offM = (lane & 15) * AP_MS + (lane >> 4);
+  const int wf = wave % WF, wc = wave / WF;
+  const int offX = (16 * wf + (lane & 15)) * AP_XS + 3 * (lane >> 4);
+  const int offM = (wc * NCT * 16 + (lane & 15)) * AP_MS + (lane >> 4);
 
   load_stage(0);
   store_stage(0);
@@ -146,13 +157,13 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
     const TC* m = sM + cur * MBUF;
 #pragma unroll
     for (int kk = 0; kk < AP_KA / 4; ++kk) {
-      TC a[3], b[4];
+      TC a[3], b[NCT];
 #pragma unroll
       for (int d = 0; d < 3; ++d) a[d] = x[offX + 12 * kk + d];
 #pragma unroll
-      for (int n = 0; n < 4; ++n) b[n] = m[offM + 16 * n * AP_MS + 4 * kk];
+      for (int n = 0; n < NCT; ++n) b[n] = m[offM + 16 * n * AP_MS + 4 * kk];
 #pragma unroll
-      for (int n = 0; n < 4; ++n)
+      for (int n = 0; n < NCT; ++n)
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], b[n], acc[n][d]);
     }
@@ -165,11 +176,11 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
   // epilogue: out[t, c, d]; optional sum of squares (fixed order: lane tree, then waves)
   double ss = 0.0;
 #pragma unroll
-  for (int n = 0; n < 4; ++n) {
-    const int c = c0 + 16 * n + (lane & 15);
+  for (int n = 0; n < NCT; ++n) {
+    const int c = c0 + (wc * NCT + n) * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
-      const int64_t t = t0 + 16 * wave + MF::row(lane, r);
+      const int64_t t = t0 + 16 * wf + MF::row(lane, r);
       if (t < T && c < n_cg) {
         TC* o = out + (t * n_cg + c) * 3;
 #pragma unroll
@@ -184,10 +195,15 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
   if (sumsq_partials) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    __shared__ double wsum[4];
+    __shared__ double wsum[NWAVE];
     if (lane == 0) wsum[wave] = ss;
     __syncthreads();
-    if (tid == 0) sumsq_partials[bid] = (wsum[0] + wsum[1]) + (wsum[2] + wsum[3]);
+    if (tid == 0) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < NWAVE; ++w) tot += wsum[w];
+      sumsq_partials[bid] = tot;
+    }
   }
 }
 
@@ -221,12 +237,13 @@ __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict
   }
 }
 
-template <typename TIn, typename TC>
-static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
-                       int nan_mode, double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
-                       void* ws, size_t ws_bytes, hipStream_t stream) {
-  const int ncb = (int)ceil_div(n_cg, AP_TC);
-  const int64_t nfb = ceil_div(T, AP_TF);
+template <typename TIn, typename TC, int THREADS, int TCB>
+static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg, int nan_mode,
+                        double nan_fill, void* out, double* sumsq, int32_t* nan_seen, void* ws,
+                        size_t ws_bytes, hipStream_t stream) {
+  constexpr int TF = 64;
+  const int ncb = (int)ceil_div(n_cg, TCB);
+  const int64_t nfb = ceil_div(T, TF);
   const int64_t nblocks = nfb * ncb;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "apply grid too large");
   double* partials = nullptr;
@@ -237,13 +254,26 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   }
   const int p_vec_ok = (((uintptr_t)P & 15) == 0) && (((int64_t)N * 3 * sizeof(TIn)) % 16 == 0);
   const int m_vec_ok = (((uintptr_t)Mx & 15) == 0) && (((int64_t)N * sizeof(TC)) % 16 == 0);
-  const size_t lds = (size_t)2 * (AP_TF * AP_XS + AP_TC * AP_MS) * sizeof(TC);
+  const size_t lds = (size_t)2 * (TF * AP_XS + TCB * AP_MS) * sizeof(TC);
+  if (lds > 65536) {
+    static thread_local bool done_t = false, done_f = false;
+    if (!done_t) {
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, true, THREADS, TCB>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done_t = true;
+    }
+    if (!done_f) {
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, false, THREADS, TCB>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      done_f = true;
+    }
+  }
   if (nan_mode == AGGF_NAN_REPLACE)
-    hipLaunchKernelGGL((apply_kernel<TIn, TC, true>), dim3((unsigned)nblocks), dim3(AP_THREADS), lds,
+    hipLaunchKernelGGL((apply_kernel<TIn, TC, true, THREADS, TCB>), dim3((unsigned)nblocks), dim3(THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)nan_fill, p_vec_ok,
                        m_vec_ok, (TC*)out, partials, nan_seen);
   else
-    hipLaunchKernelGGL((apply_kernel<TIn, TC, false>), dim3((unsigned)nblocks), dim3(AP_THREADS), lds,
+    hipLaunchKernelGGL((apply_kernel<TIn, TC, false, THREADS, TCB>), dim3((unsigned)nblocks), dim3(THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)0, p_vec_ok,
                        m_vec_ok, (TC*)out, partials, nan_seen);
   AGGF_LAUNCH_OK();
@@ -254,6 +284,19 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   return AGGF_OK;
 }
 
+template <typename TIn, typename TC>
+static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
+                       int nan_mode, double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
+                       void* ws, size_t ws_bytes, hipStream_t stream) {
+  static const char* force = getenv("AGGF_APPLY_TILE");  // "small" | "big" (benchmarks)
+  const bool big = force ? (force[0] == 'b') : (n_cg > 64);
+  if (big)
+    return apply_launch<TIn, TC, 512, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
+                                           ws_bytes, stream);
+  return apply_launch<TIn, TC, 256, 64>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
+                                        ws_bytes, stream);
+}
+
 }  // namespace aggf
 
 using namespace aggf;
@@ -261,7 +304,7 @@ using namespace aggf;
 extern "C" size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg) {
   (void)N;
   if (T <= 0 || n_cg <= 0) return 256;
-  return (size_t)round_up(ceil_div(T, AP_TF) * ceil_div(n_cg, AP_TC) * 8, 256);
+  return (size_t)round_up(ceil_div(T, 64) * ceil_div(n_cg, 64) * 8, 256);
 }
 
 extern "C" int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype,

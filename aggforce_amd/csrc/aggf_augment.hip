@@ -16,7 +16,8 @@ namespace aggf {
 template <typename TIn, typename TA, typename TOut>
 __global__ __launch_bounds__(256) void augment_kernel(
     const TIn* __restrict__ coords, const TIn* __restrict__ forces, int64_t T, int32_t N,
-    const TA* __restrict__ Mx, int32_t n_cg, const TA* __restrict__ mean,
+    const int32_t* __restrict__ mt_ptr, const int32_t* __restrict__ mt_idx, const TA* __restrict__ mt_val,
+    int32_t n_cg, const TA* __restrict__ mean,
     const TA* __restrict__ noise, uint64_t seed, int64_t frame_offset, TA var, TA kbt, int fb,
     TOut* __restrict__ out_coords, TOut* __restrict__ out_forces) {
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
@@ -52,16 +53,16 @@ __global__ __launch_bounds__(256) void augment_kernel(
     for (int f = 0; f < 4; ++f)
 #pragma unroll
       for (int d = 0; d < 3; ++d) acc[f][d] = 0;
-    for (int c = 0; c < n_cg; ++c) {
-      const TA m = Mx[(int64_t)c * N + a];
-      if (m != (TA)0) {
+    // column a of M in compressed form (M' r touches only the sites atom a contributes to)
+    for (int j = mt_ptr[a]; j < mt_ptr[a + 1]; ++j) {
+      const int c = mt_idx[j];
+      const TA m = mt_val[j];
 #pragma unroll
-        for (int f = 0; f < 4; ++f)
-          if (f < nf) {
+      for (int f = 0; f < 4; ++f)
+        if (f < nf) {
 #pragma unroll
-            for (int d = 0; d < 3; ++d) acc[f][d] += m * sR[(f * n_cg + c) * 3 + d];
-          }
-      }
+          for (int d = 0; d < 3; ++d) acc[f][d] += m * sR[(f * n_cg + c) * 3 + d];
+        }
     }
 #pragma unroll
     for (int f = 0; f < 4; ++f)
@@ -79,7 +80,8 @@ __global__ __launch_bounds__(256) void augment_kernel(
 }
 
 template <typename TIn, typename TA, typename TOut>
-static int augment_typed(const void* coords, const void* forces, int64_t T, int32_t N, const void* Mx,
+static int augment_typed(const void* coords, const void* forces, int64_t T, int32_t N,
+                         const int32_t* mt_ptr, const int32_t* mt_idx, const void* mt_val,
                          int32_t n_cg, const void* mean, const void* noise, uint64_t seed,
                          int64_t frame_offset, double var, double kbt, void* out_coords,
                          void* out_forces, hipStream_t stream) {
@@ -90,7 +92,7 @@ static int augment_typed(const void* coords, const void* forces, int64_t T, int3
   const int64_t nblocks = ceil_div(T, fb);
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "augment grid too large");
   hipLaunchKernelGGL((augment_kernel<TIn, TA, TOut>), dim3((unsigned)nblocks), dim3(256), lds, stream,
-                     (const TIn*)coords, (const TIn*)forces, T, N, (const TA*)Mx, n_cg,
+                     (const TIn*)coords, (const TIn*)forces, T, N, mt_ptr, mt_idx, (const TA*)mt_val, n_cg,
                      (const TA*)mean, (const TA*)noise, seed, frame_offset, (TA)var, (TA)kbt, fb,
                      (TOut*)out_coords, (TOut*)out_forces);
   AGGF_LAUNCH_OK();
@@ -102,22 +104,23 @@ static int augment_typed(const void* coords, const void* forces, int64_t T, int3
 using namespace aggf;
 
 extern "C" int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, int32_t N,
-                                       int traj_dtype, const void* M, int32_t n_cg, int aug_dtype,
+                                       int traj_dtype, const int32_t* mt_ptr, const int32_t* mt_idx,
+                                       const void* mt_val, int32_t n_cg, int aug_dtype,
                                        const void* mean, const void* noise, uint64_t seed,
                                        int64_t frame_offset, double var, double kbt,
                                        void* out_coords, void* out_forces, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
-  if (!coords || !forces || !M || !mean || !out_coords || !out_forces)
+  if (!coords || !forces || !mt_ptr || !mt_idx || !mt_val || !mean || !out_coords || !out_forces)
     return fail(AGGF_ERR_ARG, "aggf_condnormal_augment: NULL pointer");
   if (T <= 0 || N <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_condnormal_augment: empty problem");
   if (!(var > 0.0)) return fail(AGGF_ERR_ARG, "aggf_condnormal_augment: var must be positive");
   if (traj_dtype == AGGF_F32 && aug_dtype == AGGF_F32)
-    return augment_typed<float, float, float>(coords, forces, T, N, M, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
+    return augment_typed<float, float, float>(coords, forces, T, N, mt_ptr, mt_idx, mt_val, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
   if (traj_dtype == AGGF_F64 && aug_dtype == AGGF_F32)
-    return augment_typed<double, float, double>(coords, forces, T, N, M, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
+    return augment_typed<double, float, double>(coords, forces, T, N, mt_ptr, mt_idx, mt_val, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
   if (traj_dtype == AGGF_F64 && aug_dtype == AGGF_F64)
-    return augment_typed<double, double, double>(coords, forces, T, N, M, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
+    return augment_typed<double, double, double>(coords, forces, T, N, mt_ptr, mt_idx, mt_val, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
   if (traj_dtype == AGGF_F32 && aug_dtype == AGGF_F64)
-    return augment_typed<float, double, double>(coords, forces, T, N, M, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
+    return augment_typed<float, double, double>(coords, forces, T, N, mt_ptr, mt_idx, mt_val, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
   return fail(AGGF_ERR_ARG, "aggf_condnormal_augment: bad dtype");
 }

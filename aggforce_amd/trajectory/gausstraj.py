@@ -86,7 +86,9 @@ class CondNormal(Augmenter):
         noise = self._next_noise(c.device)
         stream_seed = self.seed + 0x9E3779B97F4A7C15 * self._calls
         self._calls += 1
-        oc, of = K.condnormal_augment(c, f, m_dev, mean, self.var, kbt, noise, stream_seed, self.frame_offset)
+        cols = K.premap_columns(M, K.torch_dtype(self.dtype), c.device)
+        oc, of = K.condnormal_augment(c, f, cols, M.shape[0], mean, self.var, kbt, noise, stream_seed,
+                                      self.frame_offset)
         return K.like_input(oc, coords), K.like_input(of, coords)
 
     def sample(self, source):
@@ -100,7 +102,9 @@ class CondNormal(Augmenter):
         noise = self._next_noise(c.device)
         stream_seed = self.seed + 0x9E3779B97F4A7C15 * self._calls
         self._calls += 1
-        oc, _ = K.condnormal_augment(c, zeros, m_dev, mean, self.var, 0.0, noise, stream_seed, self.frame_offset)
+        cols = K.premap_columns(M, K.torch_dtype(self.dtype), c.device)
+        oc, _ = K.condnormal_augment(c, zeros, cols, M.shape[0], mean, self.var, 0.0, noise, stream_seed,
+                                     self.frame_offset)
         return K.like_input(oc[:, c.shape[1]:, :].to(K.torch_dtype(self.dtype)).contiguous(), source)
 
     def log_gradient(self, source, generated) -> Tuple:

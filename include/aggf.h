@@ -147,7 +147,9 @@ int aggf_sumsq(const void* x, int64_t count, int dtype, double* out, void* ws, s
  * AugmentedTrajectory._augment (trajectory/core.py:382-390):
  *     y = M x + sqrt(var) eps,  r = (y - M x)/var,
  *     out_coords = [x ; y],  out_forces = [F + kbt M' r ; -kbt r]   (T, N+n_cg, 3)
- * coords/forces: (T, N, 3) in traj_dtype; M: (n_cg, N), mean = M x: (T, n_cg, 3) and
+ * coords/forces: (T, N, 3) in traj_dtype; the premap M (n_cg, N) is given by its columns in
+ * compressed form -- atom a contributes M[mt_idx[j], a] = mt_val[j] for j in
+ * [mt_ptr[a], mt_ptr[a+1]) -- (mt_val in aug_dtype); mean = M x: (T, n_cg, 3) and
  * noise: (T, n_cg, 3) in aug_dtype (the augmenter's dtype, float32 by default in
  * the reference); noise == NULL draws eps from Philox4x32-10 keyed by
  * (seed, frame_offset + t, site, dim), independent of sharding.  Outputs are in
@@ -155,7 +157,8 @@ int aggf_sumsq(const void* x, int64_t count, int dtype, double* out, void* ws, s
  * aggf_slice_gather with out_dtype = aug_dtype.
  * ------------------------------------------------------------------------- */
 int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, int32_t N,
-                            int traj_dtype, const void* M, int32_t n_cg, int aug_dtype,
+                            int traj_dtype, const int32_t* mt_ptr, const int32_t* mt_idx,
+                            const void* mt_val, int32_t n_cg, int aug_dtype,
                             const void* mean, const void* noise, uint64_t seed,
                             int64_t frame_offset, double var, double kbt, void* out_coords,
                             void* out_forces, void* stream);
