@@ -252,8 +252,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "unsupported vmcnt");
 }
 
-template <typename T, int ABL = 0>
-__global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
+template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2>
+__global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
   using M = Mfma<T>;
@@ -267,7 +267,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
   static_assert(PIECES % 4 == 0, "piece split");
   constexpr int PANEL_ELEMS = KB * ROW_STRIDE;
   constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
-  constexpr int NBUF = 3;
+  constexpr int AHEAD = NBUF - 1;  // stages in flight ahead of the one being computed
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -352,8 +352,8 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
   const int offB = PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wn * 64 + (lane & 15));
 
   if (n_it > 0) issue_stage(0);
-  if (n_it > 1) issue_stage(1);
-  if (n_it > 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+  if (AHEAD > 1 && n_it > 1) issue_stage(1);
+  if (AHEAD > 1 && n_it > 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -361,7 +361,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
   for (int it = 0; it < n_it; ++it) {
     // DMAs of stage it+2 first (placing them between the MFMA groups instead, or raising the
     // wave priority around the MFMA groups, measured no better: tools/gram_ablate.hip history)
-    if (ABL == 0 && it + 2 < n_it) issue_stage(it + 2);
+    if (ABL == 0 && it + AHEAD < n_it) issue_stage(it + AHEAD);
     const T* pa = smem + ((ABL ? it % 2 : it % NBUF)) * BUF_ELEMS;
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
@@ -380,7 +380,7 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_dma_kernel(
     }
     // stage it+1 must have landed (this wave's pieces), stage it+2 may stay in flight
     if (ABL < 2) {
-      if (it + 2 < n_it) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+      if (AHEAD > 1 && it + 2 < n_it) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");

@@ -30,22 +30,22 @@ static double run(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs, siz
 
 static int32_t* g_table = nullptr;
 
-template <typename T, int ABL>
+template <typename T, int ABL, int NBUF = 3, int WPS = 2>
 static double run_dma(const T* X, int64_t rows, int n_pad, int ksplit, T* slabs) {
   constexpr int KB = GramCfg<T>::KB;
   const int nt1 = n_pad / TILE, n_tiles = nt1 * (nt1 + 1) / 2;
   int64_t fps = round_up(ceil_div(rows, ksplit), KB);
-  const size_t lds = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);
+  const size_t lds = (size_t)NBUF * 2 * KB * ROW_STRIDE * sizeof(T);
   if (!g_table) hipMalloc(&g_table, 1 << 20);
   hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, 0, nt1, g_table);
-  hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, ABL, NBUF, WPS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   hipEvent_t a, b;
   hipEventCreate(&a);
   hipEventCreate(&b);
   float best = 1e30f;
   for (int rep = 0; rep < 3; ++rep) {
     hipEventRecord(a);
-    hipLaunchKernelGGL((gram_tile_dma_kernel<T, ABL>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(GRAM_THREADS), lds, 0, X, rows,
+    hipLaunchKernelGGL((gram_tile_dma_kernel<T, ABL, NBUF, WPS>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(GRAM_THREADS), lds, 0, X, rows,
                        (int64_t)n_pad * 3, nt1, n_tiles, ksplit, g_table, fps, slabs);
     hipEventRecord(b);
     hipEventSynchronize(b);
@@ -81,6 +81,10 @@ static void sweep(int64_t rows, int n_pad, double peak) {
     double d2 = run_dma<T, 2>(X, rows, n_pad, ksplit, slabs);
     printf("   LDS-DMA ring: full %.2f ms (%.1f TF exec, %.0f%%) | no DMA in loop %.2f (%.1f TF) | + no barrier %.2f (%.1f TF)\n",
            d0, flops_exec / d0 / 1e9, 100 * flops_exec / d0 / 1e9 / peak, d1, flops_exec / d1 / 1e9, d2, flops_exec / d2 / 1e9);
+    double e23 = run_dma<T, 0, 2, 3>(X, rows, n_pad, ksplit, slabs);
+    double e22 = run_dma<T, 0, 2, 2>(X, rows, n_pad, ksplit, slabs);
+    printf("   LDS-DMA 2-stage ring: 3 waves/SIMD %.2f ms (%.1f TF) | 2 waves/SIMD %.2f ms (%.1f TF)\n", e23,
+           flops_exec / e23 / 1e9, e22, flops_exec / e22 / 1e9);
     double ts = run<T, 0, true>(X, rows, n_pad, ksplit, slabs);
     double ts1 = run<T, 1, true>(X, rows, n_pad, ksplit, slabs);
     printf("   staggered: full %.2f ms (%.1f TF exec, %.0f%%) | no-gload %.2f (%.1f TF)\n", ts, flops_exec / ts / 1e9,

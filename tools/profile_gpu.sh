@@ -5,8 +5,10 @@ set -o pipefail
 tag=$1; shift
 export TMPDIR=/tmp
 out=gpurun_out
-rm -rf $out/${tag}_trace $out/${tag}_fetch $out/${tag}_write
+rm -rf $out/${tag}_trace $out/${tag}_fetch $out/${tag}_write $out/${tag}_dram
 rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_trace -- python3 bench.py --no-cpu-baseline "$@" > $out/${tag}_trace.log 2>&1 || { tail -5 $out/${tag}_trace.log; exit 1; }
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_fetch -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $out/${tag}_fetch.log 2>&1 || { tail -5 $out/${tag}_fetch.log; exit 1; }
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_write -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 0 "$@" > $out/${tag}_write.log 2>&1 || { tail -5 $out/${tag}_write.log; exit 1; }
+for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "dram TCC_EA0_RDREQ_DRAM_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  set -- $pass; name=$1; shift
+  rocprofv3 --pmc "$@" --output-format csv -d $out/${tag}_$name -- python3 bench.py --no-cpu-baseline --steps 1 --warmup 1 > $out/${tag}_$name.log 2>&1 || { tail -5 $out/${tag}_$name.log; }
+done
 python3 tools/summarize_profile.py $tag
