@@ -313,8 +313,15 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
   }
 
   // rows past the end of this split's frame range must read as zeros (last stage only)
-  auto prep_stage = [&](int s) {
-    const int64_t t0 = t_begin + (int64_t)s * KB;
+  // Stage order is rotated by (ti + tj) mod 8: the 8 workgroups of an XCD group that share a
+  // panel then ask for a given (panel, stage) in 8 different iterations, so the first request
+  // misses and the other 7 hit the XCD's L2.  In lock-step (all at once) every request misses,
+  // because concurrent misses to one line are not merged (TCC_MISS == TCC_EA0_RDREQ before).
+  const int skew = n_it > 16 ? ((ti + tj) & 7) : 0;
+  auto stage_of = [&](int seq) { const int v = seq + skew; return v >= n_it ? v - n_it : v; };
+  auto prep_stage = [&](int seq) {
+    const int s = seq;  // ring slot follows the sequence position
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
     if (t0 + KB > t_end) {
       T* lbase = smem + (s % NBUF) * BUF_ELEMS;
       const int first = (int)(t_end - t0);
@@ -327,7 +334,7 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
     }
   };
   auto issue_piece = [&](int s, int q) {
-    const int64_t t0 = t_begin + (int64_t)s * KB;
+    const int64_t t0 = t_begin + (int64_t)stage_of(s) * KB;
     const bool row_ok = t0 + p_row[q] < t_end;
     const bool lane_ok = !p_half[q] || lane < 32;
     if (row_ok && lane_ok) {

@@ -52,6 +52,21 @@ def parse():
     return p.parse_args()
 
 
+def profiled_traffic(workload, world):
+    """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
+    (profiles/r01_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
+    and counts 128-byte requests as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM): x 2."""
+    if workload != "c3" or world != 1:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_c3_rocprof_summary.json")))
+        rd = [e["FETCH_SIZE"]["per_dispatch"] for e in d["pmc_fetch"] if "gram_tile" in e["kernel"]][0]
+        wr = [e["WRITE_SIZE"]["per_dispatch"] for e in d.get("pmc_write", []) if "gram_tile" in e["kernel"]]
+        return 2.0 * rd * 1024 + (wr[0] * 1024 if wr else 0.0)
+    except Exception:
+        return None
+
+
 def blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -224,7 +239,7 @@ def main():
                 "peak": PEAK_TFLOPS[dt],
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS[dt],
-                "traffic": None,
+                "traffic": profiled_traffic(args.workload, world),
                 "ms_per_launch": gram_ms,
                 "flops_per_launch": flops,
             },
