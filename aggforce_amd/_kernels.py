@@ -413,3 +413,19 @@ def gb_apply(Fg, Pg, cg, sizes, n_id: int, n_ch: int, centers, width: float, cli
             "aggf_gb_apply",
         )
     return out
+
+
+# ------------------------------------------------------------------ K6 pair-distance variance
+
+
+def pair_dist_var(x: torch.Tensor) -> torch.Tensor:
+    """(N, N) float64 population variance over frames of every pair distance; see aggf_pair_dist_var."""
+    l = lib()
+    T, N, _ = x.shape
+    var = torch.empty((N, N), dtype=torch.float64, device=x.device)
+    need = l.aggf_pair_dist_var_workspace_bytes(T, N)
+    ws = workspace(need, x.device, "pairs")
+    with _timed("pair_var"):
+        check(l.aggf_pair_dist_var(ptr(x), T, N, dtype_code(x.dtype), ptr(var), ptr(ws), need, stream_ptr()),
+              "aggf_pair_dist_var")
+    return var

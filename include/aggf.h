@@ -206,6 +206,18 @@ int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const float* cg,
                   const double* coef, int32_t n_feat, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K6  Pair-distance fluctuations for guess_pairwise_constraints.
+ *
+ * Replaces constraints/constfinder.py:46-53 (util.distances, util.py:65-72, then
+ * np.var over frames): var[i,j] = Var_t |x_j(t) - x_i(t)|  (population variance) for all
+ * pairs, in one streaming pass with shifted sums (no (T, N, N) tensor).
+ * X: (T, N, 3) in dtype; var: (N, N) float64, symmetric, zero diagonal.
+ * ------------------------------------------------------------------------- */
+size_t aggf_pair_dist_var_workspace_bytes(int64_t T, int32_t N);
+int aggf_pair_dist_var(const void* X, int64_t T, int32_t N, int dtype, double* var, void* ws,
+                       size_t ws_bytes, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Synthetic trajectories for benchmarks and full-size property tests (no
  * reference counterpart).  out[t,a,d] = mean + sigma * z(seed, frame_offset+t, a, d)
  * with z a counter-based standard normal (Philox4x32-10 + Box-Muller), so any
