@@ -10,7 +10,14 @@ fallback: without the built library and a GPU the compute entry points raise.
 from .trajectory import Trajectory
 from .agg import project_forces
 from .constraints import guess_pairwise_constraints
-from .qp import qp_linear_map, constraint_aware_uni_map, joptgauss_map
+from .qp import (
+    qp_linear_map,
+    constraint_aware_uni_map,
+    joptgauss_map,
+    stagedjoptgauss_map,
+    stagedjslicegauss_map,
+    stagedjforcegauss_map,
+)
 from .map import LinearMap
 
 __version__ = "0.1.0"
@@ -22,5 +29,8 @@ __all__ = [
     "qp_linear_map",
     "constraint_aware_uni_map",
     "joptgauss_map",
+    "stagedjoptgauss_map",
+    "stagedjslicegauss_map",
+    "stagedjforcegauss_map",
     "LinearMap",
 ]

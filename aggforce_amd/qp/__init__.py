@@ -11,7 +11,12 @@ from .featlinearmap import (
     id_feat,
 )
 from .gbfeat import gb_feat
-from .gauss import joptgauss_map
+from .gauss import (
+    joptgauss_map,
+    stagedjforcegauss_map,
+    stagedjoptgauss_map,
+    stagedjslicegauss_map,
+)
 
 __all__ = [
     "qp_linear_map",
@@ -27,4 +32,7 @@ __all__ = [
     "id_feat",
     "gb_feat",
     "joptgauss_map",
+    "stagedjoptgauss_map",
+    "stagedjslicegauss_map",
+    "stagedjforcegauss_map",
 ]

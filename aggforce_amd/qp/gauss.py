@@ -6,12 +6,25 @@
 trajectories.  The JAX pieces of the reference (JLinearMap, JCondNormal autodiff) are
 replaced by the closed-form augmenter ``CondNormal``.
 """
+import warnings
 from typing import Optional
 
+import numpy as np
+
+from .. import _kernels as K
 from ..constraints import Constraints
-from ..map import AugmentedTMap, LinearMap, lmap_augvariables
-from ..trajectory import AugmentedTrajectory, CondNormal, Trajectory
-from .qplinear import qp_linear_map
+from ..map import (
+    AugmentedTMap,
+    ComposedTMap,
+    LinearMap,
+    NullForcesTMap,
+    RATMap,
+    SeperableTMap,
+    lmap_augvariables,
+)
+from ..trajectory import AugmentedTrajectory, CondNormal, CoordsTrajectory, Trajectory
+from .basicagg import constraint_aware_uni_map
+from .qplinear import DEFAULT_SOLVER_OPTIONS, SolverOptions, qp_linear_map
 
 
 def joptgauss_map(
@@ -47,3 +60,163 @@ def joptgauss_map(
         traj=aug_traj, coord_map=lmap_augvariables(aug_traj), constraints=constraints, **kwargs
     )
     return AugmentedTMap(aug_tmap=aug_tmap, augmenter=augmenter, kbt=kbt)
+
+
+# ---- staged maps: deterministic linear pre-map, then a noising step --------------------------
+def _noise_site_slice_map(n_sites: int, n_aug: int) -> LinearMap:
+    """Coordinate map isolating the last ``n_aug`` sites of a partially mapped trajectory."""
+    return LinearMap(mapping=[[i] for i in range(n_sites - n_aug, n_sites)], n_fg_sites=n_sites)
+
+
+def _pre_tmap(traj, coord_map, force_map, constraints, premap_l2_regularization, premap_solver_args):
+    if force_map is None:
+        return qp_linear_map(
+            traj=traj,
+            coord_map=coord_map,
+            constraints=constraints,
+            l2_regularization=premap_l2_regularization,
+            solver_args=premap_solver_args,
+        )
+    return SeperableTMap(coord_map=coord_map, force_map=force_map)
+
+
+def _backmapped_noise_postmap(pre_tmap) -> LinearMap:
+    """W M' : carries the noise force on the mapped real sites through the force map.
+
+    grad_x f(Mx) = M' [grad f](Mx) is the atomistic noise force; the force map W then maps it
+    (reference jgauss.py:266-280, ``j_force_map @ j_coord_map.T``).
+    """
+    W = pre_tmap.force_map.standard_matrix
+    M = pre_tmap.coord_map.standard_matrix
+    return LinearMap(W @ M.T, handle_nans=False)
+
+
+def stagedjoptgauss_map(
+    traj: Trajectory,
+    coord_map: LinearMap,
+    var: float,
+    kbt: float,
+    force_map: Optional[LinearMap] = None,
+    constraints: Optional[Constraints] = None,
+    seed: Optional[int] = None,
+    premap_l2_regularization: float = 0.0,
+    premap_solver_args: SolverOptions = DEFAULT_SOLVER_OPTIONS,
+    noise=None,
+    **kwargs,
+) -> ComposedTMap:
+    """Optimised Gaussian map as a linear pre-map followed by a noising map (jgauss.py:143-312).
+
+    Steps: (1) optimise (or take ``force_map`` as) a noise-free force map; (2) augment the
+    full-resolution trajectory with noised copies of the mapped sites (K5); (3) map its real
+    sites with the pre-map (K3), keeping the noise sites; (4) optimise a second force map that
+    mixes mapped-real and noise forces (K1 + K2 on 2 n_cg sites, no constraints).  The result
+    is ``ComposedTMap([post_tmap, pre_tmap])``: ``pre_tmap`` may be applied before saving data,
+    ``post_tmap`` (stochastic) afterwards.  ``noise`` as in ``joptgauss_map``: the first array
+    is consumed by the fit, the following ones by successive applications of ``post_tmap``.
+    """
+    pre_tmap = _pre_tmap(traj, coord_map, force_map, constraints, premap_l2_regularization,
+                         premap_solver_args)
+    augmenter = CondNormal(var=var, premap=pre_tmap.coord_map, seed=seed)
+    noise = list(noise) if noise is not None else []
+    if noise:
+        augmenter.inject_noise(noise[0])
+    aug_traj = AugmentedTrajectory.from_trajectory(t=traj, augmenter=augmenter, kbt=kbt)
+    pmapped_traj = RATMap(tmap=pre_tmap)(aug_traj)
+    pmapped_tmap = qp_linear_map(
+        traj=pmapped_traj,
+        coord_map=_noise_site_slice_map(pmapped_traj.n_sites, aug_traj.n_aug_sites),
+        constraints=set(),
+        **kwargs,
+    )
+    pmapped_augmenter = CondNormal(var=var, source_postmap=_backmapped_noise_postmap(pre_tmap), seed=seed)
+    if len(noise) > 1:
+        pmapped_augmenter.inject_noise(*noise[1:])
+    post_tmap = AugmentedTMap(aug_tmap=pmapped_tmap, augmenter=pmapped_augmenter, kbt=kbt)
+    return ComposedTMap(submaps=[post_tmap, pre_tmap])
+
+
+def stagedjslicegauss_map(
+    traj: CoordsTrajectory,
+    coord_map: LinearMap,
+    var: float,
+    kbt: float,
+    seed: Optional[int] = None,
+    constraints: Optional[Constraints] = None,  # noqa: ARG001
+    warn_input_forces: bool = True,
+    noise=None,
+) -> ComposedTMap:
+    """Gaussian map whose reported forces come from the noise only (jgauss.py:315-446).
+
+    Three submaps: ``[2]`` adds null (NaN) forces so that force-free input is accepted, ``[1]``
+    maps the coordinates to the coarse resolution, ``[0]`` noises them and reports the
+    noise-site forces.  No force information of ``traj`` is used.
+    """
+    naforce_traj = NullForcesTMap(warn_input_forces=warn_input_forces)(traj)
+    augmenter = CondNormal(var=var, premap=coord_map, seed=seed)
+    noise = list(noise) if noise is not None else []
+    if noise:
+        augmenter.inject_noise(noise[0])
+    aug_traj = AugmentedTrajectory.from_trajectory(t=naforce_traj, augmenter=augmenter, kbt=kbt)
+    null_fmap = LinearMap(mapping=np.ones_like(coord_map.standard_matrix), handle_nans=False)
+    pre_tmap = SeperableTMap(coord_map=coord_map, force_map=null_fmap)
+    pmapped_traj = RATMap(tmap=pre_tmap)(aug_traj)
+    pmapped_tmap = constraint_aware_uni_map(
+        traj=pmapped_traj,
+        coord_map=_noise_site_slice_map(pmapped_traj.n_sites, aug_traj.n_aug_sites),
+        constraints=set(),
+    )
+    pmapped_augmenter = CondNormal(var=var, seed=seed)
+    if len(noise) > 1:
+        pmapped_augmenter.inject_noise(*noise[1:])
+    post_tmap = AugmentedTMap(aug_tmap=pmapped_tmap, augmenter=pmapped_augmenter, kbt=kbt)
+    return ComposedTMap(submaps=[post_tmap, pre_tmap, NullForcesTMap(warn_input_forces=False)])
+
+
+def stagedjforcegauss_map(
+    traj: Trajectory,
+    coord_map: LinearMap,
+    var: float,
+    kbt: float,
+    force_map: Optional[LinearMap] = None,
+    constraints: Optional[Constraints] = None,
+    seed: Optional[int] = None,
+    premap_l2_regularization: float = 0.0,
+    premap_solver_args: SolverOptions = DEFAULT_SOLVER_OPTIONS,
+    contribution_tolerance: float = 1e-6,
+    noise=None,
+    **kwargs,
+) -> ComposedTMap:
+    """Gaussian map with the least possible noise-derived force content (jgauss.py:449-650).
+
+    As ``stagedjoptgauss_map``, but the second optimisation sees a trajectory whose real
+    forces are zero, so it minimises the noise contribution alone; a warning is raised when the
+    remaining mean-square noise force exceeds ``contribution_tolerance``.
+    """
+    pre_tmap = _pre_tmap(traj, coord_map, force_map, constraints, premap_l2_regularization,
+                         premap_solver_args)
+    augmenter = CondNormal(var=var, premap=pre_tmap.coord_map, seed=seed)
+    noise = list(noise) if noise is not None else []
+    if noise:
+        augmenter.inject_noise(noise[0])
+    zeroforce_traj = Trajectory(coords=traj.coords, forces=0 * traj.forces)
+    aug_traj = AugmentedTrajectory.from_trajectory(t=zeroforce_traj, augmenter=augmenter, kbt=kbt)
+    pmapped_traj = RATMap(tmap=pre_tmap)(aug_traj)
+    pmapped_tmap = qp_linear_map(
+        traj=pmapped_traj,
+        coord_map=_noise_site_slice_map(pmapped_traj.n_sites, aug_traj.n_aug_sites),
+        constraints=set(),
+        **kwargs,
+    )
+    mapped_forces = pmapped_tmap(pmapped_traj).forces
+    remaining_force_residual = float(K.sumsq(K.as_device(mapped_forces))) / max(1, int(np.prod(mapped_forces.shape)))
+    if remaining_force_residual > contribution_tolerance:
+        warnings.warn(
+            "Unable to remove all noise contributions in forces. Remaining "
+            f"contribution: {remaining_force_residual}.",
+            stacklevel=0,
+        )
+    pmapped_augmenter = CondNormal(var=var, source_postmap=_backmapped_noise_postmap(pre_tmap), seed=seed)
+    if len(noise) > 1:
+        pmapped_augmenter.inject_noise(*noise[1:])
+    post_tmap = AugmentedTMap(aug_tmap=pmapped_tmap, augmenter=pmapped_augmenter, kbt=kbt)
+    return ComposedTMap(submaps=[post_tmap, pre_tmap])

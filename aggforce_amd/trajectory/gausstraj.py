@@ -34,10 +34,17 @@ class CondNormal(Augmenter):
         seed: Optional[int] = None,
         dtype=np.float32,
         frame_offset: int = 0,
+        source_postmap=None,
     ) -> None:
         if not var > 0:
             raise ValueError("var must be positive")
         self.var = float(var)
+        # linear map applied to the log-gradient with respect to the source sites (the reference's
+        # JCondNormal(source_postmap=...), jaxgausstraj.py:281; used by the staged Gaussian maps)
+        if source_postmap is None or isinstance(source_postmap, LinearMap):
+            self.source_postmap = source_postmap
+        else:
+            self.source_postmap = LinearMap(np.asarray(source_postmap), handle_nans=False)
         if premap is None or isinstance(premap, LinearMap):
             self.premap = premap
         else:
@@ -58,6 +65,14 @@ class CondNormal(Augmenter):
         if self.premap is None:
             return np.eye(n_src, dtype=self.dtype)
         return self.premap.standard_matrix.astype(self.dtype, copy=False)
+
+    def _correction_matrix(self, M: np.ndarray) -> np.ndarray:
+        """Matrix whose columns give the source-force correction: M, or M Q' with a source_postmap Q
+        (d/dsource after the postmap = Q M' r = (M Q')' r)."""
+        if self.source_postmap is None:
+            return M
+        Q = self.source_postmap.standard_matrix.astype(self.dtype, copy=False)
+        return (M @ Q.T).astype(self.dtype, copy=False)
 
     def _next_noise(self, device):
         if self._noise_queue:
@@ -86,7 +101,7 @@ class CondNormal(Augmenter):
         noise = self._next_noise(c.device)
         stream_seed = self.seed + 0x9E3779B97F4A7C15 * self._calls
         self._calls += 1
-        cols = K.premap_columns(M, K.torch_dtype(self.dtype), c.device)
+        cols = K.premap_columns(self._correction_matrix(M), K.torch_dtype(self.dtype), c.device)
         oc, of = K.condnormal_augment(c, f, cols, M.shape[0], mean, self.var, kbt, noise, stream_seed,
                                       self.frame_offset)
         return K.like_input(oc, coords), K.like_input(of, coords)
@@ -117,13 +132,13 @@ class CondNormal(Augmenter):
         m_dev = torch.from_numpy(np.ascontiguousarray(M)).to(c.device)
         mean = self._mean(c, m_dev, M)
         r = (g - mean) / self.var
-        mt = torch.from_numpy(np.ascontiguousarray(M.T)).to(c.device)
+        mt = torch.from_numpy(np.ascontiguousarray(self._correction_matrix(M).T)).to(c.device)
         d_src = K.linearmap_apply(r.contiguous(), mt)
         return K.like_input(d_src, source), K.like_input(-r, source)
 
     def astype(self, dtype, *args, **kwargs) -> "CondNormal":  # noqa: ARG002
         new = self.__class__(var=self.var, premap=self.premap, seed=self.seed, dtype=dtype,
-                             frame_offset=self.frame_offset)
+                             frame_offset=self.frame_offset, source_postmap=self.source_postmap)
         new._calls = self._calls
         new._noise_queue = list(self._noise_queue)
         return new
@@ -131,6 +146,8 @@ class CondNormal(Augmenter):
     def to_SimpleCondNormal(self) -> "SimpleCondNormal":
         if self.premap is not None and not self.premap.close_to_identity():
             raise ValueError("Only can convert to SimpleCondNormal for identity premap.")
+        if self.source_postmap is not None and not self.source_postmap.close_to_identity():
+            raise ValueError("Only can convert to SimpleCondNormal for identity source_postmap.")
         return SimpleCondNormal(var=self.var, dtype=self.dtype)
 
 

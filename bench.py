@@ -114,6 +114,11 @@ def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores):
 
 def main():
     args = parse()
+    # ONE JSON line on stdout: libraries (RCCL prints a version banner on init) write to fd 1, so fd 1
+    # is pointed at stderr for the run and the result line goes to the saved descriptor.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -250,7 +255,8 @@ def main():
                               min(args.cpu_frames, T_total), blas_threads())
             cb.pop("_check")
             line["cpu_baseline"] = cb
-        print(json.dumps(line), flush=True)
+        sys.stdout.flush()
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:
         import torch.distributed as dist
 

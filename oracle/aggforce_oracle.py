@@ -516,3 +516,65 @@ def joptgauss_force_map(coords, forces, coord_matrix, var, kbt, noise, constrain
     W = qp_linear_map(full_forces, aug_cmap, constraints, l2_regularization)
     return {"aug_coords": full_coords, "aug_forces": full_forces, "aug_coord_matrix": aug_cmap,
             "force_map": W}
+
+
+# ---- staged Gaussian maps (qp/jgauss.py:143-650) -- PARITY UNPINNED (JAX absent here) ---------
+def _augment_postmap(coords, forces, var, kbt, noise, postmap, dtype=np.float32):
+    """AugmentedTrajectory._augment with JCondNormal(cov=var, source_postmap=Q): identity premap,
+    source log-gradient passed through Q (jaxgausstraj.py:281-283)."""
+    n = coords.shape[1]
+    eye = np.eye(n, dtype=dtype)
+    aug_coords = condnormal_sample(coords, eye, var, noise, dtype)
+    d_src, d_gen = condnormal_log_gradient(coords, aug_coords, eye, var, dtype)
+    if postmap is not None:
+        d_src = trjdot(d_src, np.asarray(postmap, dtype=dtype))
+    full_coords = np.concatenate([np.asarray(coords, dtype=dtype), aug_coords], axis=1)
+    full_forces = np.concatenate([forces + kbt * d_src, kbt * d_gen], axis=1)
+    return full_coords, full_forces
+
+
+def staged_gauss_fit(coords, forces, coord_matrix, var, kbt, noise, variant="opt", force_matrix=None,
+                     constraints=None, l2_regularization=0.0, premap_l2_regularization=0.0,
+                     dtype=np.float32):
+    """Fit of stagedjoptgauss_map ("opt", jgauss.py:216-263), stagedjforcegauss_map ("force",
+    jgauss.py:531-599) or stagedjslicegauss_map ("slice", jgauss.py:378-427).
+
+    Returns the pieces of the ComposedTMap: pre coordinate/force matrices, the second-stage
+    force matrix over [mapped real | noise] sites, and the source_postmap Q = W M'.
+    """
+    M = np.asarray(coord_matrix, dtype=np.float64)
+    n_cg = M.shape[0]
+    if variant == "slice":
+        W = np.ones_like(M)
+        f_in = np.full_like(np.asarray(coords, dtype=dtype), np.nan)
+    else:
+        W = (np.asarray(force_matrix, dtype=np.float64) if force_matrix is not None
+             else qp_linear_map(forces, M, constraints, premap_l2_regularization))
+        f_in = np.zeros_like(forces) if variant == "force" else forces
+    full_coords, full_forces = augment(coords, f_in, M.astype(dtype), var, kbt, noise, dtype)
+    n_real = coords.shape[1]
+    # RATMap: real sites through the pre-map (no NaN handling for the slice variant's ones map)
+    pm_coords = np.concatenate([trjdot(full_coords[:, :n_real], M), full_coords[:, n_real:]], axis=1)
+    pm_forces = np.concatenate([trjdot(full_forces[:, :n_real], W), full_forces[:, n_real:]], axis=1)
+    slice_map = list_mapping_matrix([[x] for x in range(n_cg, 2 * n_cg)], 2 * n_cg)
+    if variant == "slice":
+        W2 = constraint_aware_uni_map(slice_map, set())
+        Q = None
+    else:
+        W2 = qp_linear_map(pm_forces, slice_map, set(), l2_regularization)
+        Q = W @ M.T
+    return {"pre_coord_matrix": M, "pre_force_matrix": W, "post_force_matrix": W2, "postmap": Q,
+            "pmapped_coords": pm_coords, "pmapped_forces": pm_forces}
+
+
+def staged_gauss_apply(fit, coords, forces, var, kbt, noise, variant="opt", dtype=np.float32):
+    """Application of the ComposedTMap returned by the staged maps to (coords, forces)."""
+    M, W, W2 = fit["pre_coord_matrix"], fit["pre_force_matrix"], fit["post_force_matrix"]
+    n_cg = M.shape[0]
+    if variant == "slice":
+        forces = np.full_like(np.asarray(coords, dtype=np.float64), np.nan)
+    c1 = trjdot(coords, M)
+    f1 = trjdot(forces, W)
+    full_coords, full_forces = _augment_postmap(c1, f1, var, kbt, noise, fit["postmap"], dtype)
+    slice_map = list_mapping_matrix([[x] for x in range(n_cg, 2 * n_cg)], 2 * n_cg)
+    return trjdot(full_coords, slice_map), linearmap_apply(full_forces, W2)

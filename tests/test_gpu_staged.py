@@ -1,0 +1,121 @@
+"""GPU parity: staged Gaussian maps (reference qp/jgauss.py:143-650) against the oracle composition.
+
+The reference needs JAX for these maps, which this image lacks: the oracle restates them from the
+pinned pieces (qp_linear_map, the closed-form conditional normal) -- see oracle header.
+"""
+import warnings
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from aggforce_amd import (  # noqa: E402
+    LinearMap,
+    Trajectory,
+    stagedjforcegauss_map,
+    stagedjoptgauss_map,
+    stagedjslicegauss_map,
+)
+from aggforce_amd.map import AugmentedTMap, ComposedTMap, NullForcesTMap, SeperableTMap  # noqa: E402
+from aggforce_amd.trajectory import CondNormal, CoordsTrajectory  # noqa: E402
+from oracle import aggforce_oracle as orc  # noqa: E402
+
+
+def rel(a, b):
+    a = np.asarray(a, dtype=np.float64)
+    b = np.asarray(b, dtype=np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def system(T=400, N=12, seed=0):
+    rng = np.random.default_rng(seed)
+    coords = rng.normal(size=(T, N, 3)).astype(np.float32)
+    forces = rng.normal(size=(T, N, 3)).astype(np.float32)
+    # rigid pair (0,1): equal-and-opposite constraint force component
+    c = rng.normal(size=(T, 3)).astype(np.float32) * 5
+    forces[:, 0] += c
+    forces[:, 1] -= c
+    cmap = LinearMap([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]], n_fg_sites=N)
+    cons = {frozenset([0, 1])}
+    eps = [rng.normal(size=(T, 4, 3)).astype(np.float32) for _ in range(2)]
+    return coords, forces, cmap, cons, eps
+
+
+VAR, KBT = 0.3, 0.7
+
+
+@pytest.mark.parametrize("variant", ["opt", "force"])
+def test_staged_opt_and_force_maps(variant):
+    coords, forces, cmap, cons, eps = system()
+    traj = Trajectory(coords=coords, forces=forces)
+    fn = stagedjoptgauss_map if variant == "opt" else stagedjforcegauss_map
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        tm = fn(traj, cmap, var=VAR, kbt=KBT, constraints=cons, noise=eps, gram_dtype=np.float64,
+                l2_regularization=1e-3)
+    assert isinstance(tm, ComposedTMap) and len(tm.submaps) == 2
+    assert isinstance(tm[0], AugmentedTMap) and isinstance(tm[1], SeperableTMap)
+    fit = orc.staged_gauss_fit(coords, forces, cmap.standard_matrix, VAR, KBT, eps[0], variant=variant,
+                               constraints=cons, l2_regularization=1e-3)
+    assert rel(tm[1].force_map.standard_matrix, fit["pre_force_matrix"]) < 1e-5
+    assert rel(tm[0].tmap.force_map.standard_matrix, fit["post_force_matrix"]) < 2e-4
+    assert rel(tm[0].augmenter.source_postmap.standard_matrix, fit["postmap"]) < 1e-5
+    mapped = tm(traj)
+    oc, of = orc.staged_gauss_apply(fit, coords, forces, VAR, KBT, eps[1], variant=variant)
+    assert mapped.coords.shape == (coords.shape[0], 4, 3)
+    assert rel(mapped.coords, oc) < 1e-5 and rel(mapped.forces, of) < 2e-4
+    # two-stage use: pre-map first (e.g. before saving), noising map later
+    pre = tm[1](traj)
+    assert rel(pre.forces, orc.trjdot(forces, fit["pre_force_matrix"])) < 1e-5
+
+
+def test_staged_force_map_warns_on_residual_noise():
+    coords, forces, cmap, cons, eps = system(T=64)
+    with pytest.warns(UserWarning, match="Unable to remove all noise"):
+        stagedjforcegauss_map(Trajectory(coords=coords, forces=forces), cmap, var=VAR, kbt=KBT,
+                              constraints=cons, noise=eps, contribution_tolerance=0.0,
+                              gram_dtype=np.float64)
+
+
+def test_staged_given_force_map_is_used():
+    coords, forces, cmap, cons, eps = system(T=128, seed=3)
+    fmap = LinearMap([[0, 2], [3], [6, 7, 8], [9, 11]], n_fg_sites=12)
+    tm = stagedjoptgauss_map(Trajectory(coords=coords, forces=forces), cmap, var=VAR, kbt=KBT,
+                             force_map=fmap, noise=eps, gram_dtype=np.float64)
+    assert tm[1].force_map is fmap
+    fit = orc.staged_gauss_fit(coords, forces, cmap.standard_matrix, VAR, KBT, eps[0], variant="opt",
+                               force_matrix=fmap.standard_matrix)
+    assert rel(tm[0].tmap.force_map.standard_matrix, fit["post_force_matrix"]) < 2e-4
+    mc, mf = tm.map_arrays(coords, forces)
+    oc, of = orc.staged_gauss_apply(fit, coords, forces, VAR, KBT, eps[1])
+    assert rel(mc, oc) < 1e-5 and rel(mf, of) < 2e-4
+
+
+def test_staged_slice_map_uses_noise_forces_only():
+    coords, forces, cmap, _, eps = system(T=200, seed=5)
+    with pytest.warns(UserWarning, match="Discarding forces"):
+        tm = stagedjslicegauss_map(Trajectory(coords=coords, forces=forces), cmap, var=VAR, kbt=KBT, noise=eps)
+    assert len(tm.submaps) == 3 and isinstance(tm[2], NullForcesTMap)
+    fit = orc.staged_gauss_fit(coords, forces, cmap.standard_matrix, VAR, KBT, eps[0], variant="slice")
+    assert np.array_equal(tm[0].tmap.force_map.standard_matrix, fit["post_force_matrix"])
+    # accepts force-free input; reported forces are -kbt * (y - Mx) / var of the application noise
+    out = tm(CoordsTrajectory(coords=coords))
+    oc, of = orc.staged_gauss_apply(fit, coords, None, VAR, KBT, eps[1], variant="slice")
+    assert np.isfinite(out.forces).all()
+    assert rel(out.coords, oc) < 1e-5 and rel(out.forces, of) < 1e-4
+    expect = -KBT * np.sqrt(VAR) * eps[1] / VAR
+    assert rel(out.forces, expect) < 1e-4
+
+
+def test_source_postmap_log_gradient():
+    rng = np.random.default_rng(11)
+    src = rng.normal(size=(9, 4, 3)).astype(np.float32)
+    gen = rng.normal(size=(9, 4, 3)).astype(np.float32)
+    Q = rng.normal(size=(4, 4))
+    a = CondNormal(var=0.4, source_postmap=Q)
+    ds, dg = a.log_gradient(src, gen)
+    ds0, dg0 = orc.condnormal_log_gradient(src, gen, np.eye(4), 0.4)
+    assert rel(ds, orc.trjdot(ds0, Q)) < 1e-5 and rel(dg, dg0) < 1e-6
+    with pytest.raises(ValueError):
+        a.to_SimpleCondNormal()
