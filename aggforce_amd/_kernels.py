@@ -288,6 +288,31 @@ def sumsq(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def gram_quadform(G: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
+    """q[i] = x_i' G x_i for the rows of X (m, n); float64 on the device."""
+    l = lib()
+    n = G.shape[0]
+    m = X.shape[0]
+    assert G.dtype == torch.float64 and X.dtype == torch.float64 and X.shape[1] == n
+    q = torch.empty(m, dtype=torch.float64, device=G.device)
+    need = l.aggf_gram_quadform_workspace_bytes(n, m)
+    ws = workspace(need, G.device, "quadform")
+    check(l.aggf_gram_quadform(ptr(G.contiguous()), n, ptr(X.contiguous()), m, ptr(q), ptr(ws), need, stream_ptr()),
+          "aggf_gram_quadform")
+    return q
+
+
+def axpby(a: float, x: torch.Tensor, b: float, y: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = a*x + b*y (float64, same shape)."""
+    assert x.dtype == torch.float64 and y.dtype == torch.float64 and x.shape == y.shape
+    x = x.contiguous()
+    y = y.contiguous()
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().aggf_daxpby(x.numel(), float(a), ptr(x), float(b), ptr(y), ptr(out), stream_ptr()), "aggf_daxpby")
+    return out
+
+
 # ------------------------------------------------------------------ K5 augment
 
 

@@ -47,6 +47,9 @@ PROTOTYPES = {
     "aggf_gb_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp]),
     "aggf_pair_dist_var_workspace_bytes": (_sz, [_i64, _i32]),
     "aggf_pair_dist_var": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _sz, _vp]),
+    "aggf_gram_quadform_workspace_bytes": (_sz, [_i32, _i32]),
+    "aggf_gram_quadform": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
+    "aggf_daxpby": (C.c_int, [_i64, _dbl, _vp, _dbl, _vp, _vp, _vp]),
     "aggf_synth_normal": (C.c_int, [_vp, _i64, _i32, C.c_int, _u64, _i64, _dbl, _dbl, _dbl, _vp]),
 }
 

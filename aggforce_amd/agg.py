@@ -86,33 +86,107 @@ def project_forces(
     }
 
 
+_GRAM_REUSE_GRID_ARGS: Final = frozenset({"l2_regularization"})
+_GRAM_REUSE_FIXED_ARGS: Final = frozenset(
+    {"coord_map", "constrained_inds", "method", "l2_regularization", "solver_args", "gram_dtype", "comm"}
+)
+
+
+def _take_frames(arr, idx):
+    if hasattr(arr, "detach"):
+        import torch
+
+        return arr[torch.as_tensor(idx, device=arr.device)]
+    return arr[idx]
+
+
+def _gram_reuse_applicable(grid_names, kwargs) -> bool:
+    """The one-pass cross-validation covers the linear optimiser with explicit constraints."""
+    if kwargs.get("method", qp_linear_map) is not qp_linear_map or "coord_map" not in kwargs:
+        return False
+    if not set(grid_names) <= _GRAM_REUSE_GRID_ARGS or not set(kwargs) <= _GRAM_REUSE_FIXED_ARGS:
+        return False
+    cons = kwargs.get("constrained_inds", PROJECT_FORCES_CNSTR_AUTO)
+    return not isinstance(cons, str)  # "auto" guesses constraints per training subset
+
+
+def _grid_cv_gram_reuse(grid, forces, folds, kwargs) -> Dict[str, Dict[Any, Any]]:
+    """Cross-validation of the linear map in ONE pass over the frames.
+
+    G = sum over frames is additive, so each fold's Gram is formed once (K1), the training Gram of
+    fold k is ``total - G_k`` and the hold-out score of the trained reduced coefficients X is
+    ``sum_i x_i' G_k x_i / (3 T_k n_cg)`` -- no second pass over training or validation frames
+    (replaces the loop body of the reference's agg.py:208-231).
+    """
+    import torch
+    from .qp.qplinear import LinearProblem
+
+    comm = kwargs.get("comm")
+    f_dev = forces
+    prob = LinearProblem(kwargs["coord_map"], kwargs.get("constrained_inds"), f_dev.device)
+    fold_grams = torch.stack([prob.gram(_take_frames(f_dev, idx).contiguous(), kwargs.get("gram_dtype")) for idx in folds])
+    counts = torch.tensor([float(len(idx)) for idx in folds], dtype=torch.float64, device=f_dev.device)
+    all_reduce_sum_(fold_grams, comm)
+    all_reduce_sum_(counts, comm)
+    counts = counts.tolist()
+    total = fold_grams[0].clone()
+    for k in range(1, len(folds)):
+        K.axpby(1.0, total, 1.0, fold_grams[k], out=total)
+    n_cg = prob.A.shape[0]
+    results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
+    train = torch.empty_like(total)
+    for label, args in grid:
+        l2 = dict(kwargs, **args).get("l2_regularization", 0.0)
+        scores = []
+        for k in range(len(folds)):
+            try:
+                K.axpby(1.0, total, -1.0, fold_grams[k], out=train)
+                X = prob.solve(train, l2)
+                q = K.gram_quadform(fold_grams[k], X)
+                scores.append(float(q.cpu().numpy().sum()) / (3.0 * counts[k] * n_cg))
+            except ValueError as e:
+                print(e)
+        results[SCORES_KNAME][label] = mean(scores)
+        results[SDS_KNAME][label] = sample_sd(scores)
+        results[NRUNS_KNAME][label] = len(scores)
+    return results
+
+
 def project_forces_grid_cv(
     cv_arg_dict: Mapping[str, List[T]],
     coords,
     forces,
     n_folds: int = 5,
     rng=None,
+    reuse_gram: bool = True,
     **kwargs,
 ) -> Dict[str, Dict[NamedTuple, T]]:
     """Grid cross-validation over project_forces arguments (reference agg.py:142-235).
 
-    Host-side hyper-parameter loop around the hot path.  ``rng`` (a numpy Generator) makes the
-    fold shuffle reproducible; the reference uses an unseeded generator.
+    For every grid point the map is trained on the frames outside each fold and scored by
+    ``force_smoothness`` of the mapped hold-out forces; returns ``{"scores", "sds", "n_runs"}``
+    keyed by the grid point.  ``rng`` (a numpy Generator) makes the fold shuffle reproducible; the
+    reference uses an unseeded generator.  When the grid runs over ``l2_regularization`` of the
+    linear optimiser with explicit constraints and ``reuse_gram`` is true, all folds and grid
+    points share one pass over the frames (``_grid_cv_gram_reuse``); otherwise the reference's
+    loop over ``project_forces`` calls is followed.
+
+    (The reference calls ``trained_tmap.from_arrays`` at agg.py:224, which no TMap defines; the
+    intended ``map_arrays`` is used here.)
     """
     n_frames = forces.shape[0]
     frames = np.arange(n_frames)
     (np.random.default_rng() if rng is None else rng).shuffle(frames)
     folds = np.array_split(frames, n_folds)
+    grid = process_cvargs(cv_arg_dict)
+    if reuse_gram and _gram_reuse_applicable(list(cv_arg_dict.keys()), kwargs):
+        f_dev = K.as_device(forces)
+        if not K.has_nan(f_dev):  # NaN handling follows the generic path
+            return _grid_cv_gram_reuse(grid, f_dev, folds, kwargs)
+        del f_dev
     results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
-
-    def take(arr, idx):
-        if hasattr(arr, "detach"):
-            import torch
-
-            return arr[torch.as_tensor(idx, device=arr.device)]
-        return arr[idx]
-
-    for label, args in process_cvargs(cv_arg_dict):
+    take = _take_frames
+    for label, args in grid:
         scores = []
         merged = dict(kwargs, **args)
         for k, val_idx in enumerate(folds):
@@ -122,7 +196,7 @@ def project_forces_grid_cv(
                     TMAP_KNAME
                 ]
                 _, val_forces = tmap.map_arrays(take(coords, val_idx), take(forces, val_idx))
-                scores.append(force_smoothness(val_forces))
+                scores.append(force_smoothness(val_forces, comm=merged.get("comm")))
                 del tmap
             except ValueError as e:
                 print(e)

@@ -504,7 +504,8 @@ extern "C" int aggf_eq_qp_solve(const double* G, int32_t n, double l2, const dou
   cholesky(c, S, mpad, DinvS, stats, n);
   // Lam = S^-1 Bp ; Xt = L^-T (Y Lam)
   auto schur_solve = [&](const double* rhs, double* out) {
-    hipMemcpyAsync(T1, rhs, (size_t)mpad * rpad * sizeof(double), hipMemcpyDeviceToDevice, st);
+    if (hipMemcpyAsync(T1, rhs, (size_t)mpad * rpad * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      c.rc = fail(AGGF_ERR_HIP, "aggf_eq_qp_solve: device copy failed");
     solve_lower(c, S, mpad, DinvS, T1, T2, rpad);
     solve_lower_t(c, S, mpad, DinvS, T2, out, rpad);
   };
@@ -527,4 +528,72 @@ extern "C" int aggf_eq_qp_solve(const double* G, int32_t n, double l2, const dou
   hipLaunchKernelGGL(crop_transpose_kernel, flat_grid((int64_t)nrhs * n), dim3(256), 0, st, Xt, rpad, n, nrhs, X);
   AGGF_LAUNCH_OK();
   return c.rc;
+}
+
+// ---- Gram algebra for cross-validation (project_forces_grid_cv with Gram reuse) ---------------
+namespace aggf {
+
+// q[i] = sum_a X[i,a] * Y[i,a]; one workgroup per row, fixed summation order
+__global__ __launch_bounds__(256) void rowdot_kernel(const double* __restrict__ X, int64_t ldx,
+                                                     const double* __restrict__ Y, int64_t ldy, int n,
+                                                     double* __restrict__ q) {
+  __shared__ double part[256];
+  const int i = blockIdx.x, tid = threadIdx.x;
+  double s = 0.0;
+  for (int a = tid; a < n; a += 256) s += X[(int64_t)i * ldx + a] * Y[(int64_t)i * ldy + a];
+  part[tid] = s;
+  __syncthreads();
+  for (int w = 128; w > 0; w >>= 1) {
+    if (tid < w) part[tid] += part[tid + w];
+    __syncthreads();
+  }
+  if (tid == 0) q[i] = part[0];
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(int64_t n, double a, const double* __restrict__ x,
+                                                    double b, const double* __restrict__ y,
+                                                    double* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n;
+       e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = a * x[e] + b * y[e];
+}
+
+}  // namespace aggf
+
+extern "C" size_t aggf_gram_quadform_workspace_bytes(int32_t n, int32_t m) {
+  if (n <= 0 || m <= 0) return 0;
+  const size_t npad = (size_t)round_up(n, 64), mpad = (size_t)round_up(m, 64);
+  return (npad * npad + 2 * mpad * npad) * sizeof(double) + 256;
+}
+
+extern "C" int aggf_gram_quadform(const double* G, int32_t n, const double* X, int32_t m, double* q,
+                                  void* ws, size_t ws_bytes, void* stream_v) {
+  hipStream_t st = (hipStream_t)stream_v;
+  if (!G || !X || !q || !ws) return fail(AGGF_ERR_ARG, "aggf_gram_quadform: NULL pointer");
+  if (n <= 0 || m <= 0) return fail(AGGF_ERR_ARG, "aggf_gram_quadform: empty problem");
+  if (ws_bytes < aggf_gram_quadform_workspace_bytes(n, m))
+    return fail(AGGF_ERR_WORKSPACE, "aggf_gram_quadform: workspace too small");
+  const int npad = (int)round_up(n, 64), mpad = (int)round_up(m, 64);
+  double* Gp = reinterpret_cast<double*>(ws);
+  double* Xp = Gp + (size_t)npad * npad;
+  double* Y = Xp + (size_t)mpad * npad;
+  Ctx c{st};
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * npad), dim3(256), 0, st, G, n, n, 0, Gp, npad, npad);
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad), dim3(256), 0, st, X, m, n, 0, Xp, mpad, npad);
+  AGGF_LAUNCH_OK();
+  gemm<false, false>(c, mpad, npad, npad, 1.0, Xp, npad, Gp, npad, 0.0, Y, npad);  // Y = X G
+  if (c.rc) return c.rc;
+  hipLaunchKernelGGL(rowdot_kernel, dim3(m), dim3(256), 0, st, Xp, (int64_t)npad, Y, (int64_t)npad, n, q);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_daxpby(int64_t n, double a, const double* x, double b, const double* y, double* out,
+                           void* stream_v) {
+  hipStream_t st = (hipStream_t)stream_v;
+  if (!x || !y || !out) return fail(AGGF_ERR_ARG, "aggf_daxpby: NULL pointer");
+  if (n <= 0) return AGGF_OK;
+  hipLaunchKernelGGL(axpby_kernel, flat_grid(n), dim3(256), 0, st, n, a, x, b, y, out);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
 }

@@ -72,6 +72,56 @@ def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndar
     return X, st
 
 
+class LinearProblem:
+    """Reduced-variable layout of one (coord_map, constraints) pair: Gram, solve and map assembly.
+
+    Shared by ``qp_linear_map`` and the Gram-reusing cross-validation (``agg.project_forces_grid_cv``):
+    ``gram`` is K1 on the atoms merged into constraint groups, ``solve`` is K2 for all CG sites,
+    ``tmap`` expands the reduced coefficients (n_cg, n_red) to the force map (n_cg, n_fg).
+    """
+
+    def __init__(self, coord_map: LinearMap, constraints: Union[None, Constraints], device) -> None:
+        import torch
+
+        self.coord_map = coord_map
+        self.device = device
+        self.n_fg = coord_map.n_fg_sites
+        self.goa, self.n_red = group_layout(self.n_fg, constraints if constraints is not None else set())
+        self.grp_ptr = self.grp_atoms = None
+        # A = M @ C and diag(C'C) without forming C
+        M = np.asarray(coord_map.standard_matrix, dtype=np.float64)
+        if self.n_red != self.n_fg:
+            ptr_h, atoms_h = groups_csr(self.goa, self.n_red)
+            self.grp_ptr = torch.from_numpy(ptr_h).to(device)
+            self.grp_atoms = torch.from_numpy(atoms_h).to(device)
+            self.A = np.add.reduceat(M[:, atoms_h], ptr_h[:-1], axis=1)
+        else:
+            self.A = M
+        self.sizes = torch.from_numpy(np.bincount(self.goa, minlength=self.n_red).astype(np.float64)).to(device)
+
+    def gram(self, forces, gram_dtype=None):
+        import torch
+
+        if forces.shape[1] != self.n_fg:
+            raise ValueError(f"forces have {forces.shape[1]} sites but coord_map expects {self.n_fg}")
+        cdt = forces.dtype if gram_dtype is None else K.torch_dtype(gram_dtype)
+        if forces.dtype == torch.float64:
+            cdt = torch.float64
+        return K.gram(forces, self.grp_ptr, self.grp_atoms, self.n_red, cdt)
+
+    def solve(self, G, l2_regularization: float = 0.0):
+        X, _ = solve_constrained_maps(G, float(l2_regularization), self.sizes, self.A)
+        return X
+
+    def tmap(self, X) -> SeperableTMap:
+        import torch
+
+        W = K.expand_map(X, torch.from_numpy(self.goa).to(self.device), self.n_fg)
+        force_map = LinearMap(W.cpu().numpy())
+        force_map._dev_cache[(torch.float64, str(self.device))] = (force_map.standard_matrix, W)
+        return SeperableTMap(coord_map=self.coord_map, force_map=force_map)
+
+
 def qp_linear_map(
     traj: ForcesTrajectory,
     coord_map: LinearMap,
@@ -95,36 +145,8 @@ def qp_linear_map(
 
     Returns ``SeperableTMap(coord_map, LinearMap(W))`` with ``W`` float64 (n_cg, n_fg).
     """
-    import torch
-
-    if constraints is None:
-        constraints = set()
     forces = K.as_device(traj.forces)
-    dev = forces.device
-    n_fg = coord_map.n_fg_sites
-    if forces.shape[1] != n_fg:
-        raise ValueError(f"forces have {forces.shape[1]} sites but coord_map expects {n_fg}")
-    goa, n_red = group_layout(n_fg, constraints)
-    grp_ptr = grp_atoms = None
-    if n_red != n_fg:
-        ptr_h, atoms_h = groups_csr(goa, n_red)
-        grp_ptr = torch.from_numpy(ptr_h).to(dev)
-        grp_atoms = torch.from_numpy(atoms_h).to(dev)
-    cdt = forces.dtype if gram_dtype is None else K.torch_dtype(gram_dtype)
-    if forces.dtype == torch.float64:
-        cdt = torch.float64
-    G = K.gram(forces, grp_ptr, grp_atoms, n_red, cdt)
+    prob = LinearProblem(coord_map, constraints, forces.device)
+    G = prob.gram(forces, gram_dtype)
     all_reduce_sum_(G, comm)
-    # A = M @ C and diag(C'C) without forming C
-    M = np.asarray(coord_map.standard_matrix, dtype=np.float64)
-    if n_red == n_fg:
-        A = M
-    else:
-        A = np.add.reduceat(M[:, atoms_h], ptr_h[:-1], axis=1)
-    sizes = torch.from_numpy(np.bincount(goa, minlength=n_red).astype(np.float64)).to(dev)
-    X, _ = solve_constrained_maps(G, float(l2_regularization), sizes, A)
-    goa_dev = torch.from_numpy(goa).to(dev)
-    W = K.expand_map(X, goa_dev, n_fg)
-    force_map = LinearMap(W.cpu().numpy())
-    force_map._dev_cache[(torch.float64, str(dev))] = (force_map.standard_matrix, W)
-    return SeperableTMap(coord_map=coord_map, force_map=force_map)
+    return prob.tmap(prob.solve(G, l2_regularization))

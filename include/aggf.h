@@ -218,6 +218,22 @@ int aggf_pair_dist_var(const void* X, int64_t T, int32_t N, int dtype, double* v
                        size_t ws_bytes, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Gram algebra for cross-validation.  Replaces, inside project_forces_grid_cv
+ * (agg.py:142-235), the n_folds x |grid| repeated passes over the training and
+ * validation frames: G is additive over frames, so per-fold Grams are formed once
+ * (aggf_gram), the training Gram is total - fold (aggf_daxpby), and the hold-out
+ * score of a map with reduced coefficients X is
+ *     mean((W F_val)^2) = sum_i x_i' G_fold x_i / (3 T_val n_cg)   (agg.py:224-227,291-297).
+ * aggf_gram_quadform: q[i] = x_i' G x_i for the m rows of X (m, n); G (n, n) float64.
+ * aggf_daxpby: out = a*x + b*y on n float64 elements (out may alias x or y).
+ * ------------------------------------------------------------------------- */
+size_t aggf_gram_quadform_workspace_bytes(int32_t n, int32_t m);
+int aggf_gram_quadform(const double* G, int32_t n, const double* X, int32_t m, double* q, void* ws,
+                       size_t ws_bytes, void* stream);
+int aggf_daxpby(int64_t n, double a, const double* x, double b, const double* y, double* out,
+                void* stream);
+
+/* ---------------------------------------------------------------------------
  * Synthetic trajectories for benchmarks and full-size property tests (no
  * reference counterpart).  out[t,a,d] = mean + sigma * z(seed, frame_offset+t, a, d)
  * with z a counter-based standard normal (Philox4x32-10 + Box-Muller), so any

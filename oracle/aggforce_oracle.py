@@ -578,3 +578,23 @@ def staged_gauss_apply(fit, coords, forces, var, kbt, noise, variant="opt", dtyp
     full_coords, full_forces = _augment_postmap(c1, f1, var, kbt, noise, fit["postmap"], dtype)
     slice_map = list_mapping_matrix([[x] for x in range(n_cg, 2 * n_cg)], 2 * n_cg)
     return trjdot(full_coords, slice_map), linearmap_apply(full_forces, W2)
+
+
+def project_forces_grid_cv(grid_l2, coords, forces, coord_matrix, folds, constraints=None):
+    """Intent of project_forces_grid_cv for the linear optimiser; agg.py:185-234.
+
+    ``folds``: list of frame-index arrays (the reference shuffles with an unseeded generator, so
+    the split is an input here).  Returns {l2: (mean score, sample sd, n_runs)} with the hold-out
+    score force_smoothness(W F_val) (agg.py:224-227; ``from_arrays`` there is read as ``map_arrays``).
+    """
+    out = {}
+    for l2 in grid_l2:
+        scores = []
+        for k, val in enumerate(folds):
+            train = np.concatenate([f for j, f in enumerate(folds) if j != k])
+            W = qp_linear_map(forces[train], coord_matrix, constraints, l2)
+            scores.append(float(np.mean(linearmap_apply(forces[val], W) ** 2)))
+        m = sum(scores) / len(scores)
+        sd = (sum((s - m) ** 2 for s in scores) / (len(scores) - 1)) ** 0.5
+        out[l2] = (m, sd, len(scores))
+    return out

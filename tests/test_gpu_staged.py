@@ -119,3 +119,48 @@ def test_source_postmap_log_gradient():
     assert rel(ds, orc.trjdot(ds0, Q)) < 1e-5 and rel(dg, dg0) < 1e-6
     with pytest.raises(ValueError):
         a.to_SimpleCondNormal()
+
+
+# ------------------------------------------------------------------ cross-validation
+def test_grid_cv_gram_reuse_matches_loop_and_oracle():
+    from aggforce_amd.agg import project_forces_grid_cv
+
+    coords, forces, cmap, cons, _ = system(T=300, seed=9)
+    forces = forces.astype(np.float64)
+    grid = {"l2_regularization": [0.0, 1e-2, 10.0]}
+    kw = dict(coord_map=cmap, constrained_inds=cons)
+    fast = project_forces_grid_cv(grid, coords, forces, n_folds=4, rng=np.random.default_rng(5), **kw)
+    loop = project_forces_grid_cv(grid, coords, forces, n_folds=4, rng=np.random.default_rng(5),
+                                  reuse_gram=False, **kw)
+    frames = np.arange(300)
+    np.random.default_rng(5).shuffle(frames)
+    ref = orc.project_forces_grid_cv(grid["l2_regularization"], coords, forces, cmap.standard_matrix,
+                                     np.array_split(frames, 4), cons)
+    assert set(fast) == {"scores", "sds", "n_runs"}
+    for key in fast["scores"]:
+        l2 = key.l2_regularization
+        assert fast["n_runs"][key] == loop["n_runs"][key] == 4
+        assert abs(fast["scores"][key] - loop["scores"][key]) < 1e-9 * abs(loop["scores"][key])
+        assert abs(fast["sds"][key] - loop["sds"][key]) < 1e-7 * abs(loop["sds"][key])
+        assert abs(fast["scores"][key] - ref[l2][0]) < 1e-8 * abs(ref[l2][0])
+        assert abs(fast["sds"][key] - ref[l2][1]) < 1e-6 * abs(ref[l2][1])
+    # the generic loop is taken for anything the one-pass form does not cover
+    auto = project_forces_grid_cv({"l2_regularization": [0.0]}, coords, forces, n_folds=3,
+                                  rng=np.random.default_rng(1), coord_map=cmap, constrained_inds="auto")
+    assert auto["n_runs"][next(iter(auto["n_runs"]))] == 3
+
+
+def test_gram_quadform_and_axpby():
+    import torch
+    from aggforce_amd import _kernels as K
+
+    rng = np.random.default_rng(2)
+    for n, m in [(5, 3), (64, 64), (130, 7)]:
+        B = rng.normal(size=(n, n))
+        G = B @ B.T
+        X = rng.normal(size=(m, n))
+        q = K.gram_quadform(torch.from_numpy(G).cuda(), torch.from_numpy(X).cuda()).cpu().numpy()
+        assert rel(q, np.einsum("ia,ab,ib->i", X, G, X)) < 1e-12
+    a = torch.from_numpy(rng.normal(size=(33, 7))).cuda()
+    b = torch.from_numpy(rng.normal(size=(33, 7))).cuda()
+    assert torch.equal(K.axpby(2.0, a, -0.5, b), 2.0 * a - 0.5 * b)
