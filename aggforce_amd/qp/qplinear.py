@@ -99,7 +99,8 @@ class LinearProblem:
             self.A = M
         self.sizes = torch.from_numpy(np.bincount(self.goa, minlength=self.n_red).astype(np.float64)).to(device)
 
-    def gram(self, forces, gram_dtype=None):
+    def gram(self, forces, gram_dtype=None, out=None, accumulate: bool = False):
+        """K1 on one block of frames; ``out``/``accumulate`` add to an existing Gram (frame chunks)."""
         import torch
 
         if forces.shape[1] != self.n_fg:
@@ -107,7 +108,7 @@ class LinearProblem:
         cdt = forces.dtype if gram_dtype is None else K.torch_dtype(gram_dtype)
         if forces.dtype == torch.float64:
             cdt = torch.float64
-        return K.gram(forces, self.grp_ptr, self.grp_atoms, self.n_red, cdt)
+        return K.gram(forces, self.grp_ptr, self.grp_atoms, self.n_red, cdt, out=out, accumulate=accumulate)
 
     def solve(self, G, l2_regularization: float = 0.0):
         X, _ = solve_constrained_maps(G, float(l2_regularization), self.sizes, self.A)

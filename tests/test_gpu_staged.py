@@ -164,3 +164,35 @@ def test_gram_quadform_and_axpby():
     a = torch.from_numpy(rng.normal(size=(33, 7))).cuda()
     b = torch.from_numpy(rng.normal(size=(33, 7))).cuda()
     assert torch.equal(K.axpby(2.0, a, -0.5, b), 2.0 * a - 0.5 * b)
+
+
+# ------------------------------------------------------------------ out-of-core streaming
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_streamed_project_forces_matches_in_memory(tmp_path, dt):
+    from aggforce_amd import project_forces
+    from aggforce_amd.stream import load_trajectory, project_forces_streamed
+
+    coords, forces, cmap, cons, _ = system(T=1000, seed=21)
+    coords, forces = coords.astype(dt), forces.astype(dt)
+    np.save(tmp_path / "run_coords.npy", coords)
+    np.save(tmp_path / "run_forces.npy", forces)
+    mc, mf = load_trajectory(str(tmp_path / "run"))
+    assert isinstance(mf, np.memmap)
+    ref = project_forces(coords, forces, cmap, cons, l2_regularization=1e-3, gram_dtype=np.float64)
+    out = project_forces_streamed(mc, mf, cmap, cons, l2_regularization=1e-3, chunk_frames=128,
+                                  gram_dtype=np.float64)  # 7 full chunks + a ragged one
+    W0 = ref["tmap"].force_map.standard_matrix
+    assert rel(out["tmap"].force_map.standard_matrix, W0) < 1e-9
+    assert out["mapped_forces"].dtype == ref["mapped_forces"].dtype
+    assert out["mapped_coords"].dtype == ref["mapped_coords"].dtype
+    assert rel(out["mapped_forces"], ref["mapped_forces"]) < 1e-9
+    assert rel(out["mapped_coords"], ref["mapped_coords"]) < 1e-6
+    assert abs(out["residual"] - ref["residual"]) < 1e-9 * ref["residual"]
+    # and against the oracle
+    Wo = orc.qp_linear_map(forces, cmap.standard_matrix, cons, 1e-3)
+    assert rel(out["tmap"].force_map.standard_matrix, Wo) < 1e-6
+    one = project_forces_streamed(mc, mf, cmap, cons, l2_regularization=1e-3, chunk_frames=5000,
+                                  gram_dtype=np.float64)
+    assert rel(one["mapped_forces"], ref["mapped_forces"]) < 1e-12
+    with pytest.raises(ValueError):
+        project_forces_streamed(mc, mf, cmap, "auto")

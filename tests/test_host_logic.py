@@ -192,3 +192,20 @@ def test_frame_sharded_gram_allreduce_gloo(tmp_path):
         assert np.isclose(acc[0] / acc[1], np.mean(forces ** 2))
     # replicated ranks hold bit-identical reduced matrices -> identical replicated solves
     assert np.array_equal(np.load(tmp_path / "G0.npy"), np.load(tmp_path / "G1.npy"))
+
+
+def test_load_trajectory_npz_and_npy(tmp_path):
+    from aggforce_amd.stream import default_chunk_frames, load_trajectory
+
+    rng = np.random.default_rng(0)
+    c, f = rng.random((7, 5, 3)), rng.random((7, 5, 3))
+    np.savez(tmp_path / "traj.npz", coords=c, Fs=f)  # the reference's file layout
+    lc, lf = load_trajectory(str(tmp_path / "traj.npz"))
+    assert np.array_equal(lc, c) and np.array_equal(lf, f)
+    with pytest.raises(KeyError):
+        load_trajectory(str(tmp_path / "traj.npz"), forces_key="forces")
+    np.save(tmp_path / "x_coords.npy", c)
+    np.save(tmp_path / "x_forces.npy", f)
+    mc, mf = load_trajectory(str(tmp_path / "x"))
+    assert isinstance(mc, np.memmap) and np.array_equal(mf, f)
+    assert default_chunk_frames(4096, 8) == (8 << 30) // (4 * 4096 * 24)
