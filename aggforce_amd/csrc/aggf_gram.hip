@@ -245,12 +245,24 @@ struct DmaCfg<float> {
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
   if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if constexpr (N == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if constexpr (N == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
   else if constexpr (N == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
   else if constexpr (N == 4) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  else if constexpr (N == 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
   else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+  else if constexpr (N == 7) asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
   else static_assert(N == 0, "unsupported vmcnt");
 }
+
+#ifdef AGGF_GRAM_PROF
+// tools/clock_probe.hip: shader cycles per wave spent issuing DMAs / in ds_read+MFMA / in waitcnt+barrier
+__device__ unsigned long long aggf_gram_prof[4];
+#define AGGF_PROF_T(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define AGGF_PROF_T(x)
+#endif
 
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2>
 __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
@@ -319,6 +331,9 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
   // because concurrent misses to one line are not merged (TCC_MISS == TCC_EA0_RDREQ before).
   const int skew = n_it > 16 ? ((ti + tj) & 7) : 0;
   auto stage_of = [&](int seq) { const int v = seq + skew; return v >= n_it ? v - n_it : v; };
+  // sequence position of the one stage with fewer than KB valid rows (last split only), or -1
+  const bool ragged = n_it > 0 && (t_end - t_begin) % KB != 0;
+  const int ragged_seq = ragged ? (n_it - 1 - skew + (n_it - 1 - skew < 0 ? n_it : 0)) : -1;
   auto prep_stage = [&](int seq) {
     const int s = seq;  // ring slot follows the sequence position
     const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
@@ -334,7 +349,9 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
     }
   };
   auto issue_piece = [&](int s, int q) {
-    const int64_t t0 = t_begin + (int64_t)stage_of(s) * KB;
+    // ABL 3 (ablation): every stage re-reads the first rows of the split -> all DMAs hit the L2
+    // ABL 4: cycle over 8 stages -> DMAs miss the L1 but hit the L2
+    const int64_t t0 = t_begin + (ABL == 3 ? 0 : ABL == 4 ? (int64_t)(stage_of(s) & 7) * KB : (int64_t)stage_of(s) * KB);
     const bool row_ok = t0 + p_row[q] < t_end;
     const bool lane_ok = !p_half[q] || lane < 32;
     if (row_ok && lane_ok) {
@@ -360,16 +377,21 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
 
   if (n_it > 0) issue_stage(0);
   if (AHEAD > 1 && n_it > 1) issue_stage(1);
-  if (AHEAD > 1 && n_it > 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+  if (AHEAD > 1 && n_it > 1 && ragged_seq != 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
 
+#ifdef AGGF_GRAM_PROF
+  uint64_t prof_issue = 0, prof_compute = 0, prof_sync = 0;
+#endif
   for (int it = 0; it < n_it; ++it) {
+    AGGF_PROF_T(p0);
     // DMAs of stage it+2 first (placing them between the MFMA groups instead, or raising the
     // wave priority around the MFMA groups, measured no better: tools/gram_ablate.hip history)
-    if (ABL == 0 && it + AHEAD < n_it) issue_stage(it + AHEAD);
-    const T* pa = smem + ((ABL ? it % 2 : it % NBUF)) * BUF_ELEMS;
+    if ((ABL == 0 || ABL >= 3) && it + AHEAD < n_it) issue_stage(it + AHEAD);
+    const T* pa = smem + (((ABL == 1 || ABL == 2) ? it % 2 : it % NBUF)) * BUF_ELEMS;
+    AGGF_PROF_T(p1);
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
@@ -385,14 +407,31 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
           for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
       }
     }
+    AGGF_PROF_T(p2);
     // stage it+1 must have landed (this wave's pieces), stage it+2 may stay in flight
-    if (ABL < 2) {
-      if (AHEAD > 1 && it + 2 < n_it) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+    if (ABL != 2) {
+      // (the ragged stage of the last split issues fewer DMAs: a counted wait would let pieces
+      // of stage it+1 slip through)
+      if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
     }
+#ifdef AGGF_GRAM_PROF
+    const uint64_t p3 = __builtin_readcyclecounter();
+    prof_issue += p1 - p0;
+    prof_compute += p2 - p1;
+    prof_sync += p3 - p2;
+#endif
   }
+#ifdef AGGF_GRAM_PROF
+  if (lane == 0) {
+    atomicAdd(&aggf_gram_prof[0], (unsigned long long)prof_issue);
+    atomicAdd(&aggf_gram_prof[1], (unsigned long long)prof_compute);
+    atomicAdd(&aggf_gram_prof[2], (unsigned long long)prof_sync);
+    atomicAdd(&aggf_gram_prof[3], (unsigned long long)n_it);
+  }
+#endif
 
   T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
 #pragma unroll
@@ -417,6 +456,269 @@ __global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table
       for (int ti = si * 8; ti < si * 8 + 8 && ti < nt1; ++ti)
         for (int tj = sj * 8; tj < sj * 8 + 8 && tj < nt1; ++tj)
           if (tj >= ti) table[k++] = (ti << 16) | tj;
+}
+
+// ---------------------------------------------------------------------------
+// Pair-tile LDS-DMA kernel: one workgroup of 8 waves = TWO 128x128 output units.
+//
+// Why: with one 128x128 unit per 4-wave workgroup (2 workgroups per CU) the kernel is bound by the
+// number of cache-line misses the CU's vector L1 keeps in flight, not by MFMA, LDS or HBM
+// (tools/clock_probe.hip: 283 ms without DMAs, 293 ms with DMAs that hit the L1, 304 ms with L2 hits,
+// 317 ms shipped; the waves stall in the DMA *issue*, for about one memory latency per stage).  The
+// lever is bytes per flop through the L1: the upper wave group computes unit (ua_i, ua_j), the lower
+// group unit (ub_i, ub_j), and the panels they have in common are staged once.  Regular entries are
+// (2I, j) + (2I+1, j) with j >= 2I+2 -- 3 panels for 2 units, 25 % fewer bytes; the 3 units per
+// row pair that touch the diagonal are paired among themselves, so no flop is wasted.
+// Same slab format as the unit kernels (gram_reduce_kernel is shared).
+constexpr int PAIR_THREADS = 512;
+constexpr int PAIR_SLOTS = 4;   // distinct panels staged per LDS stage (at most)
+constexpr int PAIR_NBUF = 3;    // ring depth: 3 x 4 x 12.8 KB = 153.6 KB of the 160 KB
+
+struct PairEntry {
+  int32_t a, b;  // (i | j << 16) of the upper / lower unit; b = -1: no lower unit
+};
+
+// number of entries for nt1 unit rows (host and device agree by construction)
+__host__ __device__ inline int pair_entry_count(int nt1) {
+  const int nrb = nt1 / 2;
+  int64_t regular = 0;
+  for (int I = 0; I < nrb; ++I) regular += nt1 - (2 * I + 2) > 0 ? nt1 - (2 * I + 2) : 0;
+  const int left = 3 * nrb + (nt1 & 1);
+  return (int)(regular + (left + 1) / 2);
+}
+
+// entries in XCD-friendly order: 4 row pairs x 8 columns = 32 consecutive regular entries share
+// 8 + 8 panels; leftovers (diagonal units) at the end, paired in sequence
+__global__ void build_pair_table_kernel(int32_t nt1, PairEntry* __restrict__ table) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const int nrb = nt1 / 2;
+  int k = 0;
+  for (int si = 0; si * 4 < nrb; ++si)
+    for (int sj = 0; sj * 8 < nt1; ++sj)
+      for (int I = si * 4; I < si * 4 + 4 && I < nrb; ++I)
+        for (int j = sj * 8; j < sj * 8 + 8 && j < nt1; ++j)
+          if (j >= 2 * I + 2) {
+            table[k].a = (2 * I) | (j << 16);
+            table[k].b = (2 * I + 1) | (j << 16);
+            ++k;
+          }
+  int pending = -1;
+  auto leftover = [&](int i, int j) {
+    const int u = i | (j << 16);
+    if (pending < 0) {
+      pending = u;
+    } else {
+      table[k].a = pending;
+      table[k].b = u;
+      ++k;
+      pending = -1;
+    }
+  };
+  for (int I = 0; I < nrb; ++I) {
+    leftover(2 * I, 2 * I);
+    leftover(2 * I, 2 * I + 1);
+    leftover(2 * I + 1, 2 * I + 1);
+  }
+  if (nt1 & 1) leftover(nt1 - 1, nt1 - 1);
+  if (pending >= 0) {
+    table[k].a = pending;
+    table[k].b = -1;
+  }
+}
+
+template <int MAXN>
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  // s_waitcnt takes an immediate: dispatch on the (wave-uniform) count
+  if (n <= 0) wait_vmcnt<0>();
+  else if (n == 1) wait_vmcnt<1>();
+  else if (n == 2) wait_vmcnt<2>();
+  else if (n == 3) wait_vmcnt<3>();
+  else if (n == 4) wait_vmcnt<4>();
+  else if (n == 5) wait_vmcnt<5>();
+  else if (n == 6) wait_vmcnt<6>();
+  else if (n == 7) wait_vmcnt<7>();
+  else wait_vmcnt<8>();
+  static_assert(MAXN <= 8, "extend the dispatch");
+}
+
+template <typename T, int ABL = 0>
+__global__ __launch_bounds__(PAIR_THREADS, 1) void gram_pair_dma_kernel(
+    const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_entries, int32_t ksplit,
+    const PairEntry* __restrict__ table, int64_t frames_per_split, T* __restrict__ slabs) {
+  using M = Mfma<T>;
+  using acc_t = typename M::acc_t;
+  constexpr int KB = GramCfg<T>::KB;
+  constexpr int RP = DmaCfg<T>::ROW_PIECES;
+  constexpr int PE = DmaCfg<T>::PIECE_ELEMS;
+  constexpr int SLOT_PIECES = KB * RP;                         // 12 (f64) / 16 (f32)
+  constexpr int MAXPPW = (PAIR_SLOTS * SLOT_PIECES + 7) / 8;   // 6 / 8
+  constexpr int PANEL_ELEMS = KB * ROW_STRIDE;
+  constexpr int BUF_ELEMS = PAIR_SLOTS * PANEL_ELEMS;
+  constexpr int NBUF = PAIR_NBUF;
+  constexpr int AHEAD = NBUF - 1;
+
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  T* smem = reinterpret_cast<T*>(smem_raw);
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int grp = wave >> 2;              // 0: upper unit, 1: lower unit
+  const int wm = (wave >> 1) & 1, wn = wave & 1;
+
+  // workgroup -> (split, entry), XCD-aware: workgroups b and b+8 share an XCD, which runs 32 of
+  // them at a time (one per CU); give each XCD 32 consecutive entries of the list
+  const int b = blockIdx.x;
+  const int v = (((b >> 3) >> 5) * 8 + (b & 7)) * 32 + ((b >> 3) & 31);
+  if (v >= ksplit * n_entries) return;  // grid is padded to a multiple of 256
+  const int ks = v / n_entries;
+  const PairEntry ent = table[v - ks * n_entries];
+  const int ua_i = ent.a & 0xffff, ua_j = (ent.a >> 16) & 0xffff;
+  const bool has_b = ent.b >= 0;
+  const int ub_i = has_b ? (ent.b & 0xffff) : ua_i, ub_j = has_b ? ((ent.b >> 16) & 0xffff) : ua_j;
+
+  // distinct panels -> LDS slots (all wave-uniform, straight-line: nothing may end up in scratch,
+  // whose loads would count against vmcnt)
+  const int s0 = ua_i;
+  int s1 = -1, s2 = -1, s3 = -1, ns = 1;
+  const int a_up = 0;
+  int b_up = 0, a_lo = 0, b_lo = 0;
+  if (ua_j != s0) { s1 = ua_j; b_up = 1; ns = 2; }
+  if (ub_i == s0) a_lo = 0;
+  else if (ns > 1 && ub_i == s1) a_lo = 1;
+  else if (ns == 1) { s1 = ub_i; a_lo = 1; ns = 2; }
+  else { s2 = ub_i; a_lo = 2; ns = 3; }
+  if (ub_j == s0) b_lo = 0;
+  else if (ns > 1 && ub_j == s1) b_lo = 1;
+  else if (ns > 2 && ub_j == s2) b_lo = 2;
+  else if (ns == 1) { s1 = ub_j; b_lo = 1; ns = 2; }
+  else if (ns == 2) { s2 = ub_j; b_lo = 2; ns = 3; }
+  else { s3 = ub_j; b_lo = 3; ns = 4; }
+  const int slotA = grp ? a_lo : a_up, slotB = grp ? b_lo : b_up;
+  const bool active = grp == 0 || has_b;
+  const int my_i = grp ? ub_i : ua_i, my_j = grp ? ub_j : ua_j;
+
+  const int64_t t_begin = (int64_t)ks * frames_per_split;
+  int64_t t_end = t_begin + frames_per_split;
+  if (t_end > n_rows) t_end = n_rows;
+  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KB - 1) / KB) : 0;
+
+  // this wave's DMA pieces: piece p = wave + 8 q -> (slot, row, column piece)
+  const int n_pieces = ns * SLOT_PIECES;
+  const int my_cnt = n_pieces > wave ? (n_pieces - wave + 7) / 8 : 0;
+  int64_t g_off[MAXPPW];
+  int l_off[MAXPPW];
+#pragma unroll
+  for (int q = 0; q < MAXPPW; ++q) {
+    const int p = wave + 8 * q;
+    const int slot = p / SLOT_PIECES;
+    const int r = (p - slot * SLOT_PIECES) / RP;
+    const int cp = p % RP;
+    const int panel = slot == 0 ? s0 : slot == 1 ? s1 : slot == 2 ? s2 : s3;
+    g_off[q] = (int64_t)r * ld + (int64_t)panel * ROW_ELEMS + cp * PE + lane * (16 / (int)sizeof(T));
+    l_off[q] = slot * PANEL_ELEMS + r * ROW_STRIDE + cp * PE;
+  }
+
+  // stage order rotated per entry (see gram_tile_dma_kernel); the one ragged stage of the last
+  // split issues fewer DMAs, so the counted wait must not assume a full newest stage there
+  const int skew = n_it > 16 ? ((ua_i + ua_j) & 7) : 0;
+  auto stage_of = [&](int seq) { const int u = seq + skew; return u >= n_it ? u - n_it : u; };
+  const bool ragged = n_it > 0 && (t_end - t_begin) % KB != 0;
+  const int ragged_seq = ragged ? (n_it - 1 - skew + (n_it - 1 - skew < 0 ? n_it : 0)) : -1;
+  auto prep_stage = [&](int seq) {
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
+    if (t0 + KB > t_end) {
+      T* lbase = smem + (seq % NBUF) * BUF_ELEMS;
+      const int first = (int)(t_end - t0);
+      const int per_slot = (KB - first) * ROW_ELEMS;
+      for (int e = tid; e < ns * per_slot; e += PAIR_THREADS) {
+        const int slot = e / per_slot;
+        const int rem = e - slot * per_slot;
+        const int r = first + rem / ROW_ELEMS, c = rem % ROW_ELEMS;
+        lbase[slot * PANEL_ELEMS + r * ROW_STRIDE + c] = 0;
+      }
+    }
+  };
+  auto issue_stage = [&](int seq) {
+    prep_stage(seq);
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
+#pragma unroll
+    for (int q = 0; q < MAXPPW; ++q) {
+      const int p = wave + 8 * q;
+      const int r = (p % SLOT_PIECES) / RP;
+      const bool row_ok = t0 + r < t_end;
+      const bool lane_ok = !(sizeof(T) == 4 && (p % RP) == 1) || lane < 32;
+      if (p < n_pieces && row_ok && lane_ok) {
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(X + t0 * ld + g_off[q]),
+            (__attribute__((address_space(3))) void*)(smem + (seq % NBUF) * BUF_ELEMS + l_off[q]), 16, 0, 0);
+      }
+    }
+  };
+  // wait until everything but the newest stage's pieces has landed (newest = seq_newest)
+  auto wait_landed = [&](int seq_newest) {
+    if (seq_newest >= n_it || seq_newest == ragged_seq) wait_vmcnt<0>();
+    else wait_vmcnt_dyn<MAXPPW>(my_cnt);
+  };
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = acc_zero<T>();
+
+  const int offA = slotA * PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wm * 64 + (lane & 15));
+  const int offB = slotB * PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wn * 64 + (lane & 15));
+
+  if (n_it > 0) issue_stage(0);
+  if (n_it > 1) issue_stage(1);
+  wait_landed(1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int it = 0; it < n_it; ++it) {
+    if (ABL == 0 && it + AHEAD < n_it) issue_stage(it + AHEAD);
+    const T* pa = smem + (ABL ? it % 2 : it % NBUF) * BUF_ELEMS;
+    if (active) {
+#pragma unroll
+      for (int kk = 0; kk < KB / 4; ++kk) {
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          T a[4], bb[4];
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
+#pragma unroll
+          for (int n = 0; n < 4; ++n) bb[n] = pa[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+#pragma unroll
+          for (int m = 0; m < 4; ++m)
+#pragma unroll
+            for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+        }
+      }
+    }
+    // stage it+1 must have landed before anyone reads it; stage it+2 may stay in flight
+    if (ABL < 2) {
+      wait_landed(it + 2);
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+    }
+  }
+
+  if (!active) return;
+  const int tile_lin = my_i * nt1 - my_i * (my_i - 1) / 2 + (my_j - my_i);
+  T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + m * 16 + M::row(lane, r);
+        const int col = wn * 64 + n * 16 + (lane & 15);
+        slab[row * TILE + col] = acc[m][n][r];
+      }
 }
 
 // ---------------------------------------------------------------------------
@@ -464,8 +766,12 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
+enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2 };
+
 struct GramPlan {
   int32_t n_pad, nt1, n_tiles;
+  int staging;         // GramStaging
+  int32_t n_entries;   // work items per split: n_tiles (unit kernels) or pair entries
   bool direct;         // gram kernel reads F in place
   int ksplit;
   int64_t frames_per_split;
@@ -473,7 +779,8 @@ struct GramPlan {
   size_t slab_bytes, pack_bytes;
 };
 
-static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t max_splits) {
+static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t max_splits,
+                         int units_per_wg = 1) {
   // Minimise a simple time model over the split count k: workgroups run in rounds of `slots`
   // (2 per CU); a workgroup costs its frames plus a fixed prologue/epilogue, and every
   // workgroup writes (and the reducer re-reads) one 128x128 slab.
@@ -483,7 +790,7 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
   if (hi > 1024) hi = 1024;
   const double us_per_frame = 0.64 * 4.0 / kb;     // one LDS stage = 48 MFMAs per wave, 2 waves per SIMD
   const double fixed_frames = 48.0;                // pipeline fill + slab store, in frame units
-  const double slab_us = 2.0 * TILE * TILE * (kb == 4 ? 8 : 4) / 2.0e6;  // write + read at ~2 TB/s
+  const double slab_us = units_per_wg * 2.0 * TILE * TILE * (kb == 4 ? 8 : 4) / 2.0e6;  // write + read at ~2 TB/s
   double best_cost = 1e300;
   int64_t best = 1;
   for (int64_t k = 1; k <= hi; ++k) {
@@ -500,7 +807,18 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
 }
 
 static size_t dtype_size(int dt) { return dt == AGGF_F64 ? 8 : 4; }
-static size_t table_bytes(const GramPlan& p) { return (size_t)round_up((int64_t)p.n_tiles * 4, 256); }
+static size_t table_bytes(const GramPlan& p) { return (size_t)round_up((int64_t)p.n_tiles * 8, 256); }
+
+// fp64: LDS-DMA ring (+4 % over register staging); fp32: register staging is faster (its panel
+// rows are 1.5 DMA pieces, i.e. 8 DMA instructions per wave and stage instead of 6).
+// AGGF_GRAM_STAGING = "pair" | "dma" | "reg" overrides (benchmarks, tests).
+static int choose_staging(int compute_dtype, int nt1) {
+  static const char* force = getenv("AGGF_GRAM_STAGING");
+  int st = compute_dtype == AGGF_F64 ? STAGE_DMA : STAGE_REG;
+  if (force) st = force[0] == 'p' ? STAGE_PAIR : force[0] == 'd' ? STAGE_DMA : STAGE_REG;
+  if (st == STAGE_PAIR && nt1 < 2) st = STAGE_DMA;
+  return st;
+}
 
 static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
                      bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p) {
@@ -508,9 +826,13 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->nt1 = p->n_pad / TILE;
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
   p->direct = !has_groups && (N % TILE == 0) && in_dtype == compute_dtype && aligned;
+  p->staging = choose_staging(compute_dtype, p->nt1);
+  const bool pair = p->staging == STAGE_PAIR;
+  p->n_entries = pair ? pair_entry_count(p->nt1) : p->n_tiles;
+  const int upw = pair ? 2 : 1;
   const int kb = compute_dtype == AGGF_F64 ? GramCfg<double>::KB : GramCfg<float>::KB;
   const size_t cs = dtype_size(compute_dtype);
-  const int slots = 2 * device_cu_count();
+  const int slots = (pair ? 1 : 2) * device_cu_count();
   const size_t slab1 = (size_t)p->n_tiles * TILE * TILE * cs;  // one split
   const size_t row_bytes = (size_t)p->n_pad * 3 * cs;
   if (query) {
@@ -522,7 +844,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
       if (cf > T) cf = T;
       p->chunk_frames = cf > 0 ? cf : 1;
     }
-    p->ksplit = choose_ksplit(p->n_tiles, p->chunk_frames, kb, slots, 1 << 20);
+    p->ksplit = choose_ksplit(p->n_entries, p->chunk_frames, kb, slots, 1 << 20, upw);
     p->slab_bytes = slab1 * p->ksplit;
     p->pack_bytes = p->direct ? 0 : round_up((int64_t)(p->chunk_frames * row_bytes), 256);
     return AGGF_OK;
@@ -547,7 +869,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   avail = avail > 512 ? avail - 512 : 0;  // room for the 256-byte roundings
   const int64_t max_splits = (int64_t)(avail / slab1);
   if (max_splits < 1) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small for one slab set");
-  p->ksplit = choose_ksplit(p->n_tiles, p->chunk_frames, kb, slots, max_splits);
+  p->ksplit = choose_ksplit(p->n_entries, p->chunk_frames, kb, slots, max_splits, upw);
   p->slab_bytes = slab1 * p->ksplit;
   return AGGF_OK;
 }
@@ -561,10 +883,28 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   if (fps < KB) fps = KB;
   const int64_t nblocks = (int64_t)ksplit * p.n_tiles;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
-  // fp64: LDS-DMA ring (+4 % over register staging); fp32: register staging is faster (its panel
-  // rows are 1.5 DMA pieces, i.e. 8 DMA instructions per wave and stage instead of 6)
-  static const char* force = getenv("AGGF_GRAM_STAGING");  // "dma" | "reg" (benchmarks)
-  const bool use_dma = force ? (force[0] == 'd') : (sizeof(T) == 8);
+  if (p.staging == STAGE_PAIR) {
+    const size_t lds = (size_t)PAIR_NBUF * PAIR_SLOTS * KB * ROW_STRIDE * sizeof(T);  // 153.6 KB
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_pair_dma_kernel<T>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+      attr_done = true;
+    }
+    const int64_t nwg = (int64_t)ksplit * p.n_entries;
+    if (nwg > 0x7fffff00LL) return fail(AGGF_ERR_ARG, "gram grid too large");
+    PairEntry* table = reinterpret_cast<PairEntry*>(tile_table);
+    hipLaunchKernelGGL(build_pair_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, table);
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_pair_dma_kernel<T>), dim3((unsigned)round_up(nwg, 256)), dim3(PAIR_THREADS), lds,
+                       stream, X, rows, ld, p.nt1, p.n_entries, ksplit, table, fps, slabs);
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
+                       slabs, p.nt1, ksplit, n_red, accumulate, G);
+    AGGF_LAUNCH_OK();
+    return AGGF_OK;
+  }
+  const bool use_dma = p.staging == STAGE_DMA;
   if (use_dma) {
     const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);  // 3-stage ring, 76.8 KB
     static thread_local bool attr_done = false;
