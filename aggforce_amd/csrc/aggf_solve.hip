@@ -22,15 +22,28 @@ constexpr int GS = GK + 2;      // LDS row stride of GEMM operand tiles (element
 // C[M x N] = alpha * op(A) op(B) + beta * C  (and the same values to C2 if non-null).
 // Row-major; M % 64 == 0, N % 64 == 0, K % 16 == 0.  op(A) is M x K, op(B) is K x N.
 // lower_only: skip tiles strictly above the block diagonal (square trailing updates).
+// blockIdx.z = batch index z: operand X is offset by (z / inner) * x_o + (z % inner) * x_i elements.
+struct GemmBatch {
+  int inner;
+  int64_t a_o, a_i, b_o, b_i, c_o, c_i;
+};
+
 template <bool TA, bool TB>
 __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
                                                         const double* A, int64_t lda,
                                                         const double* B, int64_t ldb,
                                                         double beta, double* C, int64_t ldc,
-                                                        double* C2, int64_t ldc2, int lower_only) {
+                                                        double* C2, int64_t ldc2, int lower_only,
+                                                        GemmBatch bt) {
   using MF = Mfma<double>;
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (lower_only && bj > bi) return;
+  if (gridDim.z > 1) {
+    const int zo = blockIdx.z / bt.inner, zi = blockIdx.z % bt.inner;
+    A += zo * bt.a_o + zi * bt.a_i;
+    B += zo * bt.b_o + zi * bt.b_i;
+    C += zo * bt.c_o + zi * bt.c_i;
+  }
   __shared__ __attribute__((aligned(16))) double sA[2][64 * GS];
   __shared__ __attribute__((aligned(16))) double sB[2][64 * GS];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -124,96 +137,71 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
       }
 }
 
-// Factor one 64x64 diagonal block in LDS: A_kk = L L' (lower), and Linv = L^-1.
+// Factor one 64x64 diagonal block: A_kk = L L' (lower), and Linv = L^-1.
 // info[0]: 1-based global index of the first non-positive pivot (0 = ok).
-__global__ __launch_bounds__(256) void potrf_diag_kernel(double* __restrict__ Akk, int64_t lda,
-                                                         double* __restrict__ Linv,
-                                                         double* __restrict__ info, int pivot_base) {
+//
+// ONE wave, the block in registers: lane i holds row i (64 doubles); the loops are fully unrolled,
+// so every register index is static.  Column j: pivot by v_readlane from lane j, the scaled column
+// goes through a 64-entry LDS buffer and comes back as uniform-address (broadcast) reads for the
+// rank-1 update -- one LDS round trip per column and no multi-wave barrier (the 256-thread LDS
+// version spent ~1.2 us per column, 80 us per block, 5.4 ms of a 12 ms solve at n = 4096; reading
+// the column with v_readlane instead costs two SGPR hazards per element).  The inverse is a forward
+// substitution with lane c holding column c of L^-1 and L[i][k] broadcast from LDS.
+__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+__global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ Akk, int64_t lda,
+                                                        double* __restrict__ Linv,
+                                                        double* __restrict__ info, int pivot_base) {
   __shared__ double a[NB][NB + 1];
-  __shared__ double inv[NB][NB + 1];
-  __shared__ double col[2][NB];   // column j of the trailing matrix, double-buffered by parity of j
-  const int tid = threadIdx.x;
-  // Each thread keeps one 4x4 block of the matrix in registers for the whole factorisation
-  // (16x16 blocks; only blocks on or below the diagonal work).  Per column j: the owners publish
-  // column j through LDS, ONE barrier, everybody scales it by 1/sqrt(pivot) and applies the rank-1
-  // update to its registers.
-  const int bi = tid >> 4, bk = tid & 15;
-  const int i0 = 4 * bi, k0 = 4 * bk;
-  const bool active = bi >= bk;
-  double r[4][4];
+  __shared__ double colbuf[2][NB];
+  const int lane = threadIdx.x;
+  for (int row = 0; row < NB; ++row) a[row][lane] = (lane <= row) ? Akk[(int64_t)row * lda + lane] : 0.0;
+  __syncthreads();
+  double r[NB];
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int k = 0; k < NB; ++k) r[k] = a[lane][k];
+  double rinv = 0.0;  // lane j keeps 1 / L[j][j]
 #pragma unroll
-    for (int y = 0; y < 4; ++y)
-      r[x][y] = (active && k0 + y <= i0 + x) ? Akk[(int64_t)(i0 + x) * lda + k0 + y] : 0.0;
-  for (int e = tid; e < NB * NB; e += 256) inv[e >> 6][e & 63] = 0.0;
   for (int j = 0; j < NB; ++j) {
-    const int jb = j >> 2, jy = j & 3, par = j & 1;
-    if (bk == jb && active) {
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y)
-          if (y == jy) col[par][i0 + x] = r[x][y];
-    }
-    __syncthreads();
-    double d = col[par][j];
+    double d = lane_bcast(r[j], j);
     if (!(d > 0.0)) {
-      if (tid == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + j + 1);
+      if (lane == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + j + 1);
       d = 1.0;
     }
-    const double rs = 1.0 / sqrt(d);
-    if (active) {
-      double li[4], lk[4];
+    // 1/sqrt(d): hardware estimate + two Newton steps (the IEEE divide + sqrt sequence is ~4x longer
+    // and sits on the 64-step dependency chain)
+    double rs = __builtin_amdgcn_rsq(d);
+    double e = fma(-d * rs, rs, 1.0);
+    rs = fma(rs * e, fma(e, 0.375, 0.5), rs);
+    e = fma(-d * rs, rs, 1.0);
+    rs = fma(rs * 0.5, e, rs);
+    r[j] = (lane == j) ? d * rs : r[j] * rs;  // column j of L (rows above the diagonal: unused values)
+    if (lane == j) rinv = rs;
+    colbuf[j & 1][lane] = r[j];
+    __syncthreads();  // one wave: orders the LDS write before the broadcast reads
 #pragma unroll
-      for (int x = 0; x < 4; ++x) li[x] = col[par][i0 + x] * rs;
-#pragma unroll
-      for (int y = 0; y < 4; ++y) lk[y] = col[par][k0 + y] * rs;
-#pragma unroll
-      for (int x = 0; x < 4; ++x)
-#pragma unroll
-        for (int y = 0; y < 4; ++y) {
-          const int i = i0 + x, k = k0 + y;
-          if (k == j && i >= j) r[x][y] = (i == j) ? d * rs : li[x];   // final L[:, j]
-          else if (k > j && i >= k) r[x][y] -= li[x] * lk[y];
-        }
-    }
+    for (int k = j + 1; k < NB; ++k)
+      r[k] = fma(-r[j], colbuf[j & 1][k], r[k]);  // A[i][k] -= L[i][j] L[k][j]; only rows i >= k are ever read
   }
   __syncthreads();
 #pragma unroll
-  for (int x = 0; x < 4; ++x)
+  for (int k = 0; k < NB; ++k) a[lane][k] = (k <= lane) ? r[k] : 0.0;
+  __syncthreads();
+  for (int row = 0; row < NB; ++row)
+    if (lane <= row) Akk[(int64_t)row * lda + lane] = a[row][lane];
+  // X = L^-1 by forward substitution; x[k] of lane c is X[k][c] (zero for k < c by construction)
+  double x[NB];
 #pragma unroll
-    for (int y = 0; y < 4; ++y) a[i0 + x][k0 + y] = (active && k0 + y <= i0 + x) ? r[x][y] : 0.0;
-  __syncthreads();
-  // inverse of the lower-triangular factor by block doubling, all 256 threads:
-  //   [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]],  block size s = 1, 2, ..., 32
-  // (a per-column forward substitution on 64 threads took ~85 us of this kernel's 130 us)
-  if (tid < NB) inv[tid][tid] = 1.0 / a[tid][tid];
-  __syncthreads();
-  for (int s = 1; s < NB; s <<= 1) {
-    const int per_pair = s * s, n_el = (NB / (2 * s)) * per_pair;
-    // T = B A^-1 -> stored in the (still unused) upper triangle's mirror: tmp lives in a's upper part
-    for (int e = tid; e < n_el; e += 256) {
-      const int p = e / per_pair, r = e - p * per_pair, i = r / s, j = r - i * s;
-      const int base = 2 * s * p;
-      double t = 0.0;
-      for (int k = j; k < s; ++k) t += a[base + s + i][base + k] * inv[base + k][base + j];
-      a[base + j][base + s + i] = t;  // T[i][j] kept transposed above the diagonal of this pair
-    }
-    __syncthreads();
-    for (int e = tid; e < n_el; e += 256) {
-      const int p = e / per_pair, r = e - p * per_pair, i = r / s, j = r - i * s;
-      const int base = 2 * s * p;
-      double x = 0.0;
-      for (int k = 0; k <= i; ++k) x += inv[base + s + i][base + s + k] * a[base + j][base + s + k];
-      inv[base + s + i][base + j] = -x;
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int i = e >> 6, j = e & 63;
-    if (j <= i) Akk[(int64_t)i * lda + j] = a[i][j];
-    Linv[e] = inv[i][j];
+  for (int i = 0; i < NB; ++i) {
+    double sum = (lane == i) ? 1.0 : 0.0;
+#pragma unroll
+    for (int k = 0; k < i; ++k) sum = fma(-a[i][k], x[k], sum);
+    x[i] = sum * lane_bcast(rinv, i);
+    Linv[i * NB + lane] = x[i];
   }
 }
 
@@ -360,37 +348,120 @@ static inline dim3 flat_grid(int64_t n) {
 template <bool TA, bool TB>
 static void gemm(Ctx& c, int M, int N, int K, double alpha, const double* A, int64_t lda,
                  const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
-                 double* C2 = nullptr, int64_t ldc2 = 0, int lower_only = 0) {
-  if (c.rc || M <= 0 || N <= 0) return;
-  hipLaunchKernelGGL((gemm64_kernel<TA, TB>), dim3(N / 64, M / 64), dim3(256), 0, c.stream, K, alpha,
-                     A, lda, B, ldb, beta, C, ldc, C2, ldc2, lower_only);
+                 double* C2 = nullptr, int64_t ldc2 = 0, int lower_only = 0, int nbatch = 1,
+                 GemmBatch bt = GemmBatch{1, 0, 0, 0, 0, 0, 0}) {
+  if (c.rc || M <= 0 || N <= 0 || nbatch <= 0) return;
+  hipLaunchKernelGGL((gemm64_kernel<TA, TB>), dim3(N / 64, M / 64, nbatch), dim3(256), 0, c.stream, K, alpha,
+                     A, lda, B, ldb, beta, C, ldc, C2, ldc2, lower_only, bt);
   if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "gemm launch failed");
 }
 
-// in-place lower Cholesky of the npad x npad matrix P (ld = npad); Dinv: npad/64 blocks
-static void cholesky(Ctx& c, double* P, int npad, double* Dinv, double* info, int pivot_base) {
-  const int nb = npad / NB;
-  for (int k = 0; k < nb && !c.rc; ++k) {
-    double* Akk = P + (int64_t)k * NB * npad + (int64_t)k * NB;
-    double* Dk = Dinv + (int64_t)k * NB * NB;
-    hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(256), 0, c.stream, Akk, (int64_t)npad, Dk,
-                       info, pivot_base + k * NB);
-    if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
-    const int rem = npad - (k + 1) * NB;
-    if (rem <= 0) break;
-    double* panel = Akk + (int64_t)NB * npad;  // rows below the diagonal block, same columns
-    // panel <- panel * Linv'  (in place: every workgroup reads exactly the rows it writes)
-    gemm<false, true>(c, rem, NB, NB, 1.0, panel, npad, Dk, NB, 0.0, panel, npad);
-    // trailing <- trailing - panel panel'   (lower tiles only)
-    gemm<false, true>(c, rem, rem, NB, -1.0, panel, npad, panel, npad, 1.0, panel + NB, npad, nullptr, 0, 1);
+// in-place lower Cholesky of the npad x npad matrix P (ld = npad); Dinv: npad/64 blocks.
+// Two-level blocking: 64-wide inner panels (the diagonal block kernel's size) inside 256-wide outer
+// panels.  Inner steps update only the columns of their outer panel; the matrix to the right of it
+// is updated once per outer panel with K = 256, so the trailing matrix -- the n^3/3 part -- is read
+// and written 4x less often than with K = 64 updates (those ran at ~4 TF, bound by the C traffic).
+constexpr int OUTER_PANELS = 4;
+constexpr int BIG = OUTER_PANELS * NB;  // 256: edge of the inverted diagonal blocks used by the solves
+
+// elements of the "Dinv" workspace of an npad x npad factor: [npad/64 inverses of 64x64 diagonal
+// blocks | npad/256 inverses of 256x256 diagonal blocks | scratch for building them]
+static size_t dinv_elems(int npad) {
+  return (size_t)npad * NB + (size_t)(npad / BIG) * BIG * BIG + (size_t)(npad / BIG + 1) * (BIG / 2) * (BIG / 2);
+}
+static inline double* dbig_of(double* Dinv, int npad) { return Dinv + (size_t)npad * NB; }
+static inline const double* dbig_of(const double* Dinv, int npad) { return Dinv + (size_t)npad * NB; }
+
+// Dbig[ob] (256x256) <- block diagonal of the four 64x64 inverses of outer block ob, zeros elsewhere
+__global__ __launch_bounds__(256) void dbig_init_kernel(const double* __restrict__ Dinv, double* __restrict__ Dbig,
+                                                        int nbig) {
+  const int64_t total = (int64_t)nbig * BIG * BIG;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int ob = (int)(e / (BIG * BIG)), r = (int)(e % (BIG * BIG)), i = r / BIG, j = r % BIG;
+    Dbig[e] = (i / NB == j / NB) ? Dinv[((int64_t)(ob * OUTER_PANELS + i / NB) * NB + i % NB) * NB + j % NB] : 0.0;
   }
 }
 
-// Y = L^-1 Bw ; Bw (npad x w, ld = w) is consumed
+// Inverses of the 256x256 diagonal blocks of L by block doubling,
+//   [[A,0],[B,C]]^-1 = [[A^-1,0],[-C^-1 B A^-1, C^-1]],
+// 64 -> 128 -> 256, every level two batched GEMMs over all blocks.  With them a triangular solve
+// takes npad/256 steps of K = 256 GEMMs instead of npad/64 steps of K = 64 (those were bound by
+// the ~128 dependent launches per solve, not by their flops).
+static void build_big_inverses(Ctx& c, const double* L, int npad, double* Dinv) {
+  const int nbig = npad / BIG;
+  if (nbig <= 0 || c.rc) return;
+  double* Dbig = dbig_of(Dinv, npad);
+  double* T = Dbig + (size_t)nbig * BIG * BIG;
+  hipLaunchKernelGGL(dbig_init_kernel, flat_grid((int64_t)nbig * BIG * BIG), dim3(256), 0, c.stream, Dinv, Dbig, nbig);
+  if (hipGetLastError() != hipSuccess) { c.rc = fail(AGGF_ERR_HIP, "dbig_init launch failed"); return; }
+  const int64_t l_o = (int64_t)BIG * npad + BIG, d_o = (int64_t)BIG * BIG, t_o = (int64_t)(BIG / 2) * (BIG / 2);
+  // level 1: pairs of 64-blocks (p = 0, 1) inside every outer block
+  {
+    const int64_t l_i = (int64_t)2 * NB * npad + 2 * NB, d_i = (int64_t)2 * NB * BIG + 2 * NB;
+    // T = B Ainv
+    gemm<false, false>(c, NB, NB, NB, 1.0, L + (int64_t)NB * npad, npad, Dbig, BIG, 0.0, T, NB, nullptr, 0, 0,
+                       2 * nbig, GemmBatch{2, l_o, l_i, d_o, d_i, t_o, (int64_t)NB * NB});
+    // X = -Cinv T
+    gemm<false, false>(c, NB, NB, NB, -1.0, Dbig + (int64_t)NB * BIG + NB, BIG, T, NB, 0.0, Dbig + (int64_t)NB * BIG, BIG,
+                       nullptr, 0, 0, 2 * nbig, GemmBatch{2, d_o, d_i, t_o, (int64_t)NB * NB, d_o, d_i});
+  }
+  // level 2: the two 128-blocks of every outer block
+  {
+    const int H = BIG / 2;
+    gemm<false, false>(c, H, H, H, 1.0, L + (int64_t)H * npad, npad, Dbig, BIG, 0.0, T, H, nullptr, 0, 0, nbig,
+                       GemmBatch{1, l_o, 0, d_o, 0, t_o, 0});
+    gemm<false, false>(c, H, H, H, -1.0, Dbig + (int64_t)H * BIG + H, BIG, T, H, 0.0, Dbig + (int64_t)H * BIG, BIG,
+                       nullptr, 0, 0, nbig, GemmBatch{1, d_o, 0, t_o, 0, d_o, 0});
+  }
+}
+
+static void cholesky(Ctx& c, double* P, int npad, double* Dinv, double* info, int pivot_base) {
+  const int nb = npad / NB;
+  for (int k0 = 0; k0 < nb && !c.rc; k0 += OUTER_PANELS) {
+    const int kend = k0 + OUTER_PANELS < nb ? k0 + OUTER_PANELS : nb;
+    for (int k = k0; k < kend && !c.rc; ++k) {
+      double* Akk = P + (int64_t)k * NB * npad + (int64_t)k * NB;
+      double* Dk = Dinv + (int64_t)k * NB * NB;
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, c.stream, Akk, (int64_t)npad, Dk,
+                         info, pivot_base + k * NB);
+      if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
+      const int rem = npad - (k + 1) * NB;
+      if (rem <= 0) break;
+      double* panel = Akk + (int64_t)NB * npad;  // rows below the diagonal block, same columns
+      // panel <- panel * Linv'  (in place: every workgroup reads exactly the rows it writes)
+      gemm<false, true>(c, rem, NB, NB, 1.0, panel, npad, Dk, NB, 0.0, panel, npad);
+      // remaining columns of this outer panel <- themselves - panel panel'   (lower tiles only)
+      const int inner_cols = (kend - 1 - k) * NB;
+      if (inner_cols > 0)
+        gemm<false, true>(c, rem, inner_cols, NB, -1.0, panel, npad, panel, npad, 1.0, panel + NB, npad, nullptr, 0, 1);
+    }
+    const int rem2 = npad - kend * NB;
+    if (rem2 > 0) {
+      // trailing <- trailing - L21 L21' with all columns of the outer panel at once
+      const int kw = (kend - k0) * NB;
+      const double* L21 = P + (int64_t)kend * NB * npad + (int64_t)k0 * NB;
+      double* A22 = P + (int64_t)kend * NB * npad + (int64_t)kend * NB;
+      gemm<false, true>(c, rem2, rem2, kw, -1.0, L21, npad, L21, npad, 1.0, A22, npad, nullptr, 0, 1);
+    }
+  }
+  build_big_inverses(c, P, npad, Dinv);
+}
+
+// Y = L^-1 Bw ; Bw (npad x w, ld = w) is consumed.  Full 256-row blocks use their inverted diagonal
+// block, the (< 256 rows) remainder the 64x64 inverses.
 static void solve_lower(Ctx& c, const double* L, int npad, const double* Dinv, double* Bw, double* Y,
                         int w) {
-  const int nb = npad / NB;
-  for (int k = 0; k < nb && !c.rc; ++k) {
+  const int nb = npad / NB, nbig = npad / BIG;
+  const double* Dbig = dbig_of(Dinv, npad);
+  for (int ob = 0; ob < nbig && !c.rc; ++ob) {
+    const int64_t r0 = (int64_t)ob * BIG;
+    gemm<false, false>(c, BIG, w, BIG, 1.0, Dbig + (int64_t)ob * BIG * BIG, BIG, Bw + r0 * w, w, 0.0, Y + r0 * w, w);
+    const int rem = npad - (int)(r0 + BIG);
+    if (rem > 0)
+      gemm<false, false>(c, rem, w, BIG, -1.0, L + (r0 + BIG) * npad + r0, npad, Y + r0 * w, w, 1.0,
+                         Bw + (r0 + BIG) * w, w);
+  }
+  for (int k = nbig * OUTER_PANELS; k < nb && !c.rc; ++k) {
     const double* Dk = Dinv + (int64_t)k * NB * NB;
     gemm<false, false>(c, NB, w, NB, 1.0, Dk, NB, Bw + (int64_t)k * NB * w, w, 0.0,
                        Y + (int64_t)k * NB * w, w);
@@ -404,14 +475,21 @@ static void solve_lower(Ctx& c, const double* L, int npad, const double* Dinv, d
 // X = L^-T Zw ; Zw (npad x w) is consumed
 static void solve_lower_t(Ctx& c, const double* L, int npad, const double* Dinv, double* Zw, double* X,
                           int w) {
-  const int nb = npad / NB;
-  for (int k = nb - 1; k >= 0 && !c.rc; --k) {
+  const int nb = npad / NB, nbig = npad / BIG;
+  const double* Dbig = dbig_of(Dinv, npad);
+  for (int k = nb - 1; k >= nbig * OUTER_PANELS && !c.rc; --k) {
     const double* Dk = Dinv + (int64_t)k * NB * NB;
     gemm<true, false>(c, NB, w, NB, 1.0, Dk, NB, Zw + (int64_t)k * NB * w, w, 0.0,
                       X + (int64_t)k * NB * w, w);
     if (k > 0)  // Zw[0:k] -= L[k, 0:k]' X_k
       gemm<true, false>(c, k * NB, w, NB, -1.0, L + (int64_t)k * NB * npad, npad,
                         X + (int64_t)k * NB * w, w, 1.0, Zw, w);
+  }
+  for (int ob = nbig - 1; ob >= 0 && !c.rc; --ob) {
+    const int64_t r0 = (int64_t)ob * BIG;
+    gemm<true, false>(c, BIG, w, BIG, 1.0, Dbig + (int64_t)ob * BIG * BIG, BIG, Zw + r0 * w, w, 0.0, X + r0 * w, w);
+    if (r0 > 0)  // Zw[0:r0] -= L[r0:r0+256, 0:r0]' X_ob
+      gemm<true, false>(c, (int)r0, w, BIG, -1.0, L + r0 * npad, npad, X + r0 * w, w, 1.0, Zw, w);
   }
 }
 
@@ -434,12 +512,12 @@ static SolveLayout solve_layout(int n, int m, int nrhs) {
   };
   const size_t wmax = (size_t)(l.mpad > l.rpad ? l.mpad : l.rpad);
   l.off_Pt = take((size_t)l.npad * l.npad);
-  l.off_Dinv = take((size_t)l.npad * NB);
+  l.off_Dinv = take(dinv_elems(l.npad));
   l.off_Ap = take((size_t)l.mpad * l.npad);
   l.off_Y = take((size_t)l.npad * l.mpad);
   l.off_Bw = take((size_t)(l.npad > l.mpad ? l.npad : l.mpad) * wmax);
   l.off_S = take((size_t)l.mpad * l.mpad);
-  l.off_DinvS = take((size_t)l.mpad * NB);
+  l.off_DinvS = take(dinv_elems(l.mpad));
   l.off_Bp = take((size_t)l.mpad * l.rpad);
   l.off_T1 = take((size_t)l.mpad * l.rpad);
   l.off_T2 = take((size_t)l.mpad * l.rpad);
