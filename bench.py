@@ -238,7 +238,7 @@ def main():
                 "residual": out["residual"],
             },
             "roofline": {
-                "kernel": "gram_tile_kernel (+ slab reduce) = aggf_gram",
+                "kernel": "gram_tile_dma_kernel<double> (+ slab reduce) = aggf_gram" if dt == "f64" else "gram_tile_kernel<float> (+ slab reduce) = aggf_gram",
                 "bound": "mfma",
                 "achieved": achieved,
                 "peak": PEAK_TFLOPS[dt],
