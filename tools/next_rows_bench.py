@@ -1,0 +1,106 @@
+"""GPU box: one measured number for every SURVEY 8(f) row that is built (JSON lines on stdout).
+
+  cv      project_forces_grid_cv, 5 folds x 4 l2 values: one-pass Gram reuse vs the reference-style loop
+  staged  stagedjoptgauss_map fit + application at the C5 size
+  k6      guess_pairwise_constraints' pair-distance statistics kernel
+  stream  out-of-core project_forces_streamed from memory-mapped .npy files
+"""
+import json
+import os
+import sys
+import tempfile
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from aggforce_amd import LinearMap, Trajectory, stagedjoptgauss_map  # noqa: E402
+from aggforce_amd import _kernels as K  # noqa: E402
+from aggforce_amd.agg import project_forces_grid_cv  # noqa: E402
+from aggforce_amd.stream import load_trajectory, project_forces_streamed  # noqa: E402
+
+
+def sync():
+    torch.cuda.synchronize()
+    return time.perf_counter()
+
+
+def emit(**kw):
+    print(json.dumps(kw), flush=True)
+
+
+def bench_cv():
+    T, N, n_cg = 500_000, 2048, 128
+    forces = K.synth_normal(T, N, torch.float32, 1, sigma=30.0)
+    coords = K.synth_normal(T, N, torch.float32, 2, sigma=0.3, lattice=1.5)
+    cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
+    grid = {"l2_regularization": [0.0, 1e-3, 1e-1, 10.0]}
+    res = {}
+    for name, reuse in (("one_pass", True), ("loop", False)):
+        for rep in range(2):
+            t0 = sync()
+            r = project_forces_grid_cv(grid, coords, forces, n_folds=5, rng=np.random.default_rng(0),
+                                       coord_map=cmap, constrained_inds=None, reuse_gram=reuse)
+            res[name] = (sync() - t0, r)
+    a, b = res["one_pass"][1]["scores"], res["loop"][1]["scores"]
+    worst = max(abs(a[k] - b[k]) / abs(b[k]) for k in a)
+    emit(row="cv", workload=f"{T} x {N} x {n_cg} fp32, 5 folds x 4 l2 values", one_pass_s=res["one_pass"][0],
+         loop_s=res["loop"][0], speedup=res["loop"][0] / res["one_pass"][0], max_rel_score_diff=worst)
+
+
+def bench_staged():
+    T, N, n_cg = 500_000, 2048, 128
+    forces = K.synth_normal(T, N, torch.float32, 3, sigma=30.0)
+    coords = K.synth_normal(T, N, torch.float32, 4, sigma=0.3, lattice=1.5)
+    cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
+    traj = Trajectory(coords=coords, forces=forces)
+    for rep in range(2):
+        t0 = sync()
+        tm = stagedjoptgauss_map(traj, cmap, var=0.05, kbt=0.6, seed=7)
+        t1 = sync()
+        mapped = tm(traj)
+        t2 = sync()
+    emit(row="staged", workload=f"stagedjoptgauss_map, {T} x {N} x {n_cg} fp32", fit_s=t1 - t0, apply_s=t2 - t1,
+         frames_per_s=T / (t2 - t0), mapped_shape=list(mapped.forces.shape))
+
+
+def bench_k6():
+    T, N = 2000, 4096
+    x = K.synth_normal(T, N, torch.float32, 5, sigma=0.3, lattice=1.5)
+    for rep in range(3):
+        t0 = sync()
+        K.pair_dist_var(x)
+        dt = sync() - t0
+    emit(row="k6", workload=f"pair-distance variance, {T} frames x {N} atoms", seconds=dt,
+         pair_distances_per_s=T * N * (N - 1) / 2 / dt)
+
+
+def bench_stream():
+    T, N, n_cg = 200_000, 1024, 64
+    rng = np.random.default_rng(0)
+    with tempfile.TemporaryDirectory(dir="/tmp") as d:
+        prefix = os.path.join(d, "run")
+        for name, scale in (("coords", 0.3), ("forces", 30.0)):
+            mm = np.lib.format.open_memmap(f"{prefix}_{name}.npy", mode="w+", dtype=np.float32, shape=(T, N, 3))
+            for b in range(0, T, 20000):
+                mm[b:b + 20000] = rng.standard_normal((min(20000, T - b), N, 3), dtype=np.float32) * scale
+            mm.flush()
+            del mm
+        coords, forces = load_trajectory(prefix)
+        cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
+        project_forces_streamed(coords[:2000], forces[:2000], cmap, None)
+        for rep in range(2):
+            t0 = time.perf_counter()
+            project_forces_streamed(coords, forces, cmap, None)
+            dt = time.perf_counter() - t0
+    gb = 3 * T * N * 3 * 4 / 1e9
+    emit(row="stream", workload=f"project_forces_streamed, {T} x {N} x {n_cg} fp32 from memory-mapped .npy",
+         seconds=dt, host_to_device_GB_per_s=gb / dt, frames_per_s=T / dt)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["cv", "staged", "k6", "stream"]
+    for w in which:
+        {"cv": bench_cv, "staged": bench_staged, "k6": bench_k6, "stream": bench_stream}[w]()
+        torch.cuda.empty_cache()
