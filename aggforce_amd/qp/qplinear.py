@@ -69,6 +69,13 @@ def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndar
             f"(pivot {int(st[0])}, constraint residual {st[1]:.3e}). "
             "The problem is under-determined; add frames or use l2_regularization > 0."
         )
+    if st[1] > 1e-8:
+        # e.g. two CG sites whose atoms were merged into one constraint group: (M C) x = e_i has no
+        # solution (the reference's solver returns None there and the map assembly fails)
+        raise ValueError(
+            f"{what} failed: the equality constraints cannot be met (residual {st[1]:.3e}); "
+            "the coordinate map is rank deficient once constrained atoms share a coefficient."
+        )
     return X, st
 
 

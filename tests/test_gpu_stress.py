@@ -1,0 +1,37 @@
+"""GPU parity: seeded random sweep of project_forces (linear path) against the oracle -- random sizes,
+mapping kinds, constraint sets, dtypes, regularisation; infeasible problems must be refused."""
+import importlib.util
+import os
+import sys
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load_tool():
+    spec = importlib.util.spec_from_file_location("stress_parity", os.path.join(ROOT, "tools", "stress_parity.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+@pytest.mark.parametrize("seed", [11, 12])
+def test_random_sweep_matches_oracle(seed, monkeypatch, capsys):
+    sp = _load_tool()
+    monkeypatch.setattr(sys, "argv", ["stress_parity.py", "30", str(seed)])
+    sp.main()  # exits non-zero (SystemExit) on the first mismatch
+    assert "30 cases ok" in capsys.readouterr().out
+
+
+def test_infeasible_constraints_are_refused():
+    from aggforce_amd import LinearMap, project_forces
+
+    rng = np.random.default_rng(0)
+    f = rng.normal(size=(60, 8, 3))
+    # two CG sites inside one rigid group share a coefficient: (M C) x = e_i cannot hold for both
+    with pytest.raises(ValueError, match="cannot be met|not positive definite"):
+        project_forces(f, f, LinearMap([[0], [1]], n_fg_sites=8), {frozenset([0, 1])}, l2_regularization=0.1)

@@ -144,6 +144,22 @@ int main() {
     });
   }
   printf("flops per launch (executed) %.3e; 2 launches per line\n", flops);
+  // row stride: 4096 atoms x 24 B = 96 KiB is a power-of-two multiple of the cache line; does the
+  // L2 alias?  Same kernel on the first 4096 atoms of rows that are 16 / 5 / 1 atoms longer.
+  for (int extra : {16, 80, 1040}) {
+    T* Xp;
+    const int64_t ldp = (int64_t)(n_pad + extra) * 3;
+    if (hipMalloc(&Xp, (size_t)rows * ldp * sizeof(T)) != hipSuccess) break;
+    aggf_synth_normal(Xp, rows, n_pad + extra, AGGF_F64, 1, 0, 0.0, 30.0, 0.0, nullptr);
+    hipDeviceSynchronize();
+    char name[64];
+    snprintf(name, sizeof name, "dma full, row stride +%d atoms", extra);
+    with_probe(name, 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(GRAM_THREADS), lds_dma, s, Xp, rows, ldp, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
+    hipFree(Xp);
+  }
   // tile length sweep: shorter frame ranges per workgroup = less time for the workgroups that share
   // panels in an XCD's L2 to drift apart
   hipFree(slabs);

@@ -1,0 +1,116 @@
+"""GPU box: randomized parity sweep of project_forces (linear path) against the oracle.
+
+Random frame counts, atom counts, mapping kinds (slice, centre-of-mass-like, overlapping), constraint
+sets (pairs, chains, larger groups), dtypes and regularisation.  Prints the worst relative errors;
+exits non-zero on the first mismatch (test infrastructure: uses oracle/).
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+
+from aggforce_amd import LinearMap, project_forces  # noqa: E402
+from oracle import aggforce_oracle as orc  # noqa: E402
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def random_case(rng):
+    N = int(rng.integers(2, 400))
+    n_cg = int(rng.integers(1, min(N, 70) + 1))
+    dt = rng.choice([np.float32, np.float64])
+    # frames: enough for a well-posed problem most of the time, sometimes few (then l2 > 0)
+    few = rng.random() < 0.25
+    T = int(rng.integers(1, 6)) if few else int(rng.integers(max(4, N // 2), 2 * N + 40))
+    kind = rng.choice(["slice", "blocks", "overlap"])
+    if kind == "slice":
+        sel = rng.choice(N, size=n_cg, replace=False)
+        mapping = [[int(i)] for i in sel]
+    elif kind == "blocks":
+        edges = np.sort(rng.choice(np.arange(1, N), size=n_cg - 1, replace=False)) if n_cg > 1 else np.array([], int)
+        parts = np.split(np.arange(N), edges)
+        mapping = [[int(i) for i in p] for p in parts]
+    else:
+        mapping = [[int(i) for i in rng.choice(N, size=int(rng.integers(1, min(N, 6) + 1)), replace=False)]
+                   for _ in range(n_cg)]
+    cmap = LinearMap(mapping, n_fg_sites=N)
+    if np.linalg.matrix_rank(cmap.standard_matrix) < n_cg:
+        return None
+    cons = set()
+    n_cons = int(rng.integers(0, max(1, N // 3)))
+    for _ in range(n_cons):
+        size = int(rng.choice([2, 2, 2, 3, 5]))
+        if size <= N:
+            cons.add(frozenset(int(i) for i in rng.choice(N, size=size, replace=False)))
+    # the reduced constraint matrix (M C) must keep full row rank, or the QP is infeasible
+    A = orc.linear_problem(np.zeros((1, N, 3)), cmap.standard_matrix, cons)["A"]
+    if np.linalg.matrix_rank(A) < n_cg:
+        return dict(infeasible=True, N=N, cmap=cmap, cons=cons)
+    l2 = float(rng.choice([0.0, 1e-6, 1e-2, 3.0])) if not few else float(rng.choice([1e-2, 3.0]))
+    coords = rng.normal(size=(T, N, 3)).astype(dt)
+    forces = (rng.normal(size=(T, N, 3)) * 20).astype(dt)
+    return dict(T=T, N=N, n_cg=n_cg, dt=dt, kind=kind, cmap=cmap, cons=cons, l2=l2, coords=coords, forces=forces)
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 120
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = {"W": 0.0, "mf": 0.0, "mc": 0.0, "res": 0.0}
+    done = skipped = infeasible_ok = 0
+    while done < n_cases:
+        c = random_case(rng)
+        if c is None:
+            continue
+        if c.get("infeasible"):
+            # the product must refuse (ValueError), never return a map
+            f = rng.normal(size=(2 * c["N"], c["N"], 3))
+            try:
+                project_forces(f, f, c["cmap"], c["cons"], l2_regularization=0.1)
+            except ValueError:
+                infeasible_ok += 1
+                continue
+            print("INFEASIBLE CASE ACCEPTED: N", c["N"], "cons", len(c["cons"]))
+            sys.exit(1)
+        desc = f"T={c['T']} N={c['N']} n_cg={c['n_cg']} {c['dt'].__name__} {c['kind']} cons={len(c['cons'])} l2={c['l2']}"
+        try:
+            ref = orc.project_forces(c["coords"], c["forces"], c["cmap"].standard_matrix, c["cons"], c["l2"])
+        except Exception as e:  # singular reference problem: the product must refuse too
+            try:
+                project_forces(c["coords"], c["forces"], c["cmap"], c["cons"], l2_regularization=c["l2"], gram_dtype=np.float64)
+            except ValueError:
+                skipped += 1
+                continue
+            print("oracle failed but product succeeded:", desc, repr(e)[:100])
+            skipped += 1
+            continue
+        cond_guard = np.linalg.cond(ref["force_map"]) if False else 0
+        try:
+            out = project_forces(c["coords"], c["forces"], c["cmap"], c["cons"], l2_regularization=c["l2"],
+                                 gram_dtype=np.float64)
+        except ValueError as e:
+            print("product refused a case the oracle solved:", desc, str(e)[:120])
+            skipped += 1
+            continue
+        W = out["tmap"].force_map.standard_matrix
+        e = {"W": rel(W, ref["force_map"]), "mf": rel(out["mapped_forces"], ref["mapped_forces"]),
+             "mc": rel(out["mapped_coords"], ref["mapped_coords"]),
+             "res": abs(out["residual"] - ref["residual"]) / max(1e-300, abs(ref["residual"]))}
+        # ill-conditioned cases (few frames, tiny l2) legitimately lose digits in W; the mapped forces
+        # (what the optimisation pins down) must agree
+        tol_mf = 2e-4 if c["dt"] == np.float32 else 1e-6
+        if e["mf"] > tol_mf or e["mc"] > 1e-5 or e["res"] > 10 * tol_mf:
+            print("MISMATCH", desc, e)
+            sys.exit(1)
+        for k in worst:
+            worst[k] = max(worst[k], e[k])
+        done += 1
+    print(f"{done} cases ok ({skipped} skipped, {infeasible_ok} infeasible problems correctly refused); "
+          f"worst relative errors: {worst}")
+
+
+if __name__ == "__main__":
+    main()
