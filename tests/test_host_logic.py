@@ -209,3 +209,38 @@ def test_load_trajectory_npz_and_npy(tmp_path):
     mc, mf = load_trajectory(str(tmp_path / "x"))
     assert isinstance(mc, np.memmap) and np.array_equal(mf, f)
     assert default_chunk_frames(4096, 8) == (8 << 30) // (4 * 4096 * 24)
+
+
+def test_grid_cv_gram_reuse_applicability():
+    """Which project_forces_grid_cv calls may take the one-pass Gram-reuse form (host logic only)."""
+    from aggforce_amd import LinearMap, qp_linear_map
+    from aggforce_amd.agg import _gram_reuse_applicable, process_cvargs
+    from aggforce_amd.qp import constraint_aware_uni_map
+
+    cmap = LinearMap([[0], [2]], n_fg_sites=4)
+    base = dict(coord_map=cmap, constrained_inds=None)
+    assert _gram_reuse_applicable(["l2_regularization"], base)
+    assert _gram_reuse_applicable([], dict(base, l2_regularization=1.0, method=qp_linear_map))
+    assert not _gram_reuse_applicable(["l2_regularization"], dict(base, constrained_inds="auto"))
+    assert not _gram_reuse_applicable(["l2_regularization"], dict(coord_map=cmap))  # default is "auto"
+    assert not _gram_reuse_applicable(["l2_regularization"], dict(base, method=constraint_aware_uni_map))
+    assert not _gram_reuse_applicable(["var"], base)
+    assert not _gram_reuse_applicable(["l2_regularization"], dict(base, kbt=1.0))
+    grid = process_cvargs({"l2_regularization": [0.0, 1.0], "x": ["a"]})
+    assert [g[1] for g in grid] == [{"l2_regularization": 0.0, "x": "a"}, {"l2_regularization": 1.0, "x": "a"}]
+    assert grid[0][0].l2_regularization == 0.0 and grid[1][0].x == "a"
+
+
+def test_staged_map_signatures_match_reference_names():
+    import inspect
+
+    import aggforce_amd as pkg
+
+    sig = inspect.signature(pkg.stagedjoptgauss_map)
+    for name in ("traj", "coord_map", "var", "kbt", "force_map", "constraints", "seed",
+                 "premap_l2_regularization", "premap_solver_args"):
+        assert name in sig.parameters
+    sig = inspect.signature(pkg.stagedjforcegauss_map)
+    assert sig.parameters["contribution_tolerance"].default == 1e-6
+    sig = inspect.signature(pkg.stagedjslicegauss_map)
+    assert sig.parameters["warn_input_forces"].default is True
