@@ -38,6 +38,13 @@ WORKLOADS = {
     "c4": (20_000, 1024, 64, "f32"),       # configs[3]: featurised id_feat + gb_feat (n_basis 8, cutoff 8)
     "c5": (500_000, 2048, 128, "f32"),     # configs[4]: joptgauss_map, var 0.01 (4 GPUs in BASELINE)
 }
+METHOD_LABEL = {
+    "c3": "linear qp_linear_map, no constraints",
+    "c2": "linear qp_linear_map, no constraints",
+    "tiny": "linear qp_linear_map, no constraints",
+    "c4": "featurised qp_feat_linear_map (id_feat + gb_feat, n_basis 8), bond-pair constraints, fp64 Gram products",
+    "c5": "noised joptgauss_map (var 0.01), no constraints",
+}
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (MI355X_MICROARCH.md / SURVEY 8(d))
 SEED = 42100
 
@@ -218,6 +225,7 @@ def main():
             n_gram = N + n_cg
         flops = 3.0 * T_local * n_gram * (n_gram + 1)  # SYRK, upper triangle, per launch
         achieved = flops / (gram_ms * 1e-3) / 1e12
+        gdt = "f64" if args.workload == "c4" else dt  # arithmetic type of the Gram products
         line = {
             "metric": "frames/sec through project_forces (Gram+solve), 1e6x4096-atom traj, 1/2/4/8 GPU",
             "value": T_total * args.steps / elapsed,
@@ -232,20 +240,20 @@ def main():
             "dtype": dt,
             "data": "synthetic",
             "config": {
-                "workload": (f"{args.workload}: {T_total} frames x {N} atoms x {n_cg} CG beads, linear qp_linear_map, "
-                             f"{dt}, slice coord map, no constraints, frames sharded over {world} GPU(s)"),
+                "workload": (f"{args.workload}: {T_total} frames x {N} atoms x {n_cg} CG beads, {METHOD_LABEL[args.workload]}, "
+                             f"{dt} trajectory, slice coord map, frames sharded over {world} GPU(s)"),
                 "frames_per_gpu": T_local,
                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
                 "constraint_residual": cons_resid,
                 "residual": out["residual"],
             },
             "roofline": {
-                "kernel": "gram_tile_dma_kernel<double> (+ slab reduce) = aggf_gram" if dt == "f64" else "gram_tile_kernel<float> (+ slab reduce) = aggf_gram",
+                "kernel": "gram_tile_dma_kernel<double> (+ slab reduce) = aggf_gram" if gdt == "f64" else "gram_tile_kernel<float> (+ slab reduce) = aggf_gram",
                 "bound": "mfma",
                 "achieved": achieved,
-                "peak": PEAK_TFLOPS[dt],
+                "peak": PEAK_TFLOPS[gdt],
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS[dt],
+                "frac": achieved / PEAK_TFLOPS[gdt],
                 "traffic": profiled_traffic(args.workload, world),
                 "ms_per_launch": gram_ms,
                 "flops_per_launch": flops,
