@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import F32, F64, check, dtype_code, lib, ptr, stream_ptr, workspace
+from ._lib import check, dtype_code, lib, ptr, stream_ptr, workspace
 
 _TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
 _NP_OF = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64)}

@@ -6,7 +6,7 @@ single all-reduce (RCCL over xGMI through ``torch.distributed`` backend "nccl"; 
 CPU tensors in the unit tests), and every rank then runs the identical, replicated solve
 (K2) -- no broadcast is needed -- and maps its own frames (K3).
 """
-from typing import Optional, Tuple
+from typing import Tuple
 
 import torch
 

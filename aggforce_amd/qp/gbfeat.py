@@ -24,7 +24,6 @@ last-labelled constraint group gets no Gaussian features (Quirk A). 
 are numbered by smallest member (``constraint_group_labels``); the reference's order is
 CPython's set order, an arbitrary permutation.
 """
-from functools import partial
 from typing import List, Optional, Tuple
 
 import numpy as np
@@ -33,7 +32,6 @@ from .. import _kernels as K
 from ..constraints import Constraints
 from ..distributed import all_reduce_sum_
 from ..map import CLAFTMap, CLAMap, LinearMap
-from ..util import Curry
 from .featlinearmap import KNAME_DIVS, KNAME_FEATS, KNAME_NAMES, constraint_group_labels, id_feat
 
 DIVMETHOD_REORDER = "reorder"

@@ -7,14 +7,13 @@ the GPU (K1, MFMA SYRK fused with the constraint-group sums), optionally summed 
 frame-sharded ranks with one all-reduce, and all n_cg problems are solved exactly by one
 on-device factorisation (K2).
 """
-from typing import Optional, Union
+from typing import Union
 
 import numpy as np
 from typing_extensions import TypedDict
 
 from .. import _kernels as K
-from ..constraints import Constraints, group_layout, groups_csr, reduce_constraint_sets
-from ..constraints.tools import constraint_lookup_dict
+from ..constraints import Constraints, group_layout, groups_csr
 from ..distributed import all_reduce_sum_
 from ..map import LinearMap, SeperableTMap
 from ..trajectory import ForcesTrajectory

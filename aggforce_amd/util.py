@@ -4,7 +4,7 @@
 it runs on the GPU (K3, ``aggf_linearmap_apply``).  ``Curry``/``curry`` bind featuriser
 options exactly like the reference's helpers (util.py:146-252).
 """
-from typing import Any, Callable, Generic, Iterable, List, TypeVar, Union
+from typing import Any, Callable, Generic, Iterable, List, TypeVar
 
 import numpy as np
 

@@ -15,7 +15,6 @@ CLN025 saved force matrices).
     python oracle/gen_golden.py
 """
 import os
-import re
 import sys
 
 sys.dont_write_bytecode = True
