@@ -115,8 +115,10 @@ _ws_cache: dict = {}
 
 
 def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
-    """A cached uint8 scratch tensor of at least nbytes (256-byte aligned by the allocator)."""
-    key = (str(device), tag)
+    """A cached uint8 scratch tensor of at least nbytes (256-byte aligned by the allocator).
+
+    One buffer per (device, tag, current stream): calls issued on different streams never share scratch."""
+    key = (str(device), tag, torch.cuda.current_stream(device).cuda_stream)
     w = _ws_cache.get(key)
     if w is None or w.numel() < nbytes:
         _ws_cache.pop(key, None)

@@ -162,6 +162,10 @@ def recognise(featurizers) -> Optional[Tuple[bool, Optional[dict]]]:
     return None
 
 
+_SOLVE_STREAMS = 4  # side streams for the per-site solves (the hardware exposes a few concurrent queues)
+_SOLVE_CHUNK = 8    # sites per chunk: one (n_feat, n_feat) float64 Gram each is kept until its solve has run
+
+
 def fit_id_gb(
     traj,
     coord_map: LinearMap,
@@ -200,9 +204,16 @@ def fit_id_gb(
     Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).to(geo.dev)  # (n_cg, G) float64
     n_cg = coord_map.n_cg_sites
     gen = np.random.default_rng() if rng is None else rng
-    coefs: List[np.ndarray] = []
+    coefs: List[np.ndarray] = [None] * n_cg  # type: ignore [list-item]
     used: List[np.ndarray] = []
-    for site in range(n_cg):
+    # The per-site solve (K2) is a chain of small dependent kernels that leaves most of the GPU idle,
+    # while the per-site Gram (K1) fills it (and, once running, keeps later queues waiting).  Sites are
+    # therefore processed in chunks: all Grams of a chunk on the main stream, then the solves of the
+    # chunk side by side on a few streams.
+    main = torch.cuda.current_stream(geo.dev)
+    side = [torch.cuda.Stream(device=geo.dev) for _ in range(_SOLVE_STREAMS)]
+
+    def prepare(site: int):
         K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
         # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
         # exceeds l2 = 10 relative to force-squared sums of ~1e8 and P is no longer numerically positive
@@ -224,15 +235,33 @@ def fit_id_gb(
                 S, n_cg, n_ch * n_basis)
         b = torch.zeros((S, n_cg), dtype=torch.float64, device=geo.dev)
         b[:, site] = 1
-        X, stats = K.eq_qp_solve(Gm, float(l2_regularization), None, A.reshape(S * n_cg, n_feat).contiguous(),
-                                 b.reshape(-1, 1).contiguous(), schur_reg=1e-12, n_refine=3)
-        st = stats.cpu().numpy()
-        if st[0] != 0 or not np.isfinite(st[1]):
-            raise ValueError(
-                f"Map optimization failed. (site {site if 'site' in dir() else ind}: pivot {int(st[0])}, "
-                f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
-            )
-        coefs.append(X[0].cpu().numpy())
+        return Gm, A.reshape(S * n_cg, n_feat).contiguous(), b.reshape(-1, 1).contiguous()
+
+    for c0 in range(0, n_cg, _SOLVE_CHUNK):
+        sites = list(range(c0, min(n_cg, c0 + _SOLVE_CHUNK)))
+        problems = [prepare(site) for site in sites]
+        ready = torch.cuda.Event()
+        ready.record(main)
+        results = []
+        for j, (Gm, A2, b2) in enumerate(problems):
+            st_side = side[j % _SOLVE_STREAMS]
+            st_side.wait_event(ready)
+            with torch.cuda.stream(st_side):
+                results.append(K.eq_qp_solve(Gm, float(l2_regularization), None, A2, b2, schur_reg=1e-12, n_refine=3))
+            for t in (Gm, A2, b2):
+                t.record_stream(st_side)  # allocated on the main stream, read on the side stream
+        for st_side in side:
+            main.wait_stream(st_side)     # the next chunk's Grams start after these solves
+            st_side.synchronize()
+        for site, (X, stats) in zip(sites, results):
+            st = stats.cpu().numpy()
+            if st[0] != 0 or not np.isfinite(st[1]):
+                raise ValueError(
+                    f"Map optimization failed. (site {site}: pivot {int(st[0])}, "
+                    f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
+                )
+            coefs[site] = X[0].cpu().numpy()
+        del problems, results
     coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
 
     def apply_f(points, copoints):
