@@ -264,8 +264,8 @@ __device__ unsigned long long aggf_gram_prof[4];
 #define AGGF_PROF_T(x)
 #endif
 
-template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2>
-__global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
+template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false>
+__global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
   using M = Mfma<T>;
@@ -275,8 +275,15 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
   constexpr int PE = DmaCfg<T>::PIECE_ELEMS;
   constexpr int PANELS = 2;  // diagonal tiles stage their panel twice (one code path, fixed vmcnt)
   constexpr int PIECES = PANELS * KB * RP;           // per stage: 24/12 (f64), 32/16 (f32)
-  constexpr int PPW = PIECES / 4;                    // per wave: 6/3, 8/4
-  static_assert(PIECES % 4 == 0, "piece split");
+  constexpr int PPW = PIECES / NW;                   // per wave: 6 (f64) / 8 (f32) with 4 waves, 3 / 4 with 8
+  static_assert(PIECES % NW == 0, "piece split");
+  // NW waves tile the 128x128 output as 2 x (NW/2): wave tile 64 x 64 (NW = 4) or 64 x 32 (NW = 8,
+  // four waves per SIMD with two workgroups per CU: half the accumulators and half the DMA
+  // instructions per wave, twice the waves to cover each other's stalls)
+  constexpr int WN = NW / 2;
+  constexpr int WCOLS = TILE / WN;                   // columns per wave: 64 / 32
+  constexpr int NACC = WCOLS / 16;                   // 16-column accumulator tiles per wave: 4 / 2
+  constexpr int NTHREADS = 64 * NW;
   constexpr int PANEL_ELEMS = KB * ROW_STRIDE;
   constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
   constexpr int AHEAD = NBUF - 1;  // stages in flight ahead of the one being computed
@@ -287,7 +294,7 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
 
   // workgroup -> (split, tile), XCD-aware.  Workgroups b and b+8 land on the same XCD (observed
   // round-robin dispatch; only speed depends on it), and an XCD runs 64 of them at a time (32 CUs x
@@ -313,7 +320,7 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
   bool p_half[PPW];
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
-    const int p = wave + 4 * q;
+    const int p = wave + NW * q;
     const int panel = p / (KB * RP);
     const int r = (p - panel * KB * RP) / RP;
     const int cp = p % RP;
@@ -340,7 +347,7 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
     if (t0 + KB > t_end) {
       T* lbase = smem + (s % NBUF) * BUF_ELEMS;
       const int first = (int)(t_end - t0);
-      for (int e = tid; e < PANELS * (KB - first) * ROW_ELEMS; e += GRAM_THREADS) {
+      for (int e = tid; e < PANELS * (KB - first) * ROW_ELEMS; e += NTHREADS) {
         const int panel = e / ((KB - first) * ROW_ELEMS);
         const int rem = e - panel * (KB - first) * ROW_ELEMS;
         const int r = first + rem / ROW_ELEMS, c = rem % ROW_ELEMS;
@@ -366,14 +373,14 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
     for (int q = 0; q < PPW; ++q) issue_piece(s, q);
   };
 
-  acc_t acc[4][4];
+  acc_t acc[4][NACC];
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n) acc[m][n] = acc_zero<T>();
+    for (int n = 0; n < NACC; ++n) acc[m][n] = acc_zero<T>();
 
   const int offA = (lane >> 4) * ROW_STRIDE + 3 * (wm * 64 + (lane & 15));
-  const int offB = PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wn * 64 + (lane & 15));
+  const int offB = PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wn * WCOLS + (lane & 15));
 
   if (n_it > 0) issue_stage(0);
   if (AHEAD > 1 && n_it > 1) issue_stage(1);
@@ -389,22 +396,36 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
     AGGF_PROF_T(p0);
     // DMAs of stage it+2 first (placing them between the MFMA groups instead, or raising the
     // wave priority around the MFMA groups, measured no better: tools/gram_ablate.hip history)
-    if ((ABL == 0 || ABL >= 3) && it + AHEAD < n_it) issue_stage(it + AHEAD);
+    // SPREAD_DMA: one share of the stage's DMAs before each MFMA group instead of all up front
+    // (the DMA path accepts ~1 KiB per 100+ cycles under this load; a burst of 24 KiB after every
+    // barrier queues the waves behind it)
+    constexpr int GROUPS = 3 * KB / 4;
+    constexpr bool SPREAD = SPREAD_DMA && (PPW % GROUPS == 0);  // (uneven shares measured worse: fp32)
+    const bool issue_now = (ABL == 0 || ABL >= 3) && it + AHEAD < n_it;
+    if (issue_now) {
+      if (SPREAD) prep_stage(it + AHEAD); else issue_stage(it + AHEAD);
+    }
     const T* pa = smem + (((ABL == 1 || ABL == 2) ? it % 2 : it % NBUF)) * BUF_ELEMS;
     AGGF_PROF_T(p1);
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
-        T a[4], bb[4];
+        T a[4], bb[NACC];
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
 #pragma unroll
-        for (int n = 0; n < 4; ++n) bb[n] = pa[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+        for (int n = 0; n < NACC; ++n) bb[n] = pa[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+        // between the operand reads and the MFMAs of the group: the reads are in flight while the DMA
+        // waits to be accepted (before the reads: +3.5 %, after the MFMAs: +1 %, tools/clock_probe.hip)
+        if (SPREAD && issue_now) {
+#pragma unroll
+          for (int q = 0; q < PPW / GROUPS; ++q) issue_piece(it + AHEAD, (kk * 3 + d) * (PPW / GROUPS) + q);
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
-          for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+          for (int n = 0; n < NACC; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
       }
     }
     AGGF_PROF_T(p2);
@@ -437,11 +458,11 @@ __global__ __launch_bounds__(GRAM_THREADS, WPS) void gram_tile_dma_kernel(
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
-    for (int n = 0; n < 4; ++n)
+    for (int n = 0; n < NACC; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         const int row = wm * 64 + m * 16 + M::row(lane, r);
-        const int col = wn * 64 + n * 16 + (lane & 15);
+        const int col = wn * WCOLS + n * 16 + (lane & 15);
         slab[row * TILE + col] = acc[m][n][r];
       }
 }
@@ -766,7 +787,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2 };
+enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3 };
 
 struct GramPlan {
   int32_t n_pad, nt1, n_tiles;
@@ -809,13 +830,14 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
 static size_t dtype_size(int dt) { return dt == AGGF_F64 ? 8 : 4; }
 static size_t table_bytes(const GramPlan& p) { return (size_t)round_up((int64_t)p.n_tiles * 8, 256); }
 
-// fp64: LDS-DMA ring (+4 % over register staging); fp32: register staging is faster (its panel
-// rows are 1.5 DMA pieces, i.e. 8 DMA instructions per wave and stage instead of 6).
-// AGGF_GRAM_STAGING = "pair" | "dma" | "reg" overrides (benchmarks, tests).
+// fp64: LDS-DMA ring with 8 waves per tile and the DMAs spread over the MFMA groups (769 ms at C3;
+// 4 waves with the DMAs up front 786 ms; register staging 810 ms); fp32: register staging is
+// faster (its panel rows are 1.5 DMA pieces; c5: 60.4 ms against 61.9 / 62.5 ms for the two DMA forms).
+// AGGF_GRAM_STAGING = "8waves" | "dma" | "pair" | "reg" overrides (benchmarks, tests).
 static int choose_staging(int compute_dtype, int nt1) {
   static const char* force = getenv("AGGF_GRAM_STAGING");
-  int st = compute_dtype == AGGF_F64 ? STAGE_DMA : STAGE_REG;
-  if (force) st = force[0] == 'p' ? STAGE_PAIR : force[0] == 'd' ? STAGE_DMA : STAGE_REG;
+  int st = compute_dtype == AGGF_F64 ? STAGE_DMA8 : STAGE_REG;
+  if (force) st = force[0] == 'p' ? STAGE_PAIR : force[0] == 'd' ? STAGE_DMA : force[0] == '8' ? STAGE_DMA8 : STAGE_REG;
   if (st == STAGE_PAIR && nt1 < 2) st = STAGE_DMA;
   return st;
 }
@@ -898,6 +920,24 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_pair_dma_kernel<T>), dim3((unsigned)round_up(nwg, 256)), dim3(PAIR_THREADS), lds,
                        stream, X, rows, ld, p.nt1, p.n_entries, ksplit, table, fps, slabs);
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
+                       slabs, p.nt1, ksplit, n_red, accumulate, G);
+    AGGF_LAUNCH_OK();
+    return AGGF_OK;
+  }
+  if (p.staging == STAGE_DMA8) {
+    const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);
+    static thread_local bool attr_done = false;
+    if (!attr_done) {
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+      attr_done = true;
+    }
+    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table);
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblocks, 512)), dim3(512),
+                       lds3, stream, X, rows, ld, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs);
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                        slabs, p.nt1, ksplit, n_red, accumulate, G);

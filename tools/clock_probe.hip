@@ -138,6 +138,26 @@ int main() {
       hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, 0, nt1, table);
       hipDeviceSynchronize();
     }
+    hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+    hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 1, 3, 2, 8>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+    with_probe("8 WAVES per tile (4/SIMD), no DMA in loop", 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 1, 3, 2, 8>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(512), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
+    with_probe("8 WAVES per tile (4/SIMD), full", 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(512), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
+    hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+    hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 4, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+    with_probe("8 WAVES per tile, DMAs spread over MFMA groups", 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(512), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
+    with_probe("4 waves per tile, DMAs spread over MFMA groups", 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 4, true>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(256), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
     with_probe("register-staged, full", 400, [&](hipStream_t s) {
       for (int i = 0; i < 2; ++i)
         hipLaunchKernelGGL((gram_tile_kernel<T, 0, false>), dim3(ksplit * n_tiles), dim3(GRAM_THREADS), lds_reg, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, fps, slabs);
