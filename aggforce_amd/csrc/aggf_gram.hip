@@ -400,7 +400,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     // (the DMA path accepts ~1 KiB per 100+ cycles under this load; a burst of 24 KiB after every
     // barrier queues the waves behind it)
     constexpr int GROUPS = 3 * KB / 4;
-    constexpr bool SPREAD = SPREAD_DMA && (PPW % GROUPS == 0);  // (uneven shares measured worse: fp32)
+    constexpr bool SPREAD = SPREAD_DMA;
     const bool issue_now = (ABL == 0 || ABL >= 3) && it + AHEAD < n_it;
     if (issue_now) {
       if (SPREAD) prep_stage(it + AHEAD); else issue_stage(it + AHEAD);
@@ -420,7 +420,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
         // waits to be accepted (before the reads: +3.5 %, after the MFMAs: +1 %, tools/clock_probe.hip)
         if (SPREAD && issue_now) {
 #pragma unroll
-          for (int q = 0; q < PPW / GROUPS; ++q) issue_piece(it + AHEAD, (kk * 3 + d) * (PPW / GROUPS) + q);
+          for (int q = 0; q < PPW; ++q)
+            if (q * GROUPS / PPW == kk * 3 + d) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -830,13 +831,14 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
 static size_t dtype_size(int dt) { return dt == AGGF_F64 ? 8 : 4; }
 static size_t table_bytes(const GramPlan& p) { return (size_t)round_up((int64_t)p.n_tiles * 8, 256); }
 
-// fp64: LDS-DMA ring with 8 waves per tile and the DMAs spread over the MFMA groups (769 ms at C3;
-// 4 waves with the DMAs up front 786 ms; register staging 810 ms); fp32: register staging is
-// faster (its panel rows are 1.5 DMA pieces; c5: 60.4 ms against 61.9 / 62.5 ms for the two DMA forms).
-// AGGF_GRAM_STAGING = "8waves" | "dma" | "pair" | "reg" overrides (benchmarks, tests).
+// Default for both dtypes: LDS-DMA ring, 8 waves per tile, the stage's DMAs spread over the MFMA groups.
+// fp64 at C3: 757 ms (4 waves with the DMAs up front 786 ms, register staging 810 ms); fp32 (panel
+// rows are 1.5 DMA pieces, uneven shares per group): c2 3.12 ms against 3.26 ms register-staged, c5
+// 60.7 against 60.3 ms.  AGGF_GRAM_STAGING = "8waves" | "dma" | "pair" | "reg" overrides (benchmarks, tests).
 static int choose_staging(int compute_dtype, int nt1) {
   static const char* force = getenv("AGGF_GRAM_STAGING");
-  int st = compute_dtype == AGGF_F64 ? STAGE_DMA8 : STAGE_REG;
+  int st = STAGE_DMA8;
+  (void)compute_dtype;
   if (force) st = force[0] == 'p' ? STAGE_PAIR : force[0] == 'd' ? STAGE_DMA : force[0] == '8' ? STAGE_DMA8 : STAGE_REG;
   if (st == STAGE_PAIR && nt1 < 2) st = STAGE_DMA;
   return st;
