@@ -8,6 +8,8 @@
 // sets fed from the same staged tile, so P is read exactly once per site block.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "aggf_common.h"
 
 namespace aggf {
@@ -24,8 +26,16 @@ __device__ __forceinline__ TC fix_nan(TC v, bool replace, TC fill) {
   return (replace && v != v) ? fill : v;
 }
 
+#ifdef AGGF_APPLY_PROF
+// tools/apply_probe.hip: shader cycles per wave spent in load issue / MFMA / LDS refill / barrier
+__device__ unsigned long long aggf_apply_prof[5];
+#define AP_T(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define AP_T(x)
+#endif
+
 template <typename TIn, typename TC, bool NANREP, int AP_THREADS, int AP_TC>
-__global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
+__global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
     int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
     double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
@@ -60,11 +70,15 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
   const int64_t rowP = (int64_t)N * 3;
   const int n_stage = (N + AP_KA - 1) / AP_KA;
 
-  TIn rp[P_PER_THREAD][VI];
-  TC rm[M_PER_THREAD][VM];
+  // two register sets: the global loads of stage s+2 are issued at the top of stage s and reach LDS
+  // at the end of stage s+1.  With one stage of distance the refill waited ~3500 cycles per stage for
+  // its loads (a CU keeps only a few dozen cache-line misses in flight; tools/apply_probe.hip).
+  TIn rp[2][P_PER_THREAD][VI];
+  TC rm[2][M_PER_THREAD][VM];
   bool saw_nan = false;  // any NaN among the P values this thread staged (fused _has_nans scan)
 
-  auto load_stage = [&](int s) {
+  auto load_stage = [&](int s, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     const int a0 = s * AP_KA;
 #pragma unroll
     for (int q = 0; q < P_PER_THREAD; ++q) {
@@ -73,18 +87,18 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       const int64_t t = t0 + r;
       const int64_t e0 = (int64_t)a0 * 3 + col;                    // element in the frame row
 #pragma unroll
-      for (int e = 0; e < VI; ++e) rp[q][e] = 0;
+      for (int e = 0; e < VI; ++e) rp[SET][q][e] = 0;
       if (c < P_CH && t < T) {
         const TIn* src = P + t * rowP + e0;
         if (p_vec_ok && e0 + VI <= rowP) {
           typedef TIn __attribute__((ext_vector_type(VI))) vin_t;
           vin_t v = *reinterpret_cast<const vin_t*>(src);
 #pragma unroll
-          for (int e = 0; e < VI; ++e) rp[q][e] = v[e];
+          for (int e = 0; e < VI; ++e) rp[SET][q][e] = v[e];
         } else {
 #pragma unroll
           for (int e = 0; e < VI; ++e)
-            if (e0 + e < rowP) rp[q][e] = src[e];
+            if (e0 + e < rowP) rp[SET][q][e] = src[e];
         }
       }
     }
@@ -95,23 +109,24 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       const int cg = c0 + r;
       const int a = a0 + col;
 #pragma unroll
-      for (int e = 0; e < VM; ++e) rm[q][e] = 0;
+      for (int e = 0; e < VM; ++e) rm[SET][q][e] = 0;
       if (c < M_CH && cg < n_cg) {
         const TC* src = Mx + (int64_t)cg * N + a;
         if (m_vec_ok && a + VM <= N) {
           typedef TC __attribute__((ext_vector_type(VM))) vm_t;
           vm_t v = *reinterpret_cast<const vm_t*>(src);
 #pragma unroll
-          for (int e = 0; e < VM; ++e) rm[q][e] = v[e];
+          for (int e = 0; e < VM; ++e) rm[SET][q][e] = v[e];
         } else {
 #pragma unroll
           for (int e = 0; e < VM; ++e)
-            if (a + e < N) rm[q][e] = src[e];
+            if (a + e < N) rm[SET][q][e] = src[e];
         }
       }
     }
   };
-  auto store_stage = [&](int buf) {
+  auto store_stage = [&](int buf, auto set_c) {
+    constexpr int SET = decltype(set_c)::value;
     TC* x = sX + buf * XBUF;
     TC* m = sM + buf * MBUF;
 #pragma unroll
@@ -121,8 +136,8 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       if (c < P_CH) {
 #pragma unroll
         for (int e = 0; e < VI; ++e) {
-          saw_nan |= (rp[q][e] != rp[q][e]);
-          x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[q][e], NANREP, nan_fill);
+          saw_nan |= (rp[SET][q][e] != rp[SET][q][e]);
+          x[r * AP_XS + col + e] = fix_nan<TC>((TC)rp[SET][q][e], NANREP, nan_fill);
         }
       }
     }
@@ -132,7 +147,7 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
       const int r = c / M_CH_ROW, col = (c - r * M_CH_ROW) * VM;
       if (c < M_CH) {
 #pragma unroll
-        for (int e = 0; e < VM; ++e) m[r * AP_MS + col + e] = rm[q][e];
+        for (int e = 0; e < VM; ++e) m[r * AP_MS + col + e] = rm[SET][q][e];
       }
     }
   };
@@ -147,12 +162,22 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
   const int offX = (16 * wf + (lane & 15)) * AP_XS + 3 * (lane >> 4);
   const int offM = (wc * NCT * 16 + (lane & 15)) * AP_MS + (lane >> 4);
 
-  load_stage(0);
-  store_stage(0);
-  __syncthreads();
-  for (int s = 0; s < n_stage; ++s) {
-    const int cur = s & 1;
-    if (s + 1 < n_stage) load_stage(s + 1);
+#ifdef AGGF_APPLY_PROF
+  uint64_t pf[4] = {0, 0, 0, 0};
+#endif
+  using set0 = std::integral_constant<int, 0>;
+  using set1 = std::integral_constant<int, 1>;
+  auto stage = [&](int s, auto set_c) {
+    // set_c = s & 1: the set that held stage s (already in LDS) is free for stage s+2; the other set
+    // holds stage s+1, loaded during stage s-1
+    constexpr int SET = decltype(set_c)::value;
+    using other = std::integral_constant<int, 1 - SET>;
+    const int cur = SET;
+    AP_T(q0);
+#if !defined(AGGF_APPLY_ABL) || AGGF_APPLY_ABL < 1
+    if (s + 2 < n_stage) load_stage(s + 2, set_c);
+#endif
+    AP_T(q1);
     const TC* x = sX + cur * XBUF;
     const TC* m = sM + cur * MBUF;
 #pragma unroll
@@ -167,10 +192,35 @@ __global__ __launch_bounds__(AP_THREADS, 2) void apply_kernel(
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], b[n], acc[n][d]);
     }
-    if (s + 1 < n_stage) store_stage(cur ^ 1);
+    AP_T(q2);
+#if !defined(AGGF_APPLY_ABL) || AGGF_APPLY_ABL < 2
+    if (s + 1 < n_stage) store_stage(cur ^ 1, other{});
+#endif
+    AP_T(q3);
     __syncthreads();
+#ifdef AGGF_APPLY_PROF
+    const uint64_t q4 = __builtin_readcyclecounter();
+    pf[0] += q1 - q0;
+    pf[1] += q2 - q1;
+    pf[2] += q3 - q2;
+    pf[3] += q4 - q3;
+#endif
+  };
+  load_stage(0, set0{});
+  store_stage(0, set0{});
+  if (n_stage > 1) load_stage(1, set1{});
+  __syncthreads();
+  for (int s = 0; s < n_stage; s += 2) {
+    stage(s, set0{});
+    if (s + 1 < n_stage) stage(s + 1, set1{});
   }
 
+#ifdef AGGF_APPLY_PROF
+  if (lane == 0) {
+    for (int i = 0; i < 4; ++i) atomicAdd(&aggf_apply_prof[i], (unsigned long long)pf[i]);
+    atomicAdd(&aggf_apply_prof[4], (unsigned long long)n_stage);
+  }
+#endif
   if (nan_seen && cb == 0 && __any(saw_nan) && lane == 0) atomicOr(nan_seen, 1);
 
   // epilogue: out[t, c, d]; optional sum of squares (fixed order: lane tree, then waves)
@@ -288,9 +338,14 @@ template <typename TIn, typename TC>
 static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
                        int nan_mode, double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
                        void* ws, size_t ws_bytes, hipStream_t stream) {
-  static const char* force = getenv("AGGF_APPLY_TILE");  // "small" | "big" (benchmarks)
-  const bool big = force ? (force[0] == 'b') : (n_cg > 64);
-  if (big)
+  // 64 frames x 128 sites with 16 waves (4 per SIMD; c3: 102.4 ms, 8 waves: 104.5 ms) when n_cg > 64,
+  // else 64 x 64 with 4 waves.  AGGF_APPLY_TILE = "wide" | "big" (8 waves) | "small" overrides (benchmarks).
+  static const char* force = getenv("AGGF_APPLY_TILE");
+  const int tile = force ? (force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
+  if (tile == 2)
+    return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
+                                            ws_bytes, stream);
+  if (tile == 1)
     return apply_launch<TIn, TC, 512, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                            ws_bytes, stream);
   return apply_launch<TIn, TC, 256, 64>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
