@@ -34,15 +34,15 @@ __device__ unsigned long long aggf_apply_prof[5];
 #define AP_T(x)
 #endif
 
-template <typename TIn, typename TC, bool NANREP, int AP_THREADS, int AP_TC>
-__global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_kernel(
+template <typename TIn, typename TC, bool NANREP, int AP_THREADS, int AP_TC, int AP_WF = 4>
+__global__ __launch_bounds__(AP_THREADS, (AP_THREADS >= 1024 || AP_WF < 4) ? 4 : 2) void apply_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
     int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
     double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
   using MF = Mfma<TC>;
   using acc_t = typename MF::acc_t;
   constexpr int NWAVE = AP_THREADS / 64;
-  constexpr int WF = 4;                  // waves along the frame axis; the others split the site axis
+  constexpr int WF = AP_WF;              // waves along the frame axis; the others split the site axis
   constexpr int WC = NWAVE / WF;
   constexpr int AP_TF = 16 * WF;         // frames per workgroup (one 16-frame MFMA row block per wave row)
   constexpr int NCT = AP_TC / 16 / WC;   // 16-site column tiles per wave
@@ -287,11 +287,11 @@ __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict
   }
 }
 
-template <typename TIn, typename TC, int THREADS, int TCB>
+template <typename TIn, typename TC, int THREADS, int TCB, int WFR = 4>
 static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg, int nan_mode,
                         double nan_fill, void* out, double* sumsq, int32_t* nan_seen, void* ws,
                         size_t ws_bytes, hipStream_t stream) {
-  constexpr int TF = 64;
+  constexpr int TF = 16 * WFR;
   const int ncb = (int)ceil_div(n_cg, TCB);
   const int64_t nfb = ceil_div(T, TF);
   const int64_t nblocks = nfb * ncb;
@@ -308,22 +308,22 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
   if (lds > 65536) {
     static thread_local bool done_t = false, done_f = false;
     if (!done_t) {
-      AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, true, THREADS, TCB>,
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, true, THREADS, TCB, WFR>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       done_t = true;
     }
     if (!done_f) {
-      AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, false, THREADS, TCB>,
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, false, THREADS, TCB, WFR>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
       done_f = true;
     }
   }
   if (nan_mode == AGGF_NAN_REPLACE)
-    hipLaunchKernelGGL((apply_kernel<TIn, TC, true, THREADS, TCB>), dim3((unsigned)nblocks), dim3(THREADS), lds,
+    hipLaunchKernelGGL((apply_kernel<TIn, TC, true, THREADS, TCB, WFR>), dim3((unsigned)nblocks), dim3(THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)nan_fill, p_vec_ok,
                        m_vec_ok, (TC*)out, partials, nan_seen);
   else
-    hipLaunchKernelGGL((apply_kernel<TIn, TC, false, THREADS, TCB>), dim3((unsigned)nblocks), dim3(THREADS), lds,
+    hipLaunchKernelGGL((apply_kernel<TIn, TC, false, THREADS, TCB, WFR>), dim3((unsigned)nblocks), dim3(THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)0, p_vec_ok,
                        m_vec_ok, (TC*)out, partials, nan_seen);
   AGGF_LAUNCH_OK();
@@ -341,6 +341,7 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   // 64 frames x 128 sites with 16 waves (4 per SIMD; c3: 102.4 ms, 8 waves: 104.5 ms) when n_cg > 64,
   // else 64 x 64 with 4 waves.  AGGF_APPLY_TILE = "wide" | "big" (8 waves) | "small" overrides (benchmarks).
   static const char* force = getenv("AGGF_APPLY_TILE");
+  // (32 frames x 128 sites with 8 waves -- two independent workgroups per CU -- measured the same 103 ms)
   const int tile = force ? (force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
   if (tile == 2)
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
@@ -359,7 +360,7 @@ using namespace aggf;
 extern "C" size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg) {
   (void)N;
   if (T <= 0 || n_cg <= 0) return 256;
-  return (size_t)round_up(ceil_div(T, 64) * ceil_div(n_cg, 64) * 8, 256);
+  return (size_t)round_up(ceil_div(T, 32) * ceil_div(n_cg, 64) * 8, 256);
 }
 
 extern "C" int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype,
