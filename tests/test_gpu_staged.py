@@ -196,3 +196,100 @@ def test_streamed_project_forces_matches_in_memory(tmp_path, dt):
     assert rel(one["mapped_forces"], ref["mapped_forces"]) < 1e-12
     with pytest.raises(ValueError):
         project_forces_streamed(mc, mf, cmap, "auto")
+
+
+# ------------------------------------------------------------------ distributed cross-validation
+def _cv_rank_worker(rank, world, port, out_dir):
+    """Two processes on one GPU, gloo for the all-reduce: each rank holds half of the frames and
+    splits them into folds locally; global fold k is the union of the ranks' fold k."""
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aggforce_amd import LinearMap as LM
+    from aggforce_amd.agg import project_forces_grid_cv as cv
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    coords, forces, _, cons, _ = system(T=400, seed=31)
+    half = slice(rank * 200, (rank + 1) * 200)
+    cmap = LM([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]], n_fg_sites=12)
+    res = cv({"l2_regularization": [0.0, 0.5]}, coords[half], forces[half].astype(np.float64), n_folds=4,
+             rng=np.random.default_rng(100 + rank), coord_map=cmap, constrained_inds=cons, comm=True)
+    out = {f"{k.l2_regularization}": (res["scores"][k], res["sds"][k], res["n_runs"][k]) for k in res["scores"]}
+    np.save(os.path.join(out_dir, f"cv{rank}.npy"), np.array([out["0.0"], out["0.5"]], dtype=np.float64))
+    dist.destroy_process_group()
+
+
+def test_grid_cv_two_ranks_matches_oracle_on_union_folds(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_cv_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    coords, forces, cmap, cons, _ = system(T=400, seed=31)
+    forces = forces.astype(np.float64)
+    folds = []
+    local = []
+    for rank in range(2):
+        fr = np.arange(200)
+        np.random.default_rng(100 + rank).shuffle(fr)
+        local.append([f + 200 * rank for f in np.array_split(fr, 4)])
+    for k in range(4):
+        folds.append(np.concatenate([local[0][k], local[1][k]]))
+    ref = orc.project_forces_grid_cv([0.0, 0.5], coords, forces, cmap.standard_matrix, folds, cons)
+    r0, r1 = np.load(tmp_path / "cv0.npy"), np.load(tmp_path / "cv1.npy")
+    assert np.array_equal(r0, r1)  # both ranks hold the same all-reduced Grams
+    for row, l2 in zip(r0, (0.0, 0.5)):
+        assert row[2] == 4
+        assert abs(row[0] - ref[l2][0]) < 1e-8 * abs(ref[l2][0])
+        assert abs(row[1] - ref[l2][1]) < 1e-6 * abs(ref[l2][1])
+
+
+def _stream_rank_worker(rank, world, port, out_dir):
+    import os
+    import sys
+
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aggforce_amd import LinearMap as LM
+    from aggforce_amd.stream import project_forces_streamed as pfs
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    coords, forces, _, cons, _ = system(T=600, seed=41)
+    half = slice(rank * 300, (rank + 1) * 300)
+    cmap = LM([[0, 1, 2], [3, 4, 5], [6, 7, 8], [9, 10, 11]], n_fg_sites=12)
+    out = pfs(coords[half], forces[half], cmap, cons, l2_regularization=1e-3, chunk_frames=77,
+              gram_dtype=np.float64, comm=True)
+    np.save(os.path.join(out_dir, f"sW{rank}.npy"), out["tmap"].force_map.standard_matrix)
+    np.save(os.path.join(out_dir, f"smf{rank}.npy"), out["mapped_forces"])
+    np.save(os.path.join(out_dir, f"sres{rank}.npy"), np.array([out["residual"]]))
+    dist.destroy_process_group()
+
+
+def test_streamed_project_forces_two_ranks(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+    from aggforce_amd import project_forces
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_stream_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    coords, forces, cmap, cons, _ = system(T=600, seed=41)
+    ref = project_forces(coords, forces, cmap, cons, l2_regularization=1e-3, gram_dtype=np.float64)
+    W0, W1 = np.load(tmp_path / "sW0.npy"), np.load(tmp_path / "sW1.npy")
+    assert np.array_equal(W0, W1) and rel(W0, ref["tmap"].force_map.standard_matrix) < 1e-9
+    mf = np.concatenate([np.load(tmp_path / "smf0.npy"), np.load(tmp_path / "smf1.npy")])
+    assert rel(mf, ref["mapped_forces"]) < 1e-9
+    r0, r1 = np.load(tmp_path / "sres0.npy")[0], np.load(tmp_path / "sres1.npy")[0]
+    assert r0 == r1 and abs(r0 - ref["residual"]) < 1e-9 * ref["residual"]
