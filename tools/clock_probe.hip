@@ -158,6 +158,16 @@ int main() {
       for (int i = 0; i < 2; ++i)
         hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 4, true>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(256), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
     });
+    hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 3, 3, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+    hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 4, 3, 2, 8, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_dma);
+    with_probe("8 waves spread, DMAs all hit L1 (ABL 3)", 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 3, 3, 2, 8, true>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(512), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
+    with_probe("8 waves spread, DMAs miss L1, hit L2 (ABL 4)", 400, [&](hipStream_t s) {
+      for (int i = 0; i < 2; ++i)
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 4, 3, 2, 8, true>), dim3((unsigned)round_up((int64_t)ksplit * n_tiles, 512)), dim3(512), lds_dma, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, ksplit, table, fps, slabs);
+    });
     with_probe("register-staged, full", 400, [&](hipStream_t s) {
       for (int i = 0; i < 2; ++i)
         hipLaunchKernelGGL((gram_tile_kernel<T, 0, false>), dim3(ksplit * n_tiles), dim3(GRAM_THREADS), lds_reg, s, X, rows, (int64_t)n_pad * 3, nt1, n_tiles, fps, slabs);
