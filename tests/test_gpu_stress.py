@@ -35,3 +35,13 @@ def test_infeasible_constraints_are_refused():
     # two CG sites inside one rigid group share a coefficient: (M C) x = e_i cannot hold for both
     with pytest.raises(ValueError, match="cannot be met|not positive definite"):
         project_forces(f, f, LinearMap([[0], [1]], n_fg_sites=8), {frozenset([0, 1])}, l2_regularization=0.1)
+
+
+def test_random_apply_sweep_matches_oracle(monkeypatch, capsys):
+    """LinearMap.__call__: slice/dense/sparse maps, dtype promotion, NaN policy (identical raises)."""
+    spec = importlib.util.spec_from_file_location("stress_apply", os.path.join(ROOT, "tools", "stress_apply.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    monkeypatch.setattr(sys, "argv", ["stress_apply.py", "80", "5"])
+    mod.main()
+    assert "80 apply cases ok" in capsys.readouterr().out
