@@ -45,3 +45,15 @@ def test_random_apply_sweep_matches_oracle(monkeypatch, capsys):
     monkeypatch.setattr(sys, "argv", ["stress_apply.py", "80", "5"])
     mod.main()
     assert "80 apply cases ok" in capsys.readouterr().out
+
+
+def test_random_k6_and_k5_sweeps_match_oracle(monkeypatch, capsys):
+    """guess_pairwise_constraints (K6) and the CondNormal augmentation (K5) on random sizes, dtypes and premaps."""
+    spec = importlib.util.spec_from_file_location("stress_misc", os.path.join(ROOT, "tools", "stress_misc.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    rng = np.random.default_rng(17)
+    mod.sweep_k6(rng, 40)
+    mod.sweep_k5(rng, 40)
+    out = capsys.readouterr().out
+    assert "40 K6 cases ok" in out and "40 K5 cases ok" in out
