@@ -244,3 +244,22 @@ def test_staged_map_signatures_match_reference_names():
     assert sig.parameters["contribution_tolerance"].default == 1e-6
     sig = inspect.signature(pkg.stagedjslicegauss_map)
     assert sig.parameters["warn_input_forces"].default is True
+
+
+def test_integration_stub_matches_the_abi():
+    """The ctypes stub shown in INTEGRATION.md binds real symbols with the right number of arguments."""
+    import re
+
+    from aggforce_amd import _lib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    text = open(os.path.join(root, "INTEGRATION.md")).read()
+    block = re.search(r"```python\nimport ctypes as C, torch\n(.*?)```", text, re.S)
+    assert block is not None
+    code = "import ctypes as C, torch\n" + block.group(1)
+    code = code.replace('C.CDLL("libaggf.so")', f'C.CDLL("{_lib.LIB_PATH}")')
+    ns: dict = {}
+    exec(compile(code, "INTEGRATION.md", "exec"), ns)  # noqa: S102
+    for name in ("aggf_gram", "aggf_gram_workspace_bytes", "aggf_eq_qp_solve", "aggf_eq_qp_workspace_bytes",
+                 "aggf_linearmap_apply"):
+        assert len(getattr(ns["_l"], name).argtypes) == len(_lib.PROTOTYPES[name][1]), name
