@@ -254,6 +254,27 @@ def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype
     return out
 
 
+def nan_flag(x: torch.Tensor) -> torch.Tensor:
+    """Device int32 flag (shape (1,)): non-zero iff x holds a NaN.  No host synchronisation."""
+    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    if x.numel():
+        check(lib().aggf_has_nan(ptr(x), x.numel(), dtype_code(x.dtype), ptr(flag), stream_ptr()), "aggf_has_nan")
+    return flag
+
+
+_side_streams: dict = {}
+
+
+def side_stream(device) -> "torch.cuda.Stream":
+    """One auxiliary stream per device for work that may overlap the main stream's kernels."""
+    key = str(device)
+    st = _side_streams.get(key)
+    if st is None:
+        st = torch.cuda.Stream(device=device)
+        _side_streams[key] = st
+    return st
+
+
 def has_nan(x: torch.Tensor) -> bool:
     l = lib()
     if x.numel() == 0:

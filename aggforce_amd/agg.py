@@ -14,7 +14,7 @@ import numpy as np
 from . import _kernels as K
 from .constraints import Constraints, guess_pairwise_constraints
 from .distributed import all_reduce_sum_
-from .map import LinearMap, TMap
+from .map import LinearMap, SeperableTMap, TMap
 from .qp import qp_linear_map
 from .trajectory import Trajectory
 
@@ -74,12 +74,25 @@ def project_forces(
         constrained_inds = guess_pairwise_constraints(coords)
     with K.upload_cache():
         t = Trajectory(coords=coords, forces=forces)
-        traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
-        mapped = traj_map(t)
-        residual = force_smoothness(mapped.forces, comm=kwargs.get("comm"))
+        # the coordinate map does not depend on the fit: a slice map's gather runs on a side stream
+        # underneath the Gram / solve kernels instead of after them
+        pending = coord_map.map_async(t.coords) if isinstance(coord_map, LinearMap) else None
+        try:
+            traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
+            if pending is not None and type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map:
+                mapped_forces = traj_map.force_map(t.forces)
+                mapped_coords = pending.result()
+                pending = None
+            else:
+                mapped = traj_map(t)
+                mapped_coords, mapped_forces = mapped.coords, mapped.forces
+        finally:
+            if pending is not None:
+                pending.discard()
+        residual = force_smoothness(mapped_forces, comm=kwargs.get("comm"))
     return {
-        PROJCOORDS_KNAME: mapped.coords,
-        PROJFORCES_KNAME: mapped.forces,
+        PROJCOORDS_KNAME: mapped_coords,
+        PROJFORCES_KNAME: mapped_forces,
         TMAP_KNAME: traj_map,
         RESIDUAL_KNAME: residual,
         CONSTRAINTS_KNAME: constrained_inds,

@@ -22,6 +22,32 @@ class _Taggable:
         self.tags = {} if tags is None else tags
 
 
+class _PendingMap:
+    """Result of LinearMap.map_async: finished (and checked) by ``result()``."""
+
+    def __init__(self, out, flag, stream, template) -> None:
+        self._out, self._flag, self._stream, self._template = out, flag, stream, template
+
+    def _join(self):
+        import torch
+
+        main = torch.cuda.current_stream(self._out.device)
+        main.wait_stream(self._stream)
+        self._out.record_stream(main)
+
+    def result(self):
+        self._join()
+        if bool(self._flag.item()):
+            raise ValueError(
+                "NaN handling is on and results seem to depend on NaN "
+                "positions in input array. Check input and standard_matrix."
+            )
+        return K.like_input(self._out, self._template)
+
+    def discard(self) -> None:
+        self._join()
+
+
 class LinearMap:
     """Linear fine-grained -> coarse-grained map given by its standard matrix.
 
@@ -173,6 +199,38 @@ class LinearMap:
                 "positions in input array. Check input and standard_matrix."
             )
         return K.like_input(raw, points)
+
+    def map_async(self, points):
+        """Start ``self(points)`` on a side stream and return a handle whose ``result()`` gives what
+        ``self(points)`` would (same NaN policy, same errors) -- or None when this map has no
+        deferred form (only slice maps with NaN handling do: a gather plus a NaN scan of its output).
+
+        Used by ``project_forces``: the coordinate map does not depend on the fitted force map, so its
+        (HBM-bound) gather overlaps the fit instead of following it.
+        """
+        shape = tuple(points.shape)
+        if len(shape) != 3 or shape[2] != self.n_dim or shape[1] != self.n_fg_sites:
+            return None
+        idx = self._onehot_index()
+        if idx is None or not self.handle_nans:
+            return None
+        import torch
+
+        out_t = K.torch_dtype(self._out_dtype(points))
+        p = K.as_device(points)
+        key = ("idx", str(p.device))
+        hit = self._dev_cache.get(key)
+        if hit is None or hit[0] is not self._standard_matrix:
+            hit = (self._standard_matrix, torch.from_numpy(idx).to(p.device))
+            self._dev_cache[key] = hit
+        main = torch.cuda.current_stream(p.device)
+        side = K.side_stream(p.device)
+        side.wait_stream(main)
+        with torch.cuda.stream(side):
+            out = K.slice_gather(p, hit[1], out_t)
+            flag = K.nan_flag(out)
+        p.record_stream(side)
+        return _PendingMap(out, flag, side, points)
 
     def flat_call(self, flattened):
         """Apply to (n_frames, n_fg_sites*3) and return (n_frames, n_cg_sites*3)."""
