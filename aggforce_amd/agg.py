@@ -47,6 +47,17 @@ def force_smoothness(array, comm=None) -> float:
     return float(s / n) if n else float("nan")
 
 
+def _mean_square(sumsq, count: int, comm=None) -> float:
+    """mean of squares from a device sum and an element count (summed over the ranks with ``comm``)."""
+    import torch
+
+    acc = torch.cat([sumsq.reshape(1).to(torch.float64),
+                     torch.tensor([float(count)], dtype=torch.float64, device=sumsq.device)])
+    all_reduce_sum_(acc, comm)
+    s, n = acc.tolist()
+    return float(s / n) if n else float("nan")
+
+
 def project_forces(
     coords,
     forces,
@@ -77,10 +88,15 @@ def project_forces(
         # the coordinate map does not depend on the fit: a slice map's gather runs on a side stream
         # underneath the Gram / solve kernels instead of after them
         pending = coord_map.map_async(t.coords) if isinstance(coord_map, LinearMap) else None
+        fused_ss = None  # sum of squares of the mapped forces when the apply kernel accumulated it
         try:
             traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
             if pending is not None and type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map:
-                mapped_forces = traj_map.force_map(t.forces)
+                fmap = traj_map.force_map
+                if isinstance(fmap, LinearMap):
+                    mapped_forces, fused_ss = fmap.call_with_sumsq(t.forces)
+                else:
+                    mapped_forces = fmap(t.forces)
                 mapped_coords = pending.result()
                 pending = None
             else:
@@ -89,7 +105,10 @@ def project_forces(
         finally:
             if pending is not None:
                 pending.discard()
-        residual = force_smoothness(mapped_forces, comm=kwargs.get("comm"))
+        if fused_ss is not None:
+            residual = _mean_square(fused_ss, int(np.prod(mapped_forces.shape)), kwargs.get("comm"))
+        else:
+            residual = force_smoothness(mapped_forces, comm=kwargs.get("comm"))
     return {
         PROJCOORDS_KNAME: mapped_coords,
         PROJFORCES_KNAME: mapped_forces,

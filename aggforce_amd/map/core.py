@@ -200,6 +200,25 @@ class LinearMap:
             )
         return K.like_input(raw, points)
 
+    def call_with_sumsq(self, points):
+        """``(self(points), s)`` with ``s`` the device scalar sum of squares of the result, accumulated
+        by the apply kernel itself (fixed order) -- or ``s = None`` when the fused form does not apply
+        (slice maps, NaNs in the input, handle_nans off): then the caller reduces the result itself."""
+        import torch
+
+        shape = tuple(points.shape)
+        if (len(shape) != 3 or shape[2] != self.n_dim or shape[1] != self.n_fg_sites or not self.handle_nans
+                or self._onehot_index() is not None):
+            return self(points), None
+        out_t = K.torch_dtype(self._out_dtype(points))
+        p = K.as_device(points)
+        m = self._device_matrix(out_t, p.device)
+        probe = torch.zeros(1, dtype=torch.int32, device=p.device)
+        out, ss = K.linearmap_apply(p, m, want_sumsq=True, nan_probe=probe)
+        if bool(probe.item()):
+            return self(points), None  # NaN policy: the reference's two extra products (rare)
+        return K.like_input(out, points), ss
+
     def map_async(self, points):
         """Start ``self(points)`` on a side stream and return a handle whose ``result()`` gives what
         ``self(points)`` would (same NaN policy, same errors) -- or None when this map has no
