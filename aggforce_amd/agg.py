@@ -85,12 +85,15 @@ def project_forces(
         constrained_inds = guess_pairwise_constraints(coords)
     with K.upload_cache():
         t = Trajectory(coords=coords, forces=forces)
-        # the coordinate map does not depend on the fit: a slice map's gather runs on a side stream
-        # underneath the Gram / solve kernels instead of after them
-        pending = coord_map.map_async(t.coords) if isinstance(coord_map, LinearMap) else None
+        pending = None
         fused_ss = None  # sum of squares of the mapped forces when the apply kernel accumulated it
         try:
             traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
+            # a slice map's gather (HBM-bound) goes to a side stream underneath the force apply (MFMA-bound):
+            # c3 869 ms/step against 874-878 one after the other; started before the fit it slows the
+            # Gram kernel by as much as it saves (872-876)
+            if isinstance(coord_map, LinearMap):
+                pending = coord_map.map_async(t.coords)
             if pending is not None and type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map:
                 fmap = traj_map.force_map
                 if isinstance(fmap, LinearMap):
