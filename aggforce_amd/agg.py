@@ -85,16 +85,16 @@ def project_forces(
         constrained_inds = guess_pairwise_constraints(coords)
     with K.upload_cache():
         t = Trajectory(coords=coords, forces=forces)
-        pending = None
         fused_ss = None  # sum of squares of the mapped forces when the apply kernel accumulated it
-        try:
-            traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
+        traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
+        pending = None
+        if type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map and isinstance(coord_map, LinearMap):
             # a slice map's gather (HBM-bound) goes to a side stream underneath the force apply (MFMA-bound):
             # c3 869 ms/step against 874-878 one after the other; started before the fit it slows the
             # Gram kernel by as much as it saves (872-876)
-            if isinstance(coord_map, LinearMap):
-                pending = coord_map.map_async(t.coords)
-            if pending is not None and type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map:
+            pending = coord_map.map_async(t.coords)
+        if pending is not None:
+            try:
                 fmap = traj_map.force_map
                 if isinstance(fmap, LinearMap):
                     mapped_forces, fused_ss = fmap.call_with_sumsq(t.forces)
@@ -102,12 +102,12 @@ def project_forces(
                     mapped_forces = fmap(t.forces)
                 mapped_coords = pending.result()
                 pending = None
-            else:
-                mapped = traj_map(t)
-                mapped_coords, mapped_forces = mapped.coords, mapped.forces
-        finally:
-            if pending is not None:
-                pending.discard()
+            finally:
+                if pending is not None:
+                    pending.discard()
+        else:
+            mapped = traj_map(t)
+            mapped_coords, mapped_forces = mapped.coords, mapped.forces
         if fused_ss is not None:
             residual = _mean_square(fused_ss, int(np.prod(mapped_forces.shape)), kwargs.get("comm"))
         else:
