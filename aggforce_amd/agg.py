@@ -91,7 +91,7 @@ def project_forces(
         if type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map and isinstance(coord_map, LinearMap):
             # a slice map's gather (HBM-bound) goes to a side stream underneath the force apply (MFMA-bound):
             # c3 869 ms/step against 874-878 one after the other; started before the fit it slows the
-            # Gram kernel by as much as it saves (872-876)
+            # Gram kernel by as much as it saves (872-876), underneath the solve it doubles the solve (874-876)
             pending = coord_map.map_async(t.coords)
         if pending is not None:
             try:
