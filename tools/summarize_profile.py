@@ -24,7 +24,7 @@ if stats:
              "avg_ms": float(r["AverageNs"]) / 1e6, "pct": float(r["Percentage"])} for r in rows]
     keep.sort(key=lambda x: -x["total_ms"])
     summary["kernel_stats"] = keep[:25]
-for name in ("fetch", "write", "dram"):
+for name in ("fetch", "write", "dram", "mfma"):
     f = find(name, "*counter_collection.csv")
     if not f:
         continue
@@ -40,6 +40,6 @@ for name in ("fetch", "write", "dram"):
 json.dump(summary, open(os.path.join(out_dir, f"{tag}_summary.json"), "w"), indent=1)
 g = [k for k in summary.get("kernel_stats", []) if "gram_tile" in k["kernel"]]
 print("gram kernel:", g[:2])
-for name in ("fetch", "write", "dram"):
+for name in ("fetch", "write", "dram", "mfma"):
     for e in summary.get(f"pmc_{name}", [])[:3]:
         print(name, json.dumps(e)[:400])
