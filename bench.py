@@ -76,6 +76,18 @@ def profiled_traffic(workload, world):
         return None
 
 
+def profiled_mfma_busy(workload, world):
+    """Fraction of the Gram kernel's cycles in which the MFMA pipes were busy, from the committed PMC pass
+    (profiles/r01_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    if workload != "c3" or world != 1:
+        return None
+    try:
+        d = json.load(open(os.path.join(ROOT, "profiles", "r01_c3_mfma_counters.json")))
+        return [v["mfma_utilisation"] for k, v in d["kernels"].items() if "gram_tile" in k][0]
+    except Exception:
+        return None
+
+
 def blas_threads():
     try:
         from threadpoolctl import threadpool_info
@@ -255,6 +267,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_TFLOPS[gdt],
                 "traffic": profiled_traffic(args.workload, world),
+                "mfma_busy_frac_pmc": profiled_mfma_busy(args.workload, world),
                 "ms_per_launch": gram_ms,
                 "flops_per_launch": flops,
             },
