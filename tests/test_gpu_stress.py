@@ -57,3 +57,27 @@ def test_random_k6_and_k5_sweeps_match_oracle(monkeypatch, capsys):
     mod.sweep_k5(rng, 40)
     out = capsys.readouterr().out
     assert "40 K6 cases ok" in out and "40 K5 cases ok" in out
+
+
+def test_bench_contract_on_tiny_workload():
+    """bench.py prints exactly one JSON line on stdout with the fields the driver reads."""
+    import json
+    import subprocess
+
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "tiny", "--steps", "2",
+                          "--warmup", "1", "--cpu-frames", "64"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    lines = [ln for ln in out.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert key in d, key
+    assert d["unit"] == "frames/s" and d["n_gpus"] == 1 and d["steps"] == 2 and d["warmup"] == 1
+    assert d["higher_is_better"] is True and d["scaling"] in ("weak", "strong") and d["vs_baseline"] is None
+    assert d["value"] > 0 and d["ms_per_step"] > 0 and "workload" in d["config"]
+    r = d["roofline"]
+    assert r["bound"] in ("hbm", "mfma") and r["unit"] in ("GB/s", "TFLOP/s")
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
+    c = d["cpu_baseline"]
+    assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
