@@ -263,3 +263,21 @@ def test_integration_stub_matches_the_abi():
     for name in ("aggf_gram", "aggf_gram_workspace_bytes", "aggf_eq_qp_solve", "aggf_eq_qp_workspace_bytes",
                  "aggf_linearmap_apply"):
         assert len(getattr(ns["_l"], name).argtypes) == len(_lib.PROTOTYPES[name][1]), name
+
+
+def test_constraint_layout_random_sets_match_oracle():
+    """The reduced-variable layout (column order of the reference's make_bond_constraint_matrix) for
+    random constraint sets: overlapping pairs, chains, larger groups, duplicates."""
+    rng = np.random.default_rng(20260101)
+    for _ in range(300):
+        n = int(rng.integers(2, 60))
+        cons = set()
+        for _ in range(int(rng.integers(0, n))):
+            size = int(rng.choice([2, 2, 2, 3, 4]))
+            if size <= n:
+                cons.add(frozenset(int(i) for i in rng.choice(n, size=size, replace=False)))
+        assert reduce_constraint_sets(cons) == orc.reduce_constraint_sets(cons)
+        C = make_bond_constraint_matrix(n, cons)
+        assert np.array_equal(C, orc.make_bond_constraint_matrix(n, cons))
+        goa, n_red = group_layout(n, cons)
+        assert C.shape == (n, n_red) and np.all(C[np.arange(n), goa] == 1) and C.sum() == n
