@@ -141,3 +141,43 @@ def test_fused_fit_larger_system_runs_and_reduces_residual():
     lin = project_forces(coords, forces, cmap, constrained_inds=cons, l2_regularization=0.0)
     assert np.isfinite(res["residual"]) and res["residual"] < lin["residual"] * 1.02
     assert len(res["tmap"].force_map.tags["coef_list"]) == n_cg
+
+
+def test_gb_feat_random_sweep_matches_oracle():
+    """gb_feat features and divergences (K4) for random geometries, constraint sets, bases and flags."""
+    rng = np.random.default_rng(77)
+    worst_f = worst_d = 0.0
+    for case in range(30):
+        N = int(rng.integers(6, 28))
+        T = int(rng.integers(1, 25))
+        dtype = rng.choice([np.float32, np.float64])
+        coords = (7 * rng.random((T, N, 3)) + 1).astype(dtype)
+        cons = set()
+        for _ in range(int(rng.integers(0, N // 2))):
+            size = int(rng.choice([2, 2, 3]))
+            cons.add(frozenset(int(i) for i in rng.choice(N, size=size, replace=False)))
+        n_cg = int(rng.integers(1, 5))
+        # two-atom sites with distinct weights: a site never coincides with a (smeared) atom position
+        cmat = np.zeros((n_cg, N))
+        for c in range(n_cg):
+            i, j = rng.choice(N, size=2, replace=False)
+            cmat[c, i], cmat[c, j] = 0.37, 0.63
+        cmap = LinearMap(cmat)
+        ids = constraint_group_labels(N, cons)
+        drop_last = bool(rng.random() < 0.5)
+        if drop_last and int(ids.max()) == 0:
+            drop_last = False  # a single group with the last channel dropped leaves no channels
+        kw = dict(outer=float(rng.choice([6.0, 9.0])), inner=float(rng.choice([0.0, 1.5])),
+                  n_basis=int(rng.integers(1, 7)), width=float(rng.choice([0.7, 1.0, 1.8])),
+                  dist_power=float(rng.choice([0.5, 1.0])))
+        res = gb_feat(coords, cmap, cons, lazy=False, drop_last_channel=drop_last, **kw)
+        n_ch = int(ids.max()) + (0 if drop_last else 1)
+        of, od = oracle_feats(coords, cmat, cons, ids, n_ch, **kw)
+        for c in range(n_cg):
+            f, d = res["feats"][c], res["divs"][c]
+            assert f.shape == of[c].shape and d.shape == od[c].shape, (case, f.shape, of[c].shape)
+            if not (np.isfinite(of[c]).all() and np.isfinite(od[c]).all()):
+                continue  # r == 0 by coincidence: the reference's NaN
+            worst_f = max(worst_f, float(np.max(np.abs(f - of[c]))))
+            worst_d = max(worst_d, float(np.max(np.abs(d - od[c]))))
+    assert worst_f < 5e-6 and worst_d < 1e-4, (worst_f, worst_d)
