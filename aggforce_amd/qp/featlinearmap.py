@@ -135,17 +135,63 @@ class Multifeaturize:
         return "\n".join(lines)
 
 
+def _reference_group_order(n_fg_sites: int, constraints: Constraints) -> List[frozenset]:
+    """Merged constraint groups (singletons included) in the order the reference labels them.
+
+    The reference's labels are positions in ``sorted(reduce_constraint_sets(groups))``
+    (featlinearmap.py:598-602).  ``<`` between disjoint frozensets is never true, so that sort
+    keeps the iteration order of the set the flood search returns -- and that order is a
+    property of CPython's hash tables (frozensets of ints hash deterministically, so it is
+    reproducible): which seed ``pop()`` yields next, and where a completed group lands in the
+    result set, depend on every insertion, removal and *resize* the containers went through
+    (``difference_update`` compacts a table once a quarter of its slots are tombstones, which
+    reshuffles what ``pop()`` sees next).  Bit-identical labels therefore need the same trace
+    of container operations as constraints/tools.py:49-77 on the same kind of container:
+
+    * the working set: ``constraints`` rebuilt in iteration order (what ``deepcopy`` does to a
+      set), then the singletons ``{0}, {1}, ...`` added in site order (featlinearmap.py:598-599);
+    * a ``.copy()`` of it is the pool; per merged group: one ``pop()``, then one
+      ``difference_update`` per flood round -- the rounds that absorb something and the two
+      empty ones that end a group -- and one ``add`` of the finished group to the result set.
+
+    Which member sets a round absorbs is looked up through a site -> member-set index here
+    (the reference rescans the whole pool each round, O(N^2) for N sites); only the trace above
+    matters for the order, and it is the same.
+    """
+    working = set(list(constraints)).union(frozenset([site]) for site in range(n_fg_sites))
+    pool = working.copy()
+    if len(working) <= 1:  # returned untouched by the reference (constraints/tools.py:52-53)
+        return sorted(pool)
+    sets_of_site: dict = {}
+    for member_set in working:
+        for site in member_set:
+            sets_of_site.setdefault(site, []).append(member_set)
+    finished: set = set()
+    while pool:
+        grown = set(pool.pop())
+        frontier = list(grown)
+        quiet_rounds = 0
+        while quiet_rounds < 2:
+            absorbed = {m for site in frontier for m in sets_of_site.get(site, ()) if m in pool}
+            pool.difference_update(list(absorbed))
+            frontier = [site for m in absorbed for site in m if site not in grown]
+            grown.update(frontier)
+            if not absorbed:
+                quiet_rounds += 1
+        finished.add(frozenset(grown))
+    return sorted(finished)
+
+
 def constraint_group_labels(n_fg_sites: int, constraints: Constraints) -> np.ndarray:
     """int32 label of every fg site; constrained sites share a label.
 
-    Labels are numbered by the smallest member of each merged group, in ascending order.
-    (The reference's label order is CPython's set iteration order, featlinearmap.py:598-609 --
-    an arbitrary but fixed permutation of the feature columns, which does not change the
-    optimised map.)
+    Bit-identical to the reference's ``id_feat(..., return_ids=True)`` (featlinearmap.py:598-609),
+    including its label ORDER (see ``_reference_group_order``): the order decides which feature
+    column belongs to which group and, through ``max_channels = max(ids)`` (jaxfeat.py:115),
+    which group ``gb_feat`` leaves without Gaussian features.
     """
-    groups = set(constraints) | {frozenset([x]) for x in range(n_fg_sites)}
     ids = np.zeros(n_fg_sites, dtype=np.int32)
-    for label, members in enumerate(sorted(reduce_constraint_sets(groups), key=min)):
+    for label, members in enumerate(_reference_group_order(n_fg_sites, constraints)):
         ids[list(members)] = label
     return ids
 

@@ -20,9 +20,9 @@ Two ways to use it, both drop-in:
 
 Reference quirk kept by default (``drop_last_channel=True``): the reference allocates
 ``max(ids)`` channels (jaxfeat.py:115), one fewer than the number of labels, so the
-last-labelled constraint group gets no Gaussian features (Quirk A).  Labels here
-are numbered by smallest member (``constraint_group_labels``); the reference's order is
-CPython's set order, an arbitrary permutation.
+last-labelled constraint group gets no Gaussian features (Quirk A).  Labels are
+the reference's own, order included (``constraint_group_labels`` reproduces id_feat's labels
+bit for bit), so the group that loses its features is the one the reference drops.
 """
 from typing import List, Optional, Tuple
 

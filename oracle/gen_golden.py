@@ -387,12 +387,77 @@ def g6():
     np.savez_compressed(os.path.join(OUT, "g6_augmented.npz"), **out)
 
 
+# ---------------------------------------------------------------- G8 id_feat label order
+def ordered_cons_array(members):
+    """Constraint sets IN INSERTION ORDER, members as written -> (n, w) int array padded with -1.
+
+    The label order of the reference's id_feat depends on the hash-table layout of the
+    constraint set it is handed, hence on how that set was built; tests rebuild it with
+    ``build_cons`` from exactly this array."""
+    width = max([len(m) for m in members], default=1)
+    arr = -np.ones((len(members), max(width, 1)), dtype=np.int64)
+    for i, m in enumerate(members):
+        arr[i, : len(m)] = m
+    return arr
+
+
+def build_cons(arr):
+    cons = set()
+    for row in arr:
+        cons.add(frozenset(int(x) for x in row if x >= 0))
+    return cons
+
+
+def g8():
+    print("G8 id_feat labels (reference order) on random constraint sets and CLN025")
+    rng = np.random.default_rng(SEED + 8)
+    cases = []
+    for n in (1, 2, 3, 5, 8, 8, 12, 17, 17, 24, 33, 40, 64, 64, 97, 128, 175, 200, 256, 300, 512, 1024):
+        members = []
+        for _ in range(int(rng.integers(0, max(1, n)))):
+            size = int(rng.choice([2, 2, 2, 3, 4]))
+            if n >= size:
+                members.append([int(x) for x in rng.choice(n, size=size, replace=False)])
+        cases.append((n, members))
+    # chains (multi-round floods), a star, everything in one group, nothing constrained
+    cases.append((50, [[i, i + 1] for i in range(49) if i % 7]))
+    cases.append((400, [[i + 1, i] for i in range(398, -1, -1) if i % 11]))
+    cases.append((30, [[0, i] for i in range(1, 30)]))
+    cases.append((9, [list(range(9))]))
+    cases.append((77, []))
+    # the C4 bench pattern: pairs {3i, 3i+1}
+    cases.append((1024, [[3 * i, 3 * i + 1] for i in range(341)]))
+    # CLN025: the 59 recovered constraint groups, as anchor-member pairs (g4's set) and as whole groups
+    g4d = np.load(os.path.join(OUT, "g4_cln025.npz"))
+    cln_pairs = [[int(x) for x in row if x >= 0] for row in g4d["pairs"]]
+    cases.append((175, cln_pairs))
+    groups = {}
+    for a, b in cln_pairs:
+        groups.setdefault(min(a, b), {min(a, b)}).add(max(a, b))
+    cases.append((175, [sorted(v) for v in groups.values()]))
+    out = {"n_cases": len(cases)}
+    for k, (n, members) in enumerate(cases):
+        arr = ordered_cons_array(members)
+        cons = build_cons(arr)
+        cmap = LinearMap([[0]], n_fg_sites=n)
+        ids = id_feat(np.zeros((1, n, 3), np.float32), cmap, cons, return_ids=True)
+        assert ids.dtype == np.int32
+        check(f"id_feat ids case {k} (n={n}, {len(members)} sets)", ids, orc.id_feat_ids(n, build_cons(arr)),
+              rtol=0, atol=0)
+        out[f"c{k}__n"] = n
+        out[f"c{k}__cons"] = arr
+        out[f"c{k}__ids"] = ids
+        if n <= 24:
+            feats = id_feat(np.zeros((2, n, 3), np.float32), cmap, cons)["feats"][0]
+            out[f"c{k}__feats"] = feats
+    np.savez_compressed(os.path.join(OUT, "g8_id_labels.npz"), **out)
+
+
+
 if __name__ == "__main__":
     print("reference package:", os.path.dirname(aggforce.__file__))
-    g1()
-    g2()
-    g3()
-    g4()
-    g5()
-    g6()
+    only = sys.argv[1:]
+    for fn in (g1, g2, g3, g4, g5, g6, g8):
+        if not only or fn.__name__ in only:
+            fn()
     print("fixtures written to", OUT)

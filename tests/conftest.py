@@ -27,3 +27,12 @@ def golden():
 def cons_from_array(arr):
     """Inverse of gen_golden.cons_to_array: (n, w) int array padded with -1 -> set of frozensets."""
     return {frozenset(int(x) for x in row if x >= 0) for row in arr}
+
+
+def cons_in_insertion_order(arr):
+    """Rebuild a constraint set exactly as oracle/gen_golden.py:build_cons did (one add per row, in
+    row order): the reference's id_feat label order depends on the set's hash-table layout."""
+    cons = set()
+    for row in arr:
+        cons.add(frozenset(int(x) for x in row if x >= 0))
+    return cons

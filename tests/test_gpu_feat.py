@@ -9,7 +9,6 @@ pytestmark = pytest.mark.gpu
 
 from aggforce_amd import LinearMap, Trajectory, project_forces  # noqa: E402
 from aggforce_amd.qp import Multifeaturize, gb_feat, id_feat, qp_feat_linear_map  # noqa: E402
-from aggforce_amd.qp.featlinearmap import constraint_group_labels  # noqa: E402
 from aggforce_amd.util import Curry  # noqa: E402
 from oracle import aggforce_oracle as orc  # noqa: E402
 
@@ -48,7 +47,7 @@ def test_gb_feat_dense_matches_oracle(with_cons, drop_last):
     if not with_cons:
         cons = set()
     cmap = LinearMap(cmat)
-    ids = constraint_group_labels(coords.shape[1], cons)
+    ids = orc.id_feat_ids(coords.shape[1], cons)  # the reference's labels: decides the dropped channel
     kw = dict(outer=8.0, inner=0.0, n_basis=5, width=1.0, dist_power=0.5)
     res = gb_feat(coords, cmap, cons, lazy=False, drop_last_channel=drop_last, **kw)
     n_ch = int(ids.max()) + (0 if drop_last else 1)
@@ -81,11 +80,11 @@ def test_fused_feat_fit_matches_dense_path_and_oracle(dtype):
     assert rel(cf, cd) < 2e-4
     mf, md = fused(traj), dense(traj)
     assert rel(mf.forces, md.forces) < 2e-4 and rel(mf.coords, md.coords) < 1e-6
-    # oracle: dense features in our label order, exact solve.  With several sampled frames the constraint
+    # oracle: dense features in the reference's label order, exact solve.  With several sampled frames the constraint
     # rows are nearly dependent (smallest singular value ~1e-3 of the largest) and the optimum moves with
     # float32-level feature differences, so the end-to-end comparison uses ONE constraint frame per site
     # (well conditioned); K4's regression matrix, the Gram and the solve are compared piecewise below.
-    ids = constraint_group_labels(coords.shape[1], cons)
+    ids = orc.id_feat_ids(coords.shape[1], cons)  # the reference's labels: decides the dropped channel
     G = int(ids.max()) + 1
     onehot = np.zeros((60, coords.shape[1], G), dtype=np.float32)
     onehot[:, np.arange(coords.shape[1]), ids] = 1
@@ -163,7 +162,7 @@ def test_gb_feat_random_sweep_matches_oracle():
             i, j = rng.choice(N, size=2, replace=False)
             cmat[c, i], cmat[c, j] = 0.37, 0.63
         cmap = LinearMap(cmat)
-        ids = constraint_group_labels(N, cons)
+        ids = orc.id_feat_ids(N, cons)
         drop_last = bool(rng.random() < 0.5)
         if drop_last and int(ids.max()) == 0:
             drop_last = False  # a single group with the last channel dropped leaves no channels

@@ -19,7 +19,7 @@ from aggforce_amd.map import smear_map
 from aggforce_amd.util import Curry, curry, flatten
 from aggforce_amd import _lib
 from oracle import aggforce_oracle as orc
-from conftest import ROOT, cons_from_array
+from conftest import ROOT, cons_from_array, cons_in_insertion_order
 
 CONS_CASES = [
     set(),
@@ -85,18 +85,31 @@ def test_uni_map_matches_saved_cln025(golden):
     assert np.array_equal(make_bond_constraint_matrix(175, cons_from_array(g["pairs"])), g["con_mat"])
 
 
-def test_id_feat_is_a_relabelling_of_the_reference(golden):
+def test_id_feat_labels_are_the_references(golden):
+    """Integer labels bit-identical to the reference's id_feat(..., return_ids=True), label ORDER
+    included (featlinearmap.py:598-609): g5 and the 30 reference-generated cases of g8."""
     g = golden("g5_feat_id.npz")
     cons = cons_from_array(g["cons"])
     cmap = LinearMap(g["coord_matrix"])
     ids = id_feat(g["coords"], cmap, cons, return_ids=True)
     ref = g["ids"]
-    assert ids.dtype == np.int32 and len(set(zip(ids, ref))) == len(set(ids)) == len(set(ref))
+    assert ids.dtype == np.int32 and np.array_equal(ids, ref)
+    g8 = golden("g8_id_labels.npz")
+    assert int(g8["n_cases"]) >= 20
+    for k in range(int(g8["n_cases"])):
+        n = int(g8[f"c{k}__n"])
+        cons_k = cons_in_insertion_order(g8[f"c{k}__cons"])
+        ours = id_feat(np.zeros((1, n, 3), np.float32), LinearMap([[0]], n_fg_sites=n), cons_k, return_ids=True)
+        assert ours.dtype == np.int32 and np.array_equal(ours, g8[f"c{k}__ids"]), k
+        assert np.array_equal(orc.id_feat_ids(n, cons_in_insertion_order(g8[f"c{k}__cons"])), g8[f"c{k}__ids"]), k
+        if f"c{k}__feats" in g8.files:
+            feats = id_feat(np.zeros((2, n, 3), np.float32), LinearMap([[0]], n_fg_sites=n), cons_k)["feats"][0]
+            assert feats.dtype == np.float32 and np.array_equal(feats, g8[f"c{k}__feats"]), k
     out = id_feat(g["coords"], cmap, cons)
     f = out["feats"]
     assert len(f) == 4 and f[0] is f[3] and f[0].shape == (48, 12, len(set(ids))) and f[0].dtype == np.float32
     assert np.all(f[0].sum(axis=2) == 1) and np.all(f[0][0, np.arange(12), ids] == 1)
-    assert np.array_equal(constraint_group_labels(5, {frozenset([3, 1])}), [0, 1, 2, 1, 3])
+    assert np.array_equal(constraint_group_labels(5, {frozenset([3, 1])}), orc.id_feat_ids(5, {frozenset([3, 1])}))
     z = Multifeaturize([id_feat, id_feat])(g["coords"], cmap, cons)
     assert isinstance(z, FeatZipper) and z["names"] is None
     joined = list(z["feats"])
