@@ -275,6 +275,16 @@ def side_stream(device) -> "torch.cuda.Stream":
     return st
 
 
+def side_streams(device, n: int) -> list:
+    """n auxiliary streams per device, created once (workspaces are cached per stream: fresh streams on
+    every call would pin a new set of scratch buffers each time)."""
+    key = (str(device), "pool")
+    pool = _side_streams.setdefault(key, [])
+    while len(pool) < n:
+        pool.append(torch.cuda.Stream(device=device))
+    return pool[:n]
+
+
 def has_nan(x: torch.Tensor) -> bool:
     l = lib()
     if x.numel() == 0:
@@ -459,6 +469,97 @@ def gb_apply(Fg, Pg, cg, sizes, n_id: int, n_ch: int, centers, width: float, cli
             "aggf_gb_apply",
         )
     return out
+
+
+# ------------------------------------------------------------------ K3c / K4b / K4c per-frame contractions
+
+
+def trjdot_frames(points: torch.Tensor, factor: torch.Tensor, trans: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t,c,d] = sum_f factor[t,c,f] points[t,f,d] (+ trans[t,c,d]); see aggf_trjdot_frames."""
+    T, N, D = points.shape
+    if D != 3 or factor.dim() != 3 or factor.shape[0] != T or factor.shape[2] != N:
+        raise ValueError(f"shape mismatch: points {tuple(points.shape)}, factor {tuple(factor.shape)}")
+    n_cg = factor.shape[1]
+    out_dtype = torch.promote_types(points.dtype, factor.dtype)
+    if trans is not None:
+        if tuple(trans.shape) != (T, n_cg, 3):
+            raise ValueError(f"shape mismatch: trans {tuple(trans.shape)}, expected {(T, n_cg, 3)}")
+        out_dtype = torch.promote_types(out_dtype, trans.dtype)
+        if out_dtype == torch.float64 and points.dtype == factor.dtype == torch.float32:
+            points = points.to(torch.float64)  # the kernel's out dtype is the promoted input dtype
+        trans = trans.to(out_dtype).contiguous()
+    out = torch.empty((T, n_cg, 3), dtype=out_dtype, device=points.device)
+    if T == 0 or n_cg == 0:
+        return out
+    with _timed("trjdot_frames"):
+        check(lib().aggf_trjdot_frames(ptr(points), dtype_code(points.dtype), ptr(factor), dtype_code(factor.dtype), T, N,
+                                       n_cg, ptr(trans), ptr(out), dtype_code(out_dtype), stream_ptr()),
+              "aggf_trjdot_frames")
+    return out
+
+
+def feat_contract(forces: torch.Tensor, feat: torch.Tensor, div: Optional[torch.Tensor], alpha: float,
+                  ld: Optional[int] = None) -> torch.Tensor:
+    """out (T, ld, 3): sum_a feat[t,a,f] F[t,a,d] + alpha div[t,f,d]; see aggf_feat_contract."""
+    T, N, _ = forces.shape
+    if feat.dim() != 3 or feat.shape[0] != T or feat.shape[1] != N:
+        raise ValueError(f"shape mismatch: forces {tuple(forces.shape)}, feats {tuple(feat.shape)}")
+    n_feat = feat.shape[2]
+    if div is not None:
+        if tuple(div.shape) != (T, n_feat, 3):
+            raise ValueError(f"shape mismatch: feats {tuple(feat.shape)}, divs {tuple(div.shape)}")
+        xdt = torch.promote_types(feat.dtype, div.dtype)
+        feat, div = feat.to(xdt).contiguous(), div.to(xdt).contiguous()
+    ld = n_feat if ld is None else int(ld)
+    out_dtype = torch.promote_types(forces.dtype, feat.dtype)
+    out = torch.empty((T, ld, 3), dtype=out_dtype, device=forces.device)
+    if T == 0:
+        return out
+    with _timed("feat_contract"):
+        check(lib().aggf_feat_contract(ptr(forces), dtype_code(forces.dtype), ptr(feat), ptr(div), dtype_code(feat.dtype),
+                                       float(alpha), T, N, n_feat, ld, ptr(out), dtype_code(out_dtype), stream_ptr()),
+              "aggf_feat_contract")
+    return out
+
+
+def feat_constraint_rows(feat: torch.Tensor, frame_idx: np.ndarray, M: torch.Tensor, site: int):
+    """(A (S*n_cg, n_feat), b (S*n_cg, 1)) float64 for one cg site; see aggf_feat_constraint_rows."""
+    T, N, n_feat = feat.shape
+    idx = np.asarray(frame_idx, dtype=np.int64).reshape(-1)
+    if idx.size == 0 or idx.min() < -T or idx.max() >= T:
+        raise IndexError("constraint frame index outside the trajectory")
+    idx = np.where(idx < 0, idx + T, idx)
+    n_cg = M.shape[0]
+    S = idx.size
+    idx_dev = torch.from_numpy(idx).to(feat.device)
+    A = torch.empty((S * n_cg, n_feat), dtype=torch.float64, device=feat.device)
+    b = torch.empty((S * n_cg, 1), dtype=torch.float64, device=feat.device)
+    check(lib().aggf_feat_constraint_rows(ptr(feat), dtype_code(feat.dtype), T, N, n_feat, ptr(idx_dev), S, ptr(M), n_cg,
+                                          int(site), ptr(A), ptr(b), stream_ptr()), "aggf_feat_constraint_rows")
+    return A, b
+
+
+def gb_constraint_rows(Mg: torch.Tensor, gauss: Optional[torch.Tensor], S: int, n_id: int, n_ch: int, n_basis: int,
+                       site: int, out_A: Optional[torch.Tensor] = None, out_b: Optional[torch.Tensor] = None):
+    """Constraint rows of the fused [id | gb] features; see aggf_gb_constraint_rows."""
+    n_cg, G = Mg.shape
+    n_feat = n_id + n_ch * n_basis
+    A = out_A if out_A is not None else torch.empty((S * n_cg, n_feat), dtype=torch.float64, device=Mg.device)
+    b = out_b if out_b is not None else torch.empty((S * n_cg, 1), dtype=torch.float64, device=Mg.device)
+    check(lib().aggf_gb_constraint_rows(ptr(Mg), ptr(gauss), S, n_cg, G, n_id, n_ch, n_basis, int(site), ptr(A), ptr(b),
+                                        stream_ptr()), "aggf_gb_constraint_rows")
+    return A, b
+
+
+def feat_weights(feat: torch.Tensor, coef: torch.Tensor, out: torch.Tensor, site: int) -> None:
+    """out[:, site, :] (T, n_cg, N float64) = feat (T, N, n_feat) . coef (n_feat); see aggf_feat_weights."""
+    T, N, n_feat = feat.shape
+    n_cg = out.shape[1]
+    if T == 0:
+        return
+    view = out[:, site, :]
+    check(lib().aggf_feat_weights(ptr(feat), dtype_code(feat.dtype), T, N, n_feat, ptr(coef), n_cg * N, view.data_ptr(),
+                                  stream_ptr()), "aggf_feat_weights")
 
 
 # ------------------------------------------------------------------ K6 pair-distance variance

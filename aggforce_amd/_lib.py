@@ -45,6 +45,11 @@ PROTOTYPES = {
     "aggf_gb_channels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),
     "aggf_gb_regmat": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, _vp]),
     "aggf_gb_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp]),
+    "aggf_trjdot_frames": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp]),
+    "aggf_feat_contract": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dbl, _i64, _i32, _i32, _i32, _vp, C.c_int, _vp]),
+    "aggf_feat_constraint_rows": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_gb_constraint_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_feat_weights": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "aggf_pair_dist_var_workspace_bytes": (_sz, [_i64, _i32]),
     "aggf_pair_dist_var": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _sz, _vp]),
     "aggf_gram_quadform_workspace_bytes": (_sz, [_i32, _i32]),
@@ -107,24 +112,30 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
-def stream_ptr() -> int:
-    return torch.cuda.current_stream().cuda_stream
+def stream_ptr(device=None) -> int:
+    """Raw hipStream_t of torch's current stream on ``device`` (default: the current device)."""
+    return torch.cuda.current_stream(device).cuda_stream
 
 
 _ws_cache: dict = {}
+_WS_MAX_PER_TAG = 6
 
 
 def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
     """A cached uint8 scratch tensor of at least nbytes (256-byte aligned by the allocator).
 
-    One buffer per (device, tag, current stream): calls issued on different streams never share scratch."""
+    One buffer per (device, tag, current stream): calls issued on different streams never share scratch.
+    The cache keeps at most ``_WS_MAX_PER_TAG`` buffers per (device, tag), least recently used first out,
+    so work spread over many streams cannot pin HBM for ever."""
     key = (str(device), tag, torch.cuda.current_stream(device).cuda_stream)
-    w = _ws_cache.get(key)
+    w = _ws_cache.pop(key, None)
     if w is None or w.numel() < nbytes:
-        _ws_cache.pop(key, None)
         w = None
         w = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
-        _ws_cache[key] = w
+    _ws_cache[key] = w  # most recently used last
+    same = [k for k in _ws_cache if k[0] == key[0] and k[1] == tag]
+    for old in same[: max(0, len(same) - _WS_MAX_PER_TAG)]:
+        del _ws_cache[old]
     return w
 
 

@@ -306,7 +306,8 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
   const int m_vec_ok = (((uintptr_t)Mx & 15) == 0) && (((int64_t)N * sizeof(TC)) % 16 == 0);
   const size_t lds = (size_t)2 * (TF * AP_XS + TCB * AP_MS) * sizeof(TC);
   if (lds > 65536) {
-    static thread_local bool done_t = false, done_f = false;
+    static thread_local PerDeviceOnce once_t, once_f;
+    bool &done_t = *once_t.flag(), &done_f = *once_f.flag();
     if (!done_t) {
       AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_kernel<TIn, TC, true, THREADS, TCB, WFR>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));

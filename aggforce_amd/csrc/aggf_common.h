@@ -33,6 +33,17 @@ static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * 
 static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 int device_cu_count();
 
+// One flag per (call site, device): hipFuncSetAttribute applies to the CURRENT device only, so a
+// process that drives several GPUs must repeat it on each of them.
+struct PerDeviceOnce {
+  bool done[64] = {};
+  bool* flag() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) dev = 0;
+    return &done[dev];
+  }
+};
+
 typedef double __attribute__((ext_vector_type(4))) f64x4;
 typedef float __attribute__((ext_vector_type(4))) f32x4;
 

@@ -909,7 +909,8 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
   if (p.staging == STAGE_PAIR) {
     const size_t lds = (size_t)PAIR_NBUF * PAIR_SLOTS * KB * ROW_STRIDE * sizeof(T);  // 153.6 KB
-    static thread_local bool attr_done = false;
+    static thread_local PerDeviceOnce attr_once;
+    bool& attr_done = *attr_once.flag();
     if (!attr_done) {
       AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_pair_dma_kernel<T>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -930,7 +931,8 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   }
   if (p.staging == STAGE_DMA8) {
     const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);
-    static thread_local bool attr_done = false;
+    static thread_local PerDeviceOnce attr_once;
+    bool& attr_done = *attr_once.flag();
     if (!attr_done) {
       AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
@@ -949,7 +951,8 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   const bool use_dma = p.staging == STAGE_DMA;
   if (use_dma) {
     const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);  // 3-stage ring, 76.8 KB
-    static thread_local bool attr_done = false;
+    static thread_local PerDeviceOnce attr_once;
+    bool& attr_done = *attr_once.flag();
     if (!attr_done) {
       AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T>,
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));

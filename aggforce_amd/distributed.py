@@ -52,3 +52,60 @@ def frame_shard(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     base, extra = divmod(n_frames, world)
     begin = rank * base + min(rank, extra)
     return begin, begin + base + (1 if rank < extra else 0)
+
+
+def shard_extent(n_local: int, comm, device) -> Tuple[int, int]:
+    """(first global frame of this rank's shard, total frames): shards are contiguous in rank order."""
+    group = resolve_comm(comm)
+    if group is None:
+        return 0, n_local
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    sizes = torch.zeros(world, dtype=torch.int64, device=device)
+    sizes[dist.get_rank(group)] = n_local
+    if world > 1:
+        dist.all_reduce(sizes, op=dist.ReduceOp.SUM, group=group)
+    sizes = sizes.cpu()
+    return int(sizes[: dist.get_rank(group)].sum()), int(sizes.sum())
+
+
+def agree_on_indices(idx, comm, device):
+    """Rank 0's integer index array on every rank (an unseeded draw differs between ranks)."""
+    import numpy as np
+
+    group = resolve_comm(comm)
+    idx = np.ascontiguousarray(np.asarray(idx, dtype=np.int64))
+    if group is None:
+        return idx
+    import torch.distributed as dist
+
+    if dist.get_world_size(group) == 1:
+        return idx
+    t = torch.from_numpy(idx).to(device)
+    dist.broadcast(t, src=dist.get_global_rank(group, 0), group=group)
+    return t.cpu().numpy()
+
+
+def take_global_frames(local: torch.Tensor, global_idx, comm) -> torch.Tensor:
+    """Frames ``global_idx`` (numbered over the whole frame-sharded trajectory) of the array whose
+    shard on this rank is ``local`` -- the same tensor, bit for bit, on every rank.
+
+    Each rank fills in the frames it owns and the zero-filled buffers are summed (x + 0 is exact),
+    so e.g. the constraint rows of the featurised fit are built from identical inputs everywhere
+    and the replicated solve really is replicated.
+    """
+    import numpy as np
+
+    idx = np.asarray(global_idx, dtype=np.int64).reshape(-1)
+    group = resolve_comm(comm)
+    first, total = shard_extent(local.shape[0], comm, local.device)
+    if idx.size and (idx.min() < 0 or idx.max() >= total):
+        raise IndexError(f"frame index outside 0..{total - 1}")
+    if group is None:
+        return local[torch.from_numpy(idx).to(local.device)]
+    out = torch.zeros((idx.size,) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+    mine = np.nonzero((idx >= first) & (idx < first + local.shape[0]))[0]
+    if mine.size:
+        out[torch.from_numpy(mine).to(local.device)] = local[torch.from_numpy(idx[mine] - first).to(local.device)]
+    return all_reduce_sum_(out, group)

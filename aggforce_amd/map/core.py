@@ -333,4 +333,8 @@ class CLAMap(_Taggable):
     def __call__(self, points, copoints):
         if self._apply is not None:
             return self._apply(points, copoints)
-        return trjdot(points, self.scale(copoints)) + self.trans(copoints)
+        from .. import _kernels as K
+
+        # trjdot(points, scale) + trans (reference map/core.py:428-430) in one pass of kernel K3c
+        out = K.trjdot_frames(K.as_device(points), K.as_device(self.scale(copoints)), K.as_device(self.trans(copoints)))
+        return K.like_input(out, points)

@@ -21,7 +21,7 @@ from typing_extensions import TypedDict
 
 from .. import _kernels as K
 from ..constraints import Constraints, reduce_constraint_sets
-from ..distributed import all_reduce_sum_
+from ..distributed import agree_on_indices, all_reduce_sum_, shard_extent, take_global_frames
 from ..map import CLAFTMap, CLAMap, LinearMap
 from ..trajectory import Trajectory
 from .qplinear import DEFAULT_SOLVER_OPTIONS, SolverOptions
@@ -216,26 +216,21 @@ def id_feat(points, cmap: LinearMap, constraints: Constraints, return_ids: bool 
 # ----------------------------------------------------------------------------------------
 
 
-def _constraint_rows(feat_dev, cg_ind: int, M_dev, frame_idx):
+def _constraint_rows(feat_dev, cg_ind: int, M_dev, frame_idx, comm=None):
     """A[(s,c), f] = sum_a M[c,a] feat[s,a,f] on the sampled frames, and the one-hot target b
-    (reference _constr_arrays, featlinearmap.py:445-459)."""
-    import torch
+    (reference _constr_arrays, featlinearmap.py:445-459) -- kernel K4b.  ``frame_idx`` numbers
+    frames over the whole trajectory; with frames sharded over ``comm`` the sampled feature
+    frames are first assembled identically on every rank."""
+    idx = np.asarray(frame_idx, dtype=np.int64).reshape(-1)
+    if comm is not None:
+        sub = take_global_frames(feat_dev, idx, comm)
+        return K.feat_constraint_rows(sub, np.arange(idx.size), M_dev, cg_ind)
+    return K.feat_constraint_rows(feat_dev, idx, M_dev, cg_ind)
 
-    sub = feat_dev[torch.as_tensor(np.asarray(frame_idx), device=feat_dev.device)].to(torch.float64)
-    mult = torch.matmul(M_dev.unsqueeze(0), sub)  # (s, n_cg, n_feat)
-    target = torch.zeros((sub.shape[0], M_dev.shape[0]), dtype=torch.float64, device=feat_dev.device)
-    target[:, cg_ind] = 1
-    return mult.reshape(-1, mult.shape[-1]).contiguous(), target.reshape(-1, 1).contiguous()
 
-
-def _site_regression(forces_dev, feat_dev, div_dev, kbt: float):
-    """R3[t,f,d] = sum_a feat[t,a,f] F[t,a,d] + kbt div[t,f,d]  -- (T, n_feat, 3), contiguous."""
-    import torch
-
-    dt = torch.promote_types(torch.promote_types(forces_dev.dtype, feat_dev.dtype), div_dev.dtype)
-    r3 = torch.bmm(feat_dev.to(dt).transpose(1, 2), forces_dev.to(dt))
-    r3.add_(div_dev.to(dt), alpha=float(kbt))
-    return r3.contiguous()
+def _site_regression(forces_dev, feat_dev, div_dev, kbt: float, ld: Optional[int] = None):
+    """R3[t,f,d] = sum_a feat[t,a,f] F[t,a,d] + kbt div[t,f,d]  -- (T, ld >= n_feat, 3), kernel K4c."""
+    return K.feat_contract(forces_dev, feat_dev, div_dev, kbt, ld)
 
 
 def qp_feat_linear_map(
@@ -261,9 +256,10 @@ def qp_feat_linear_map(
     "divs": per-site (T, n_feat, 3), "names"}.  Extras: ``frame_indices`` (one index array per
     cg site) or ``rng`` (numpy Generator) make the sampled constraint frames reproducible --
     the reference draws them from an unseeded generator (featlinearmap.py:445); ``comm`` shards
-    frames over ranks (the sampled constraint frames are then taken from each rank's shard and
-    must be given identically on every rank through ``frame_indices`` of rank-local frames);
-    ``fused=False`` forces the generic dense-feature path even for the built-in featurisers.
+    frames over ranks: frame indices then number the WHOLE trajectory, rank 0's draw is used on
+    every rank and each sampled frame comes from the rank that owns it, so all ranks solve the
+    same problem and hold the same coefficients; ``fused=False`` forces the generic
+    dense-feature path even for the built-in featurisers.
 
     Returns ``CLAFTMap(coord_map, CLAMap)`` with tags {"feat_names", "coef_list"}.
     """
@@ -283,23 +279,26 @@ def qp_feat_linear_map(
     gen = np.random.default_rng() if rng is None else rng
     coefs: List[np.ndarray] = []
     used_frames: List[np.ndarray] = []
+    _, n_frames_total = shard_extent(forces.shape[0], comm, dev)
     for ind, (feat, div) in enumerate(zip(feats, divs)):
         feat_dev = K.as_device(feat)
         div_dev = K.as_device(div)
         if frame_indices is not None:
             idx = np.asarray(frame_indices[ind])
         else:
-            idx = gen.choice(feat_dev.shape[0], size=n_constraint_frames, replace=False)
+            idx = gen.choice(n_frames_total, size=n_constraint_frames, replace=False)
+        idx = agree_on_indices(idx, comm, dev)
         used_frames.append(idx)
-        A, b = _constraint_rows(feat_dev, ind, M_dev, idx)
-        r3 = _site_regression(forces, feat_dev, div_dev, kbt)
-        G = K.gram(r3, None, None, r3.shape[1], torch.float64)  # exact Gram of R (see qp/gbfeat.py)
+        A, b = _constraint_rows(feat_dev, ind, M_dev, idx, comm)
+        n_feat = feat_dev.shape[2]
+        r3 = _site_regression(forces, feat_dev, div_dev, kbt, ld=-(-n_feat // 128) * 128)  # K1's in-place layout
+        G = K.gram(r3, None, None, n_feat, torch.float64)  # exact Gram of R (see qp/gbfeat.py)
         all_reduce_sum_(G, comm)
         X, stats = K.eq_qp_solve(G, float(l2_regularization), None, A, b, schur_reg=1e-12, n_refine=3)
         st = stats.cpu().numpy()
         if st[0] != 0 or not np.isfinite(st[1]):
             raise ValueError(
-                f"Map optimization failed. (site {site if 'site' in dir() else ind}: pivot {int(st[0])}, "
+                f"Map optimization failed. (site {ind}: pivot {int(st[0])}, "
                 f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
             )
         coefs.append(X[0].cpu().numpy())
@@ -321,33 +320,39 @@ def _feat_linear_mapping(featurizer, coefs: List[np.ndarray], mapping: LinearMap
     fused form used when the map is called: per site
     ``out[t,c,:] = coef_c . (feat_c[t]' F[t] + div_c[t])`` -- note: no kbt on the divergence
     term here, exactly as in the reference's trans_f (featlinearmap.py:517-520).
+    All contractions are HIP kernels (K4c ``aggf_feat_weights`` / ``aggf_feat_contract``, K3).
     """
     import torch
 
-    def _weights(seq, coefs_, expr):
-        out = []
-        for arr, c in zip(seq, coefs_):
-            a = K.as_device(arr)
-            out.append(torch.einsum(expr, a.to(torch.float64), torch.from_numpy(np.asarray(c, dtype=np.float64)).to(a.device)))
-        return torch.stack(out, dim=1)
+    def _coef_dev(c, device):
+        return torch.from_numpy(np.ascontiguousarray(np.asarray(c, dtype=np.float64))).to(device)
 
     def scale_f(copoints):
         feats = featurizer(copoints, mapping, constraints)[KNAME_FEATS]
-        return K.like_input(_weights(feats, coefs, "...ij,j->...i"), copoints)
+        out = None
+        for site, (feat, c) in enumerate(zip(feats, coefs)):
+            f = K.as_device(feat)
+            if out is None:
+                out = torch.empty((f.shape[0], len(coefs), f.shape[1]), dtype=torch.float64, device=f.device)
+            K.feat_weights(f, _coef_dev(c, f.device), out, site)
+        return K.like_input(out, copoints)
 
     def trans_f(copoints):
         divs = featurizer(copoints, mapping, constraints)[KNAME_DIVS]
-        return K.like_input(_weights(divs, coefs, "tij,i->tj"), copoints)
+        cols = []
+        for div, c in zip(divs, coefs):
+            d = K.as_device(div, torch.float64)  # (T, n_feat, 3); trans[t,:] = sum_f coef[f] div[t,f,:]
+            cols.append(K.linearmap_apply(d, _coef_dev(c, d.device).reshape(1, -1)))
+        return K.like_input(torch.cat(cols, dim=1), copoints)
 
     def apply_f(points, copoints):
         res = featurizer(copoints, mapping, constraints)
         F = K.as_device(points)
         cols = []
         for feat, div, c in zip(res[KNAME_FEATS], res[KNAME_DIVS], coefs):
-            y = _site_regression(F, K.as_device(feat), K.as_device(div), 1.0).to(torch.float64)
-            cvec = torch.from_numpy(np.asarray(c, dtype=np.float64)).to(F.device)
-            cols.append(torch.einsum("tfd,f->td", y, cvec))
-        return K.like_input(torch.stack(cols, dim=1), points)
+            y = _site_regression(F, K.as_device(feat), K.as_device(div), 1.0)
+            cols.append(K.linearmap_apply(y, _coef_dev(c, F.device).reshape(1, -1)))
+        return K.like_input(torch.cat(cols, dim=1), points)
 
     return CLAMap(scale=scale_f, trans=trans_f, n_fg_sites=mapping.n_fg_sites, zeroes_check=True,
                   apply=apply_f, **kwargs)

@@ -30,7 +30,7 @@ import numpy as np
 
 from .. import _kernels as K
 from ..constraints import Constraints
-from ..distributed import all_reduce_sum_
+from ..distributed import agree_on_indices, all_reduce_sum_, shard_extent, take_global_frames
 from ..map import CLAFTMap, CLAMap, LinearMap
 from .featlinearmap import KNAME_DIVS, KNAME_FEATS, KNAME_NAMES, constraint_group_labels, id_feat
 
@@ -205,13 +205,26 @@ def fit_id_gb(
     n_cg = coord_map.n_cg_sites
     gen = np.random.default_rng() if rng is None else rng
     coefs: List[np.ndarray] = [None] * n_cg  # type: ignore [list-item]
-    used: List[np.ndarray] = []
+    # Sampled constraint frames (featlinearmap.py:445): numbered over the WHOLE trajectory.  With frames
+    # sharded over ranks every rank must build the same rows A, or the "replicated" solves differ: rank 0's
+    # draw is used everywhere and each sampled frame's geometry comes from the rank that owns it.
+    _, T_total = shard_extent(geo.T, comm, geo.dev)
+    used: List[np.ndarray] = [
+        np.asarray(frame_indices[site]) if frame_indices is not None
+        else gen.choice(T_total, size=n_constraint_frames, replace=False)
+        for site in range(n_cg)
+    ]
+    used = [agree_on_indices(idx, comm, geo.dev) for idx in used]
+    flat_idx = np.concatenate(used) if used else np.zeros(0, dtype=np.int64)
+    Pg_sel = take_global_frames(geo.Pg, flat_idx, comm)
+    cg_sel = take_global_frames(geo.cg, flat_idx, comm)
+    sel_begin = np.concatenate([[0], np.cumsum([len(u) for u in used])]).astype(np.int64)
     # The per-site solve (K2) is a chain of small dependent kernels that leaves most of the GPU idle,
     # while the per-site Gram (K1) fills it (and, once running, keeps later queues waiting).  Sites are
     # therefore processed in chunks: all Grams of a chunk on the main stream, then the solves of the
     # chunk side by side on a few streams.
     main = torch.cuda.current_stream(geo.dev)
-    side = [torch.cuda.Stream(device=geo.dev) for _ in range(_SOLVE_STREAMS)]
+    side = K.side_streams(geo.dev, _SOLVE_STREAMS)
 
     def prepare(site: int):
         K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
@@ -220,22 +233,14 @@ def fit_id_gb(
         # definite; the exact Gram of the float32 regression matrix always is
         Gm = K.gram(R3, None, None, n_feat, torch.float64)
         all_reduce_sum_(Gm, comm)
-        idx = np.asarray(frame_indices[site]) if frame_indices is not None else gen.choice(
-            geo.T, size=n_constraint_frames, replace=False)
-        used.append(idx)
-        sel = torch.as_tensor(idx, device=geo.dev)
-        S = len(idx)
-        A = torch.zeros((S, n_cg, n_feat), dtype=torch.float64, device=geo.dev)
-        if n_id:
-            A[:, :, :n_id] = Mg.unsqueeze(0)
+        lo, hi = int(sel_begin[site]), int(sel_begin[site + 1])
+        S = hi - lo
+        gauss = None
         if n_ch:
-            gauss, _ = K.gb_channels(geo.Pg[sel].contiguous(), geo.cg[sel].contiguous(), site, geo.sizes, n_ch,
+            gauss, _ = K.gb_channels(Pg_sel[lo:hi].contiguous(), cg_sel[lo:hi].contiguous(), site, geo.sizes, n_ch,
                                      centers, width, CLIP)
-            A[:, :, n_id:] = (Mg[:, :n_ch].unsqueeze(0).unsqueeze(-1) * gauss.to(torch.float64).unsqueeze(1)).reshape(
-                S, n_cg, n_ch * n_basis)
-        b = torch.zeros((S, n_cg), dtype=torch.float64, device=geo.dev)
-        b[:, site] = 1
-        return Gm, A.reshape(S * n_cg, n_feat).contiguous(), b.reshape(-1, 1).contiguous()
+        A2, b2 = K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site)  # K4b
+        return Gm, A2, b2
 
     for c0 in range(0, n_cg, _SOLVE_CHUNK):
         sites = list(range(c0, min(n_cg, c0 + _SOLVE_CHUNK)))

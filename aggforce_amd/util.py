@@ -43,7 +43,8 @@ def trjdot(points, factor):
     """out[t,c,d] = sum_f factor[c,f] points[t,f,d]  (reference util.py:79-125).
 
     points: (n_steps, n_sites, 3).  factor: (n_cg, n_sites) -> GPU kernel K3; a 3-D factor
-    (n_steps, n_cg, n_sites) (per-frame maps) is contracted on the GPU as a batched matmul.
+    (n_steps, n_cg, n_sites) (per-frame maps, the reference's "...fd,...cf->...cd" branch) ->
+    the streaming kernel K3c (``aggf_trjdot_frames``).
     The result has NumPy's promoted dtype and the container type of ``points``.
     """
     from . import _kernels as K
@@ -56,12 +57,9 @@ def trjdot(points, factor):
         out_np = np.dtype(np.float64)
     out_t = K.torch_dtype(out_np)
     p = K.as_device(points)
-    f = K.as_device(factor, out_t)
     if fdim == 2:
-        return K.like_input(K.linearmap_apply(p, f), points)
-    import torch
-
-    return K.like_input(torch.bmm(f, p.to(out_t)), points)
+        return K.like_input(K.linearmap_apply(p, K.as_device(factor, out_t)), points)
+    return K.like_input(K.trjdot_frames(p, K.as_device(factor)), points)
 
 
 def flatten(nested_list: Iterable[Iterable[Any]]) -> List[Any]:

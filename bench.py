@@ -8,7 +8,10 @@ in HBM.  Default workload = the configuration BASELINE.json's metric is quoted o
 x 4096 atoms x 256 CG beads, linear map, fp64 (configs[2]); it fits one MI355X (2 x 98.3 GB of
 coordinates and forces + 12 GB of outputs).  With N > 1 ranks (torch.distributed.run, one
 process per GPU) the SAME 1e6 frames are sharded over the ranks ("scaling": "strong"), each
-rank builds the Gram matrix of its shard and one RCCL all-reduce combines them.
+rank builds the Gram matrix of its shard and one RCCL all-reduce combines them.  Typed as
+``python bench.py --gpus N`` (no WORLD_SIZE in the environment) this process only LAUNCHES:
+before anything touches the GPU it starts ``python -m torch.distributed.run --nproc-per-node N``
+on this same file as a child, forwards rank 0's JSON line and exits with the child's code.
 
 Rank 0 prints ONE JSON line: metric / value (frames/s, whole job) / roofline of the dominant
 kernel (MFMA SYRK, HIP-event timed inside this run) / cpu_baseline (the NumPy oracle = a port
@@ -18,6 +21,8 @@ frame sample, N=1 only).
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -28,7 +33,8 @@ if ROOT not in sys.path:
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
 
 import numpy as np  # noqa: E402
-import torch  # noqa: E402
+
+# torch is imported inside main(): the launcher branch must never initialise the GPU
 
 WORKLOADS = {
     # name: (frames, atoms, cg beads, dtype)
@@ -49,7 +55,7 @@ PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (MI355X_MICROARCH.
 SEED = 42100
 
 
-def parse():
+def parse(argv=None):
     p = argparse.ArgumentParser()
     p.add_argument("--gpus", type=int, default=1)
     p.add_argument("--steps", type=int, default=3)
@@ -58,7 +64,87 @@ def parse():
     p.add_argument("--frames", type=int, default=None, help="override the total frame count")
     p.add_argument("--cpu-frames", type=int, default=2000, help="frame sample of the CPU baseline")
     p.add_argument("--no-cpu-baseline", action="store_true")
-    return p.parse_args()
+    p.add_argument("--dry-run", action="store_true",
+                   help="launcher self-test on CPU (gloo, no GPU, no product compute): NOT a measurement")
+    p.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    return p.parse_args(argv)
+
+
+def free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch(args, argv):
+    """``python bench.py --gpus N`` typed by hand (N > 1, not under torch.distributed.run): start the N ranks as
+    fresh child processes and forward rank 0's line.  Nothing here imports torch or calls HIP, so no process
+    that has initialised the GPU is ever re-executed."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "8")
+    proc = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = []
+    for raw in proc.stdout.decode(errors="replace").splitlines():
+        try:
+            rec = json.loads(raw)
+        except ValueError:
+            sys.stderr.write(raw + "\n")  # anything else a child printed
+            continue
+        if isinstance(rec, dict) and "metric" in rec:
+            lines.append(raw)
+    if proc.returncode != 0:
+        sys.stderr.write(f"bench.py: a rank failed (torch.distributed.run exit code {proc.returncode})\n")
+        return proc.returncode
+    if len(lines) != 1:
+        sys.stderr.write(f"bench.py: expected ONE result line from rank 0, got {len(lines)}\n")
+        return 1
+    sys.stdout.write(lines[0] + "\n")
+    sys.stdout.flush()
+    return 0
+
+
+def dry_run(args, world, rank, result_fd):
+    """The bench skeleton without the GPU: gloo rendezvous, barrier, max-over-ranks timing, the replicated-result
+    check and the one-line output -- what the launcher test exercises on CPU."""
+    import torch
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    if rank == args.dry_run_fail_rank:
+        raise SystemExit(3)
+    t0 = time.perf_counter()
+    payload = torch.arange(16, dtype=torch.float64)  # stands for the replicated solve's result
+    if world > 1:
+        dist.barrier()
+    elapsed = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    spread = replicated_spread(payload, world)
+    if world > 1:
+        dist.all_reduce(elapsed, op=dist.ReduceOp.MAX)
+    if rank == 0:
+        line = {"metric": "launcher dry run (no measurement)", "value": None, "unit": "frames/s", "n_gpus": world,
+                "steps": args.steps, "warmup": args.warmup, "dry_run": True, "backend": "gloo",
+                "world_size_seen": dist.get_world_size() if world > 1 else 1,
+                "replicated_solve_max_abs_diff": spread}
+        os.write(result_fd, (json.dumps(line) + "\n").encode())
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def replicated_spread(t, world):
+    """max over entries of (max over ranks - min over ranks) of a tensor every rank computed for itself."""
+    if world == 1:
+        return 0.0
+    import torch.distributed as dist
+
+    hi, lo = t.clone(), t.clone()
+    dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+    dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+    return float((hi - lo).abs().max().item())
 
 
 def profiled_traffic(workload, world):
@@ -134,7 +220,10 @@ def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores):
 
 
 def main():
-    args = parse()
+    argv = sys.argv[1:]
+    args = parse(argv)
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        raise SystemExit(launch(args, argv))
     # ONE JSON line on stdout: libraries (RCCL prints a version banner on init) write to fd 1, so fd 1
     # is pointed at stderr for the run and the result line goes to the saved descriptor.
     sys.stdout.flush()
@@ -144,9 +233,11 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:
+        return dry_run(args, world, rank, result_fd)
+    import torch
+
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run: always RCCL
@@ -224,8 +315,17 @@ def main():
     if hasattr(fmap, "standard_matrix"):
         W = fmap.standard_matrix
         cons_resid = float(np.max(np.abs(cmap.standard_matrix @ W.T - np.eye(n_cg))))
+        solved = np.asarray(W, dtype=np.float64)
     else:
         cons_resid = None
+        solved = np.stack([np.asarray(c, dtype=np.float64) for c in fmap.tags["coef_list"]])
+    # the solve is replicated, not broadcast: every rank must hold the same map, bit for bit
+    w_spread = replicated_spread(torch.from_numpy(np.ascontiguousarray(solved)).cuda(), world)
+    world_seen = 1
+    if comm is not None:
+        import torch.distributed as dist
+
+        world_seen = dist.get_world_size()
 
     if rank == 0:
         gram = stages.get("gram", {"ms": float("nan"), "calls": 1})
@@ -258,6 +358,10 @@ def main():
                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
                 "constraint_residual": cons_resid,
                 "residual": out["residual"],
+                "collective": ("RCCL all-reduce of the Gram matrix (torch.distributed backend nccl)" if comm is not None
+                               else "none (single process)"),
+                "rccl_world_size_seen": world_seen if comm is not None else None,
+                "replicated_solve_max_abs_diff_across_ranks": w_spread,
             },
             "roofline": {
                 "kernel": "gram_tile_dma_kernel<double> (+ slab reduce) = aggf_gram" if gdt == "f64" else "gram_tile_kernel<float> (+ slab reduce) = aggf_gram",

@@ -206,6 +206,53 @@ int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const float* cg,
                   const double* coef, int32_t n_feat, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * K3c  trjdot with a per-frame (3-D) factor.
+ *
+ * Replaces util.trjdot's second branch, np.einsum("...fd,...cf->...cd") (util.py:119-125),
+ * which CLAMap.__call__ (map/core.py:428-430) uses to apply a configuration-dependent map:
+ *     out[t,c,d] = sum_f factor[t,c,f] * points[t,f,d]  (+ trans[t,c,d] if trans != NULL)
+ * points (T, N, 3) in p_dtype, factor (T, n_cg, N) in f_dtype, out and trans (T, n_cg, 3)
+ * in out_dtype = the promoted dtype (float64 if either input is).  HBM-bound: factor is
+ * read exactly once.
+ * ------------------------------------------------------------------------- */
+int aggf_trjdot_frames(const void* points, int p_dtype, const void* factor, int f_dtype, int64_t T,
+                       int32_t N, int32_t n_cg, const void* trans, void* out, int out_dtype, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * K4b/K4c  Dense-featuriser contractions of qp_feat_linear_map (any featuriser that
+ * follows the reference's protocol: feats (T, N, n_feat), divs (T, n_feat, 3) per site).
+ *
+ * aggf_feat_contract: featlinearmap.py:361-369 (alpha = kbt) and the force + divergence
+ *   term of the map's application, featlinearmap.py:512-520 (alpha = 1):
+ *     out[t,f,d] = sum_a feat[t,a,f] * F[t,a,d] + alpha * div[t,f,d]      (div may be NULL)
+ *   out is (T, ld, 3), ld >= n_feat; columns n_feat..ld-1 are written as zeros, so a
+ *   multiple of 128 gives aggf_gram its in-place layout.  feat and div share x_dtype;
+ *   out_dtype = promoted dtype of forces and features.
+ * aggf_feat_constraint_rows: _constr_arrays (featlinearmap.py:445-459) for one cg site:
+ *     A[(s,c),f] = sum_a M[c,a] * feat[frame_idx[s],a,f],   b[(s,c)] = (c == site)
+ *   feat (T, N, n_feat); frame_idx[S] int64 device array; M (n_cg, N) float64;
+ *   A (S*n_cg, n_feat), b (S*n_cg) float64.
+ * aggf_gb_constraint_rows: the same rows for the fused [id_feat | gb_feat] features:
+ *     A[(s,c), g]              = Mg[c,g]                       g  < n_id
+ *     A[(s,c), n_id+ch*nb+k]   = Mg[c,ch] * gauss[s,ch,k]      ch < n_ch
+ *   Mg (n_cg, G) float64 = coordinate map summed over each constraint group, gauss
+ *   (S, n_ch, nb) float32 from aggf_gb_channels on the sampled frames.
+ * aggf_feat_weights: scale_f of _feat_linear_mapping (featlinearmap.py:512-515):
+ *     w[t*ld_t + a] = sum_f feat[t,a,f] * coef[f]     (ld_t >= N lets the caller stack sites)
+ * ------------------------------------------------------------------------- */
+int aggf_feat_contract(const void* forces, int f_dtype, const void* feat, const void* div, int x_dtype,
+                       double alpha, int64_t T, int32_t N, int32_t n_feat, int32_t ld, void* out,
+                       int out_dtype, void* stream);
+int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t T, int32_t N, int32_t n_feat,
+                              const int64_t* frame_idx, int32_t S, const double* M, int32_t n_cg,
+                              int32_t site, double* A, double* b, void* stream);
+int aggf_gb_constraint_rows(const double* Mg, const float* gauss, int32_t S, int32_t n_cg, int32_t G,
+                            int32_t n_id, int32_t n_ch, int32_t n_basis, int32_t site, double* A,
+                            double* b, void* stream);
+int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32_t N, int32_t n_feat,
+                      const double* coef, int64_t ld_t, double* w, void* stream);
+
+/* ---------------------------------------------------------------------------
  * K6  Pair-distance fluctuations for guess_pairwise_constraints.
  *
  * Replaces constraints/constfinder.py:46-53 (util.distances, util.py:65-72, then

@@ -180,3 +180,26 @@ def test_gb_feat_random_sweep_matches_oracle():
             worst_f = max(worst_f, float(np.max(np.abs(f - of[c]))))
             worst_d = max(worst_d, float(np.max(np.abs(d - od[c]))))
     assert worst_f < 5e-6 and worst_d < 1e-4, (worst_f, worst_d)
+
+
+def test_gb_feat_kernels_match_autodiff_fixture(golden):
+    """K4 against the autodiff derivation of tests/golden/g7 (see oracle/gen_g7_autodiff.py): the transcribed
+    forward pass of jaxfeat.py differentiated by torch.autograd, labels from the reference's id_feat."""
+    from conftest import cons_in_insertion_order
+
+    g = golden("g7_gbfeat_autodiff.npz")
+    for name in [str(n) for n in g["names"]]:
+        outer, inner, n_basis, width, dist_power = g[f"{name}__kw"]
+        coords, cmat = g[f"{name}__coords"], g[f"{name}__cmat"]
+        cons = cons_in_insertion_order(g[f"{name}__cons"])
+        cmap = LinearMap(cmat)
+        assert np.array_equal(id_feat(coords, cmap, cons, return_ids=True), g[f"{name}__ids"])
+        for method in ("reorder", "basic"):
+            res = gb_feat(coords, cmap, cons, outer=float(outer), inner=float(inner), n_basis=int(n_basis),
+                          width=float(width), dist_power=float(dist_power), lazy=False, div_method=method)
+            ref_d = g[f"{name}__divs"] if method == "reorder" else g[f"{name}__divs_basic"]
+            for c in range(cmat.shape[0]):
+                f, d = res["feats"][c], res["divs"][c]
+                assert f.shape == g[f"{name}__feats"][c].shape and d.shape == ref_d[c].shape
+                assert np.max(np.abs(f - g[f"{name}__feats"][c])) < 5e-6, (name, c)
+                assert np.max(np.abs(d - ref_d[c])) < 1e-4, (name, c, method)

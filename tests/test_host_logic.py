@@ -294,3 +294,28 @@ def test_constraint_layout_random_sets_match_oracle():
         assert np.array_equal(C, orc.make_bond_constraint_matrix(n, cons))
         goa, n_red = group_layout(n, cons)
         assert C.shape == (n, n_red) and np.all(C[np.arange(n), goa] == 1) and C.sum() == n
+
+
+def test_bench_launcher_dry_run_two_ranks():
+    """`python bench.py --gpus 2` as typed (no WORLD_SIZE): the parent starts 2 fresh ranks through
+    torch.distributed.run, forwards rank 0's single JSON line, and fails when a rank fails.  --dry-run keeps
+    the children off the GPU (gloo; the rendezvous / barrier / max-over-ranks / replicated-result skeleton)."""
+    import json
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    bench = os.path.join(ROOT, "bench.py")
+    ok = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run"], capture_output=True, env=env, timeout=300)
+    assert ok.returncode == 0, ok.stderr.decode()[-2000:]
+    lines = [l for l in ok.stdout.decode().splitlines() if l.strip()]
+    assert len(lines) == 1
+    rec = json.loads(lines[0])
+    assert rec["n_gpus"] == 2 and rec["world_size_seen"] == 2 and rec["replicated_solve_max_abs_diff"] == 0.0
+    bad = subprocess.run([sys.executable, bench, "--gpus", "2", "--dry-run", "--dry-run-fail-rank", "1"],
+                         capture_output=True, env=env, timeout=300)
+    assert bad.returncode != 0 and not bad.stdout.strip()
+    # the launcher branch never imports torch (no GPU initialisation in the parent)
+    probe = subprocess.run([sys.executable, "-c", "import sys; sys.argv=['bench.py']; import bench; "
+                            "assert 'torch' not in sys.modules; print('clean')"], capture_output=True, env=env,
+                           cwd=ROOT, timeout=120)
+    assert probe.stdout.decode().strip() == "clean", probe.stderr.decode()[-2000:]

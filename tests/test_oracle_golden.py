@@ -149,3 +149,49 @@ def test_gb_feat_divergence_matches_finite_differences():
     f_q, d_q = orc.gb_feat_site(pts, cg, ids, smear, **kw)
     assert f_q.shape[2] == 4 * (nch - 1)
     assert np.array_equal(f_q, feats[:, :, : 4 * (nch - 1)])
+
+
+def _g7_cases(g):
+    for name in [str(n) for n in g["names"]]:
+        outer, inner, n_basis, width, dist_power = g[f"{name}__kw"]
+        kw = dict(outer=float(outer), inner=float(inner), n_basis=int(n_basis), width=float(width),
+                  dist_power=float(dist_power))
+        yield name, kw
+
+
+def test_gb_feat_oracle_matches_autodiff_fixture(golden):
+    """Second derivation (oracle/gen_g7_autodiff.py): the forward pass of jaxfeat.py transcribed op by op and
+    differentiated AUTOMATICALLY (torch.autograd; 'reorder' and 'basic' methods of gb_subfeat_jac) against the
+    oracle's hand-derived closed form -- multi-atom groups, the clip boundary, the dropped last channel."""
+    from conftest import cons_in_insertion_order
+
+    g = golden("g7_gbfeat_autodiff.npz")
+    for name, kw in _g7_cases(g):
+        coords, cmat = g[f"{name}__coords"], g[f"{name}__cmat"]
+        cons = cons_in_insertion_order(g[f"{name}__cons"])
+        N = coords.shape[1]
+        ids = orc.id_feat_ids(N, cons)
+        assert np.array_equal(ids, g[f"{name}__ids"])  # the reference's labels
+        smear = orc.smear_matrix(orc.reduce_constraint_sets(cons), N) if cons else np.eye(N, dtype=np.float32)
+        cg = orc.linearmap_apply(coords, cmat.astype(np.float32))
+        for c in range(cmat.shape[0]):
+            f, d = orc.gb_feat_site(coords, cg[:, c, :], ids, smear, **kw)
+            rf, rd, rb = g[f"{name}__feats"][c], g[f"{name}__divs"][c], g[f"{name}__divs_basic"][c]
+            assert f.shape == rf.shape and d.shape == rd.shape
+            assert f.shape[2] == kw["n_basis"] * int(ids.max())  # Quirk A: max(ids) channels, the last label has none
+            assert np.max(np.abs(f - rf)) < 5e-6, name
+            assert np.max(np.abs(d - rd)) < 5e-5 and np.max(np.abs(d - rb)) < 5e-5, name
+    # the clip boundary case really straddles the boundary: the atom just inside has a small positive
+    # feature and a non-zero gradient, the one just outside exactly zero
+    f = g["clip_edge__feats"][0]
+    ids = g["clip_edge__ids"]
+    nb, checked = 2, 0
+    if ids[2] < ids.max():  # (the last label has no channel)
+        inside = f[:, 2, nb * ids[2]]
+        assert np.all(inside > 0) and np.all(inside < 1e-3)
+        assert np.all(np.abs(g["clip_edge__divs"][0][:, nb * ids[2], 0]) > 1e-4)
+        checked += 1
+    if ids[3] < ids.max():
+        assert np.all(f[:, 3, nb * ids[3]] == 0) and np.all(g["clip_edge__divs"][0][:, nb * ids[3], :] == 0)
+        checked += 1
+    assert checked >= 1
