@@ -193,6 +193,55 @@ def eq_qp_solve(
     return X, stats
 
 
+def eq_qp_batched_bytes(n: int, m: int, nrhs: int, n_problems: int) -> int:
+    return int(lib().aggf_eq_qp_batched_workspace_bytes(n, m, nrhs, n_problems))
+
+
+def eq_qp_solve_batched(
+    G: torch.Tensor,
+    l2: float,
+    l2_diag: Optional[torch.Tensor],
+    A: torch.Tensor,
+    B: Optional[torch.Tensor] = None,
+    schur_reg: float = 0.0,
+    n_refine: int = 1,
+) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Independent problems side by side: G (p, n, n), A (p, m, n), B (p, m, nrhs) or None ->
+    X (p, nrhs, n), stats (p, 4); see aggf_eq_qp_solve_batched."""
+    l = lib()
+    if G.dim() != 3 or A.dim() != 3 or G.shape[0] != A.shape[0] or G.shape[1] != G.shape[2] or A.shape[2] != G.shape[1]:
+        raise ValueError(f"shape mismatch: G {tuple(G.shape)}, A {tuple(A.shape)}")
+    if G.dtype != torch.float64 or A.dtype != torch.float64 or not G.is_contiguous() or not A.is_contiguous():
+        raise ValueError("G and A must be contiguous float64")
+    npb, n, _ = G.shape
+    m = A.shape[1]
+    if B is not None and (B.dim() != 3 or B.shape[0] != npb or B.shape[1] != m or B.dtype != torch.float64
+                          or not B.is_contiguous()):
+        raise ValueError(f"shape mismatch: B {tuple(B.shape)}")
+    nrhs = m if B is None else B.shape[2]
+    dev = G.device
+    X = torch.empty((npb, nrhs, n), dtype=torch.float64, device=dev)
+    stats = torch.empty((npb, 4), dtype=torch.float64, device=dev)
+    need = l.aggf_eq_qp_batched_workspace_bytes(n, m, nrhs, npb)
+    ws = workspace(need, dev, "solve")
+    with _timed("solve"):
+        check(
+            l.aggf_eq_qp_solve_batched(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), m, ptr(B), nrhs, float(schur_reg),
+                                       int(n_refine), npb, ptr(X), ptr(stats), ptr(ws), need, stream_ptr()),
+            "aggf_eq_qp_solve_batched",
+        )
+    return X, stats
+
+
+def device_memory(device=None) -> Tuple[int, int]:
+    """(free, total) bytes of HBM on the current device (aggf_device_info)."""
+    import ctypes as C
+
+    cu, free, total = C.c_int32(0), C.c_size_t(0), C.c_size_t(0)
+    check(lib().aggf_device_info(C.byref(cu), C.byref(free), C.byref(total)), "aggf_device_info")
+    return int(free.value), int(total.value)
+
+
 def expand_map(X: torch.Tensor, group_of_atom: torch.Tensor, N: int) -> torch.Tensor:
     l = lib()
     n_rows, n_red = X.shape
@@ -448,7 +497,7 @@ def gb_regmat(Fg, Pg, cg, site: int, sizes, n_id: int, n_ch: int, centers, width
         check(
             l.aggf_gb_regmat(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, cg.shape[1], site, ptr(sizes),
                              n_id, n_ch, ptr(centers), centers.numel(), float(width), float(clip), float(kbt),
-                             out.shape[1], ptr(out), stream_ptr()),
+                             out.shape[1], ptr(out), dtype_code(out.dtype), stream_ptr()),
             "aggf_gb_regmat",
         )
     return out

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "aggf_gram": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _vp, _vp, _i32, _vp, C.c_int, _vp, _sz, _vp]),
     "aggf_eq_qp_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "aggf_eq_qp_solve": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_eq_qp_batched_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "aggf_eq_qp_solve_batched": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_expand_map": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aggf_linearmap_apply_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "aggf_linearmap_apply": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
@@ -43,7 +45,7 @@ PROTOTYPES = {
     "aggf_condnormal_augment": (C.c_int, [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _u64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "aggf_group_reduce": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _i32, C.c_int, C.c_int, _vp, _vp]),
     "aggf_gb_channels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),
-    "aggf_gb_regmat": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, _vp]),
+    "aggf_gb_regmat": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
     "aggf_gb_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp]),
     "aggf_trjdot_frames": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp]),
     "aggf_feat_contract": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dbl, _i64, _i32, _i32, _i32, _vp, C.c_int, _vp]),

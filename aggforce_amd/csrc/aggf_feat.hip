@@ -94,25 +94,27 @@ __global__ __launch_bounds__(256) void gb_channels_kernel(const float* __restric
 
 // R3 (T, ld_feat, 3): columns [0, n_id) = group force sums (id_feat block, optional), then
 // n_ch * n_basis Gaussian columns; columns up to ld_feat are left untouched (ignored by K1).
-template <typename TF>
+// TO = storage type of R3: the products are formed in TF (the reference's arithmetic) and only then widened,
+// so a float64 R3 -- K1's in-place operand for float64 products -- holds exactly the float32 matrix.
+template <typename TF, typename TO>
 __global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
                                                         const float* __restrict__ cg, int64_t T, int32_t G,
                                                         int32_t n_cg, int32_t site,
                                                         const float* __restrict__ sizes, int32_t n_id,
                                                         int32_t n_ch, GbParams gp, TF kbt, int32_t ld_feat,
-                                                        TF* __restrict__ R3) {
+                                                        TO* __restrict__ R3) {
   const int per_frame = n_id + n_ch;  // work items per frame: id columns, then channels
   const int64_t total = T * per_frame;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / per_frame;
     const int j = (int)(i - t * per_frame);
-    TF* row = R3 + t * (int64_t)ld_feat * 3;
+    TO* row = R3 + t * (int64_t)ld_feat * 3;
     if (j < n_id) {
       const TF* f = Fg + (t * G + j) * 3;
-      row[j * 3 + 0] = f[0];
-      row[j * 3 + 1] = f[1];
-      row[j * 3 + 2] = f[2];
+      row[j * 3 + 0] = (TO)f[0];
+      row[j * 3 + 1] = (TO)f[1];
+      row[j * 3 + 2] = (TO)f[2];
       continue;
     }
     const int ch = j - n_id;
@@ -121,14 +123,14 @@ __global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ F
     const TF* f = Fg + (t * G + ch) * 3;
     const TF f0 = f[0], f1 = f[1], f2 = f[2];
     const float m = sizes[ch];
-    TF* o = row + ((int64_t)n_id + (int64_t)ch * gp.n_basis) * 3;
+    TO* o = row + ((int64_t)n_id + (int64_t)ch * gp.n_basis) * 3;
     for (int k = 0; k < gp.n_basis; ++k) {
       float g, dg;
       gb_gauss(gp, r, k, g, dg);
       const float s = m * dg;
-      o[k * 3 + 0] = (TF)g * f0 + kbt * (TF)(s * u[0]);
-      o[k * 3 + 1] = (TF)g * f1 + kbt * (TF)(s * u[1]);
-      o[k * 3 + 2] = (TF)g * f2 + kbt * (TF)(s * u[2]);
+      o[k * 3 + 0] = (TO)((TF)g * f0 + kbt * (TF)(s * u[0]));
+      o[k * 3 + 1] = (TO)((TF)g * f1 + kbt * (TF)(s * u[1]));
+      o[k * 3 + 2] = (TO)((TF)g * f2 + kbt * (TF)(s * u[2]));
     }
   }
 }
@@ -245,7 +247,7 @@ extern "C" int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int
 extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
                               int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
                               int32_t n_ch, const float* centers, int32_t n_basis, double width,
-                              double clip, double kbt, int32_t ld_feat, void* R3, void* stream_v) {
+                              double clip, double kbt, int32_t ld_feat, void* R3, int out_dtype, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!Fg || !Pg || !cg || !sizes || !R3) return fail(AGGF_ERR_ARG, "aggf_gb_regmat: NULL pointer");
   if (T <= 0 || G <= 0 || n_ch < 0 || n_ch > G || n_id < 0 || n_id > G || site < 0 || site >= n_cg ||
@@ -255,12 +257,14 @@ extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, cons
   if (rc) return rc;
   GbParams gp{centers, n_basis, (float)width, (float)clip};
   const dim3 grid = feat_grid(T * (n_id + n_ch));
-  if (f_dtype == AGGF_F32)
-    hipLaunchKernelGGL(gb_regmat_kernel<float>, grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (float)kbt, ld_feat, (float*)R3);
-  else if (f_dtype == AGGF_F64)
-    hipLaunchKernelGGL(gb_regmat_kernel<double>, grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (double)kbt, ld_feat, (double*)R3);
+  if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((gb_regmat_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (float)kbt, ld_feat, (float*)R3);
+  else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((gb_regmat_kernel<float, double>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (float)kbt, ld_feat, (double*)R3);
+  else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((gb_regmat_kernel<double, double>), grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (double)kbt, ld_feat, (double*)R3);
   else
-    return fail(AGGF_ERR_ARG, "aggf_gb_regmat: bad dtype");
+    return fail(AGGF_ERR_ARG, "aggf_gb_regmat: bad dtype (out must be the force dtype or float64)");
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

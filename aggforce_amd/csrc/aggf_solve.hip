@@ -22,10 +22,14 @@ constexpr int GS = GK + 2;      // LDS row stride of GEMM operand tiles (element
 // C[M x N] = alpha * op(A) op(B) + beta * C  (and the same values to C2 if non-null).
 // Row-major; M % 64 == 0, N % 64 == 0, K % 16 == 0.  op(A) is M x K, op(B) is K x N.
 // lower_only: skip tiles strictly above the block diagonal (square trailing updates).
-// blockIdx.z = batch index z: operand X is offset by (z / inner) * x_o + (z % inner) * x_i elements.
+// blockIdx.z = problem * per_prob + z: operand X is offset by problem * x_p + (z / inner) * x_o +
+// (z % inner) * x_i elements (problem = one of the independent QPs of a batched solve; z = the
+// batched GEMMs of one algorithmic step inside a problem).
 struct GemmBatch {
   int inner;
   int64_t a_o, a_i, b_o, b_i, c_o, c_i;
+  int per_prob = 1;
+  int64_t a_p = 0, b_p = 0, c_p = 0;
 };
 
 template <bool TA, bool TB>
@@ -39,10 +43,11 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
   const int bi = blockIdx.y, bj = blockIdx.x;
   if (lower_only && bj > bi) return;
   if (gridDim.z > 1) {
-    const int zo = blockIdx.z / bt.inner, zi = blockIdx.z % bt.inner;
-    A += zo * bt.a_o + zi * bt.a_i;
-    B += zo * bt.b_o + zi * bt.b_i;
-    C += zo * bt.c_o + zi * bt.c_i;
+    const int prob = blockIdx.z / bt.per_prob, z = blockIdx.z % bt.per_prob;
+    const int zo = z / bt.inner, zi = z % bt.inner;
+    A += prob * bt.a_p + zo * bt.a_o + zi * bt.a_i;
+    B += prob * bt.b_p + zo * bt.b_o + zi * bt.b_i;
+    C += prob * bt.c_p + zo * bt.c_o + zi * bt.c_i;
   }
   __shared__ __attribute__((aligned(16))) double sA[2][64 * GS];
   __shared__ __attribute__((aligned(16))) double sB[2][64 * GS];
@@ -155,10 +160,14 @@ __device__ __forceinline__ double lane_bcast(double v, int src_lane) {
 
 __global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ Akk, int64_t lda,
                                                         double* __restrict__ Linv,
-                                                        double* __restrict__ info, int pivot_base) {
+                                                        double* __restrict__ info, int pivot_base,
+                                                        int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
   __shared__ double a[NB][NB + 1];
   __shared__ double colbuf[2][NB];
   const int lane = threadIdx.x;
+  Akk += blockIdx.x * a_ps;    // blockIdx.x = problem of a batched solve
+  Linv += blockIdx.x * linv_ps;
+  info += blockIdx.x * info_ps;
   for (int row = 0; row < NB; ++row) a[row][lane] = (lane <= row) ? Akk[(int64_t)row * lda + lane] : 0.0;
   __syncthreads();
   double r[NB];
@@ -205,11 +214,15 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ Akk
   }
 }
 
+// Helper kernels of the solve.  blockIdx.y = problem of a batched solve; every array argument comes
+// with its per-problem stride (`*_ps`, elements).
+
 // scale[0] = max_i (G[i,i] + l2*diag[i]), or 1 if that is not positive/finite
-__global__ __launch_bounds__(256) void max_diag_kernel(const double* __restrict__ G, int n,
+__global__ __launch_bounds__(256) void max_diag_kernel(const double* __restrict__ G, int n, int64_t g_ps,
                                                        double l2, const double* __restrict__ l2d,
-                                                       double* __restrict__ scale) {
+                                                       double* __restrict__ scale, int64_t scale_ps) {
   __shared__ double sh[256];
+  G += blockIdx.y * g_ps;
   double m = 0.0;
   for (int i = threadIdx.x; i < n; i += 256) {
     const double v = G[(int64_t)i * n + i] + l2 * (l2d ? l2d[i] : 1.0);
@@ -221,15 +234,17 @@ __global__ __launch_bounds__(256) void max_diag_kernel(const double* __restrict_
     if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) scale[0] = (sh[0] > 0.0 && sh[0] < 1e300) ? sh[0] : 1.0;
+  if (threadIdx.x == 0) scale[blockIdx.y * scale_ps] = (sh[0] > 0.0 && sh[0] < 1e300) ? sh[0] : 1.0;
 }
 
 // Pt (npad x npad) = (G + l2*diag)/s on the n x n block, identity on the padding
-__global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict__ G, int n, int npad,
+__global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict__ G, int n, int64_t g_ps, int npad,
                                                        double l2, const double* __restrict__ l2d,
-                                                       const double* __restrict__ scale,
-                                                       double* __restrict__ Pt) {
-  const double inv_s = 1.0 / scale[0];
+                                                       const double* __restrict__ scale, int64_t scale_ps,
+                                                       double* __restrict__ Pt, int64_t pt_ps) {
+  G += blockIdx.y * g_ps;
+  Pt += blockIdx.y * pt_ps;
+  const double inv_s = 1.0 / scale[blockIdx.y * scale_ps];
   const int64_t total = (int64_t)npad * npad;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -247,9 +262,11 @@ __global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict_
 }
 
 // dst (rd x cd, zero padded) = src (rs x cs) or its transpose; identity if src == NULL
-__global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict__ src, int rs, int cs,
+__global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict__ src, int rs, int cs, int64_t src_ps,
                                                        int transpose, double* __restrict__ dst,
-                                                       int rd, int cd) {
+                                                       int rd, int cd, int64_t dst_ps) {
+  if (src) src += blockIdx.y * src_ps;
+  dst += blockIdx.y * dst_ps;
   const int64_t total = (int64_t)rd * cd;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -267,15 +284,19 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict_
 }
 
 // S[i,i] = 1 for padding rows i >= m
-__global__ void fix_pad_diag_kernel(double* __restrict__ S, int m, int mpad) {
+__global__ void fix_pad_diag_kernel(double* __restrict__ S, int m, int mpad, int64_t s_ps) {
+  S += blockIdx.y * s_ps;
   const int i = m + blockIdx.x * blockDim.x + threadIdx.x;
   if (i < mpad) S[(int64_t)i * mpad + i] = 1.0;
 }
 
 // R -= Bp elementwise on (rows x cols), then out[0] = max |R| over the valid block
 __global__ __launch_bounds__(256) void resid_kernel(double* __restrict__ R, const double* __restrict__ Bp,
-                                                    int rows, int cols, int ld, double* __restrict__ out) {
+                                                    int rows, int cols, int ld, int64_t mat_ps,
+                                                    double* __restrict__ out, int64_t out_ps) {
   __shared__ double sh[256];
+  R += blockIdx.y * mat_ps;
+  Bp += blockIdx.y * mat_ps;
   double m = 0.0;
   const int64_t total = (int64_t)rows * cols;
   for (int64_t e = threadIdx.x; e < total; e += 256) {
@@ -291,7 +312,7 @@ __global__ __launch_bounds__(256) void resid_kernel(double* __restrict__ R, cons
     if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[0] = sh[0];
+  if (threadIdx.x == 0) out[blockIdx.y * out_ps] = sh[0];
 }
 
 __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ x, const double* __restrict__ y,
@@ -302,8 +323,10 @@ __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ x, const
 }
 
 // X (nrhs x n) = Xt (npad x rpad) transposed and cropped
-__global__ __launch_bounds__(256) void crop_transpose_kernel(const double* __restrict__ Xt, int rpad,
+__global__ __launch_bounds__(256) void crop_transpose_kernel(const double* __restrict__ Xt, int rpad, int64_t xt_ps,
                                                              int n, int nrhs, double* __restrict__ X) {
+  Xt += blockIdx.y * xt_ps;
+  X += blockIdx.y * (int64_t)nrhs * n;
   const int64_t total = (int64_t)nrhs * n;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -313,8 +336,10 @@ __global__ __launch_bounds__(256) void crop_transpose_kernel(const double* __res
 }
 
 // S[i,i] += reg * trace(S[:m,:m]) / m  for i < m  (Tikhonov shift for redundant constraint rows)
-__global__ __launch_bounds__(256) void schur_reg_kernel(double* __restrict__ S, int m, int mpad, double reg) {
+__global__ __launch_bounds__(256) void schur_reg_kernel(double* __restrict__ S, int m, int mpad, int64_t s_ps,
+                                                        double reg) {
   __shared__ double sh[256];
+  S += blockIdx.y * s_ps;
   double t = 0.0;
   for (int i = threadIdx.x; i < m; i += 256) t += S[(int64_t)i * mpad + i];
   sh[threadIdx.x] = t;
@@ -327,32 +352,51 @@ __global__ __launch_bounds__(256) void schur_reg_kernel(double* __restrict__ S, 
   for (int i = threadIdx.x; i < m; i += 256) S[(int64_t)i * mpad + i] += shift;
 }
 
-__global__ void init_stats_kernel(double* stats) {
-  if (threadIdx.x < 4) stats[threadIdx.x] = 0.0;
+__global__ void init_stats_kernel(double* stats, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) stats[i] = 0.0;
 }
-__global__ void copy_scalar_kernel(const double* src, double* dst) { dst[0] = src[0]; }
+__global__ void copy_scalar_kernel(const double* src, int64_t src_ps, double* dst, int64_t dst_ps) {
+  dst[blockIdx.x * dst_ps] = src[blockIdx.x * src_ps];
+}
 
 // ---------------------------------------------------------------------------
 struct Ctx {
   hipStream_t stream;
   int rc = AGGF_OK;
+  int nprob = 1;  // independent problems solved side by side (blockIdx.z of the GEMMs, .x/.y of the helpers)
 };
 
-static inline dim3 flat_grid(int64_t n) {
+// a matrix of every problem of the batch: problem p starts at p + p * ps
+struct Mat {
+  double* p;
+  int64_t ld;
+  int64_t ps;
+  Mat at(int64_t row, int64_t col) const { return Mat{p + row * ld + col, ld, ps}; }
+};
+
+static inline dim3 flat_grid(int64_t n, int nprob = 1) {
   int64_t g = ceil_div(n, 256);
   if (g > 4096) g = 4096;
   if (g < 1) g = 1;
-  return dim3((unsigned)g);
+  return dim3((unsigned)g, (unsigned)nprob);
 }
 
 template <bool TA, bool TB>
-static void gemm(Ctx& c, int M, int N, int K, double alpha, const double* A, int64_t lda,
-                 const double* B, int64_t ldb, double beta, double* C, int64_t ldc,
-                 double* C2 = nullptr, int64_t ldc2 = 0, int lower_only = 0, int nbatch = 1,
-                 GemmBatch bt = GemmBatch{1, 0, 0, 0, 0, 0, 0}) {
+static void gemm(Ctx& c, int M, int N, int K, double alpha, Mat A, Mat B, double beta, Mat C, int lower_only = 0,
+                 int nbatch = 1, GemmBatch bt = GemmBatch{1, 0, 0, 0, 0, 0, 0}) {
   if (c.rc || M <= 0 || N <= 0 || nbatch <= 0) return;
-  hipLaunchKernelGGL((gemm64_kernel<TA, TB>), dim3(N / 64, M / 64, nbatch), dim3(256), 0, c.stream, K, alpha,
-                     A, lda, B, ldb, beta, C, ldc, C2, ldc2, lower_only, bt);
+  bt.per_prob = nbatch;
+  bt.a_p = A.ps;
+  bt.b_p = B.ps;
+  bt.c_p = C.ps;
+  const int64_t gz = (int64_t)nbatch * c.nprob;
+  if (gz > 65535) {
+    c.rc = fail(AGGF_ERR_ARG, "batched solve: too many problems for one launch");
+    return;
+  }
+  hipLaunchKernelGGL((gemm64_kernel<TA, TB>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), 0, c.stream, K, alpha,
+                     A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, (double*)nullptr, (int64_t)0, lower_only, bt);
   if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "gemm launch failed");
 }
 
@@ -369,12 +413,13 @@ constexpr int BIG = OUTER_PANELS * NB;  // 256: edge of the inverted diagonal bl
 static size_t dinv_elems(int npad) {
   return (size_t)npad * NB + (size_t)(npad / BIG) * BIG * BIG + (size_t)(npad / BIG + 1) * (BIG / 2) * (BIG / 2);
 }
-static inline double* dbig_of(double* Dinv, int npad) { return Dinv + (size_t)npad * NB; }
-static inline const double* dbig_of(const double* Dinv, int npad) { return Dinv + (size_t)npad * NB; }
+static inline Mat dbig_of(Mat Dinv, int npad) { return Mat{Dinv.p + (size_t)npad * NB, BIG, Dinv.ps}; }
 
 // Dbig[ob] (256x256) <- block diagonal of the four 64x64 inverses of outer block ob, zeros elsewhere
 __global__ __launch_bounds__(256) void dbig_init_kernel(const double* __restrict__ Dinv, double* __restrict__ Dbig,
-                                                        int nbig) {
+                                                        int nbig, int64_t d_ps) {
+  Dinv += blockIdx.y * d_ps;
+  Dbig += blockIdx.y * d_ps;
   const int64_t total = (int64_t)nbig * BIG * BIG;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int ob = (int)(e / (BIG * BIG)), r = (int)(e % (BIG * BIG)), i = r / BIG, j = r % BIG;
@@ -387,61 +432,62 @@ __global__ __launch_bounds__(256) void dbig_init_kernel(const double* __restrict
 // 64 -> 128 -> 256, every level two batched GEMMs over all blocks.  With them a triangular solve
 // takes npad/256 steps of K = 256 GEMMs instead of npad/64 steps of K = 64 (those were bound by
 // the ~128 dependent launches per solve, not by their flops).
-static void build_big_inverses(Ctx& c, const double* L, int npad, double* Dinv) {
+static void build_big_inverses(Ctx& c, Mat L, int npad, Mat Dinv) {
   const int nbig = npad / BIG;
   if (nbig <= 0 || c.rc) return;
-  double* Dbig = dbig_of(Dinv, npad);
-  double* T = Dbig + (size_t)nbig * BIG * BIG;
-  hipLaunchKernelGGL(dbig_init_kernel, flat_grid((int64_t)nbig * BIG * BIG), dim3(256), 0, c.stream, Dinv, Dbig, nbig);
+  const Mat Dbig = dbig_of(Dinv, npad);
+  double* Tp = Dbig.p + (size_t)nbig * BIG * BIG;
+  hipLaunchKernelGGL(dbig_init_kernel, flat_grid((int64_t)nbig * BIG * BIG, c.nprob), dim3(256), 0, c.stream, Dinv.p,
+                     Dbig.p, nbig, Dinv.ps);
   if (hipGetLastError() != hipSuccess) { c.rc = fail(AGGF_ERR_HIP, "dbig_init launch failed"); return; }
   const int64_t l_o = (int64_t)BIG * npad + BIG, d_o = (int64_t)BIG * BIG, t_o = (int64_t)(BIG / 2) * (BIG / 2);
   // level 1: pairs of 64-blocks (p = 0, 1) inside every outer block
   {
     const int64_t l_i = (int64_t)2 * NB * npad + 2 * NB, d_i = (int64_t)2 * NB * BIG + 2 * NB;
+    const Mat T{Tp, NB, Dinv.ps};
     // T = B Ainv
-    gemm<false, false>(c, NB, NB, NB, 1.0, L + (int64_t)NB * npad, npad, Dbig, BIG, 0.0, T, NB, nullptr, 0, 0,
-                       2 * nbig, GemmBatch{2, l_o, l_i, d_o, d_i, t_o, (int64_t)NB * NB});
+    gemm<false, false>(c, NB, NB, NB, 1.0, L.at(NB, 0), Dbig, 0.0, T, 0, 2 * nbig,
+                       GemmBatch{2, l_o, l_i, d_o, d_i, t_o, (int64_t)NB * NB});
     // X = -Cinv T
-    gemm<false, false>(c, NB, NB, NB, -1.0, Dbig + (int64_t)NB * BIG + NB, BIG, T, NB, 0.0, Dbig + (int64_t)NB * BIG, BIG,
-                       nullptr, 0, 0, 2 * nbig, GemmBatch{2, d_o, d_i, t_o, (int64_t)NB * NB, d_o, d_i});
+    gemm<false, false>(c, NB, NB, NB, -1.0, Dbig.at(NB, NB), T, 0.0, Dbig.at(NB, 0), 0, 2 * nbig,
+                       GemmBatch{2, d_o, d_i, t_o, (int64_t)NB * NB, d_o, d_i});
   }
   // level 2: the two 128-blocks of every outer block
   {
     const int H = BIG / 2;
-    gemm<false, false>(c, H, H, H, 1.0, L + (int64_t)H * npad, npad, Dbig, BIG, 0.0, T, H, nullptr, 0, 0, nbig,
-                       GemmBatch{1, l_o, 0, d_o, 0, t_o, 0});
-    gemm<false, false>(c, H, H, H, -1.0, Dbig + (int64_t)H * BIG + H, BIG, T, H, 0.0, Dbig + (int64_t)H * BIG, BIG,
-                       nullptr, 0, 0, nbig, GemmBatch{1, d_o, 0, t_o, 0, d_o, 0});
+    const Mat T{Tp, H, Dinv.ps};
+    gemm<false, false>(c, H, H, H, 1.0, L.at(H, 0), Dbig, 0.0, T, 0, nbig, GemmBatch{1, l_o, 0, d_o, 0, t_o, 0});
+    gemm<false, false>(c, H, H, H, -1.0, Dbig.at(H, H), T, 0.0, Dbig.at(H, 0), 0, nbig,
+                       GemmBatch{1, d_o, 0, t_o, 0, d_o, 0});
   }
 }
 
-static void cholesky(Ctx& c, double* P, int npad, double* Dinv, double* info, int pivot_base) {
+// info: first of the 4 stats doubles of problem 0 (stride 4 between problems)
+static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_base) {
   const int nb = npad / NB;
   for (int k0 = 0; k0 < nb && !c.rc; k0 += OUTER_PANELS) {
     const int kend = k0 + OUTER_PANELS < nb ? k0 + OUTER_PANELS : nb;
     for (int k = k0; k < kend && !c.rc; ++k) {
-      double* Akk = P + (int64_t)k * NB * npad + (int64_t)k * NB;
-      double* Dk = Dinv + (int64_t)k * NB * NB;
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(1), dim3(64), 0, c.stream, Akk, (int64_t)npad, Dk,
-                         info, pivot_base + k * NB);
+      const Mat Akk = P.at((int64_t)k * NB, (int64_t)k * NB);
+      const Mat Dk{Dinv.p + (int64_t)k * NB * NB, NB, Dinv.ps};
+      hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.nprob), dim3(64), 0, c.stream, Akk.p, (int64_t)npad, Dk.p,
+                         info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
       if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
       const int rem = npad - (k + 1) * NB;
       if (rem <= 0) break;
-      double* panel = Akk + (int64_t)NB * npad;  // rows below the diagonal block, same columns
+      const Mat panel = Akk.at(NB, 0);  // rows below the diagonal block, same columns
       // panel <- panel * Linv'  (in place: every workgroup reads exactly the rows it writes)
-      gemm<false, true>(c, rem, NB, NB, 1.0, panel, npad, Dk, NB, 0.0, panel, npad);
+      gemm<false, true>(c, rem, NB, NB, 1.0, panel, Dk, 0.0, panel);
       // remaining columns of this outer panel <- themselves - panel panel'   (lower tiles only)
       const int inner_cols = (kend - 1 - k) * NB;
-      if (inner_cols > 0)
-        gemm<false, true>(c, rem, inner_cols, NB, -1.0, panel, npad, panel, npad, 1.0, panel + NB, npad, nullptr, 0, 1);
+      if (inner_cols > 0) gemm<false, true>(c, rem, inner_cols, NB, -1.0, panel, panel, 1.0, panel.at(0, NB), 1);
     }
     const int rem2 = npad - kend * NB;
     if (rem2 > 0) {
       // trailing <- trailing - L21 L21' with all columns of the outer panel at once
       const int kw = (kend - k0) * NB;
-      const double* L21 = P + (int64_t)kend * NB * npad + (int64_t)k0 * NB;
-      double* A22 = P + (int64_t)kend * NB * npad + (int64_t)kend * NB;
-      gemm<false, true>(c, rem2, rem2, kw, -1.0, L21, npad, L21, npad, 1.0, A22, npad, nullptr, 0, 1);
+      const Mat L21 = P.at((int64_t)kend * NB, (int64_t)k0 * NB);
+      gemm<false, true>(c, rem2, rem2, kw, -1.0, L21, L21, 1.0, P.at((int64_t)kend * NB, (int64_t)kend * NB), 1);
     }
   }
   build_big_inverses(c, P, npad, Dinv);
@@ -449,57 +495,52 @@ static void cholesky(Ctx& c, double* P, int npad, double* Dinv, double* info, in
 
 // Y = L^-1 Bw ; Bw (npad x w, ld = w) is consumed.  Full 256-row blocks use their inverted diagonal
 // block, the (< 256 rows) remainder the 64x64 inverses.
-static void solve_lower(Ctx& c, const double* L, int npad, const double* Dinv, double* Bw, double* Y,
-                        int w) {
+static void solve_lower(Ctx& c, Mat L, int npad, Mat Dinv, Mat Bw, Mat Y, int w) {
   const int nb = npad / NB, nbig = npad / BIG;
-  const double* Dbig = dbig_of(Dinv, npad);
+  const Mat Dbig = dbig_of(Dinv, npad);
   for (int ob = 0; ob < nbig && !c.rc; ++ob) {
     const int64_t r0 = (int64_t)ob * BIG;
-    gemm<false, false>(c, BIG, w, BIG, 1.0, Dbig + (int64_t)ob * BIG * BIG, BIG, Bw + r0 * w, w, 0.0, Y + r0 * w, w);
+    gemm<false, false>(c, BIG, w, BIG, 1.0, Dbig.at(r0, 0), Bw.at(r0, 0), 0.0, Y.at(r0, 0));
     const int rem = npad - (int)(r0 + BIG);
-    if (rem > 0)
-      gemm<false, false>(c, rem, w, BIG, -1.0, L + (r0 + BIG) * npad + r0, npad, Y + r0 * w, w, 1.0,
-                         Bw + (r0 + BIG) * w, w);
+    if (rem > 0) gemm<false, false>(c, rem, w, BIG, -1.0, L.at(r0 + BIG, r0), Y.at(r0, 0), 1.0, Bw.at(r0 + BIG, 0));
   }
   for (int k = nbig * OUTER_PANELS; k < nb && !c.rc; ++k) {
-    const double* Dk = Dinv + (int64_t)k * NB * NB;
-    gemm<false, false>(c, NB, w, NB, 1.0, Dk, NB, Bw + (int64_t)k * NB * w, w, 0.0,
-                       Y + (int64_t)k * NB * w, w);
+    const Mat Dk{Dinv.p + (int64_t)k * NB * NB, NB, Dinv.ps};
+    const int64_t r0 = (int64_t)k * NB;
+    gemm<false, false>(c, NB, w, NB, 1.0, Dk, Bw.at(r0, 0), 0.0, Y.at(r0, 0));
     const int rem = npad - (k + 1) * NB;
-    if (rem > 0)
-      gemm<false, false>(c, rem, w, NB, -1.0, L + (int64_t)(k + 1) * NB * npad + (int64_t)k * NB, npad,
-                         Y + (int64_t)k * NB * w, w, 1.0, Bw + (int64_t)(k + 1) * NB * w, w);
+    if (rem > 0) gemm<false, false>(c, rem, w, NB, -1.0, L.at(r0 + NB, r0), Y.at(r0, 0), 1.0, Bw.at(r0 + NB, 0));
   }
 }
 
 // X = L^-T Zw ; Zw (npad x w) is consumed
-static void solve_lower_t(Ctx& c, const double* L, int npad, const double* Dinv, double* Zw, double* X,
-                          int w) {
+static void solve_lower_t(Ctx& c, Mat L, int npad, Mat Dinv, Mat Zw, Mat X, int w) {
   const int nb = npad / NB, nbig = npad / BIG;
-  const double* Dbig = dbig_of(Dinv, npad);
+  const Mat Dbig = dbig_of(Dinv, npad);
   for (int k = nb - 1; k >= nbig * OUTER_PANELS && !c.rc; --k) {
-    const double* Dk = Dinv + (int64_t)k * NB * NB;
-    gemm<true, false>(c, NB, w, NB, 1.0, Dk, NB, Zw + (int64_t)k * NB * w, w, 0.0,
-                      X + (int64_t)k * NB * w, w);
+    const Mat Dk{Dinv.p + (int64_t)k * NB * NB, NB, Dinv.ps};
+    const int64_t r0 = (int64_t)k * NB;
+    gemm<true, false>(c, NB, w, NB, 1.0, Dk, Zw.at(r0, 0), 0.0, X.at(r0, 0));
     if (k > 0)  // Zw[0:k] -= L[k, 0:k]' X_k
-      gemm<true, false>(c, k * NB, w, NB, -1.0, L + (int64_t)k * NB * npad, npad,
-                        X + (int64_t)k * NB * w, w, 1.0, Zw, w);
+      gemm<true, false>(c, k * NB, w, NB, -1.0, L.at(r0, 0), X.at(r0, 0), 1.0, Zw);
   }
   for (int ob = nbig - 1; ob >= 0 && !c.rc; --ob) {
     const int64_t r0 = (int64_t)ob * BIG;
-    gemm<true, false>(c, BIG, w, BIG, 1.0, Dbig + (int64_t)ob * BIG * BIG, BIG, Zw + r0 * w, w, 0.0, X + r0 * w, w);
+    gemm<true, false>(c, BIG, w, BIG, 1.0, Dbig.at(r0, 0), Zw.at(r0, 0), 0.0, X.at(r0, 0));
     if (r0 > 0)  // Zw[0:r0] -= L[r0:r0+256, 0:r0]' X_ob
-      gemm<true, false>(c, (int)r0, w, BIG, -1.0, L + r0 * npad, npad, X + r0 * w, w, 1.0, Zw, w);
+      gemm<true, false>(c, (int)r0, w, BIG, -1.0, L.at(r0, 0), X.at(r0, 0), 1.0, Zw);
   }
 }
 
+// Workspace: every array holds all problems of the batch back to back ([problem][elements]).
 struct SolveLayout {
   int npad, mpad, rpad;
+  size_t e_Pt, e_Dinv, e_Ap, e_Y, e_Bw, e_S, e_DinvS, e_mr, e_nr;  // elements per problem
   size_t off_Pt, off_Dinv, off_Ap, off_Y, off_Bw, off_S, off_DinvS, off_Bp, off_T1, off_T2, off_Lam,
       off_Z, off_Xt, off_X2, off_scal, total;
 };
 
-static SolveLayout solve_layout(int n, int m, int nrhs) {
+static SolveLayout solve_layout(int n, int m, int nrhs, int nprob) {
   SolveLayout l;
   l.npad = (int)round_up(n, NB);
   l.mpad = (int)round_up(m, NB);
@@ -507,27 +548,122 @@ static SolveLayout solve_layout(int n, int m, int nrhs) {
   size_t o = 0;
   auto take = [&](size_t elems) {
     size_t r = o;
-    o += (size_t)round_up((int64_t)(elems * sizeof(double)), 256);
+    o += (size_t)round_up((int64_t)(elems * nprob * sizeof(double)), 256);
     return r;
   };
   const size_t wmax = (size_t)(l.mpad > l.rpad ? l.mpad : l.rpad);
-  l.off_Pt = take((size_t)l.npad * l.npad);
-  l.off_Dinv = take(dinv_elems(l.npad));
-  l.off_Ap = take((size_t)l.mpad * l.npad);
-  l.off_Y = take((size_t)l.npad * l.mpad);
-  l.off_Bw = take((size_t)(l.npad > l.mpad ? l.npad : l.mpad) * wmax);
-  l.off_S = take((size_t)l.mpad * l.mpad);
-  l.off_DinvS = take(dinv_elems(l.mpad));
-  l.off_Bp = take((size_t)l.mpad * l.rpad);
-  l.off_T1 = take((size_t)l.mpad * l.rpad);
-  l.off_T2 = take((size_t)l.mpad * l.rpad);
-  l.off_Lam = take((size_t)l.mpad * l.rpad);
-  l.off_Z = take((size_t)l.npad * l.rpad);
-  l.off_Xt = take((size_t)l.npad * l.rpad);
-  l.off_X2 = take((size_t)l.npad * l.rpad);
-  l.off_scal = take(32);
+  l.e_Pt = (size_t)l.npad * l.npad;
+  l.e_Dinv = dinv_elems(l.npad);
+  l.e_Ap = (size_t)l.mpad * l.npad;
+  l.e_Y = (size_t)l.npad * l.mpad;
+  l.e_Bw = (size_t)(l.npad > l.mpad ? l.npad : l.mpad) * wmax;
+  l.e_S = (size_t)l.mpad * l.mpad;
+  l.e_DinvS = dinv_elems(l.mpad);
+  l.e_mr = (size_t)l.mpad * l.rpad;
+  l.e_nr = (size_t)l.npad * l.rpad;
+  l.off_Pt = take(l.e_Pt);
+  l.off_Dinv = take(l.e_Dinv);
+  l.off_Ap = take(l.e_Ap);
+  l.off_Y = take(l.e_Y);
+  l.off_Bw = take(l.e_Bw);
+  l.off_S = take(l.e_S);
+  l.off_DinvS = take(l.e_DinvS);
+  l.off_Bp = take(l.e_mr);
+  l.off_T1 = take(l.e_mr);
+  l.off_T2 = take(l.e_mr);
+  l.off_Lam = take(l.e_mr);
+  l.off_Z = take(l.e_nr);
+  l.off_Xt = take(l.e_nr);
+  l.off_X2 = take(l.e_nr);
+  l.off_scal = take(4);
   l.total = o;
   return l;
+}
+
+static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double* l2_diag, const double* A,
+                            int32_t m, const double* B, int32_t nrhs, double schur_reg, int32_t n_refine,
+                            int32_t nprob, double* X, double* stats, void* ws, size_t ws_bytes, void* stream_v,
+                            const char* who) {
+  if (!G || !A || !X || !stats || !ws) return fail(AGGF_ERR_ARG, "%s: NULL pointer", who);
+  if (n <= 0 || m <= 0 || nrhs <= 0 || nprob <= 0) return fail(AGGF_ERR_ARG, "%s: empty problem", who);
+  if (!B && nrhs != m) return fail(AGGF_ERR_ARG, "%s: B == NULL needs nrhs == m", who);
+  if (!(l2 >= 0.0)) return fail(AGGF_ERR_ARG, "%s: l2 must be >= 0", who);
+  if (!(schur_reg >= 0.0) || n_refine < 0 || n_refine > 100) return fail(AGGF_ERR_ARG, "%s: bad schur_reg / n_refine", who);
+  if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "%s: workspace not 256-byte aligned", who);
+  const SolveLayout l = solve_layout(n, m, nrhs, nprob);
+  if (ws_bytes < l.total) return fail(AGGF_ERR_WORKSPACE, "%s: workspace too small (%zu < %zu)", who, ws_bytes, l.total);
+  if ((int64_t)nprob * 2 * (l.npad / BIG + 1) > 65535) return fail(AGGF_ERR_ARG, "%s: too many problems", who);
+  Ctx c;
+  c.stream = (hipStream_t)stream_v;
+  c.nprob = nprob;
+  char* w = (char*)ws;
+  const int npad = l.npad, mpad = l.mpad, rpad = l.rpad;
+  auto M_ = [&](size_t off, int64_t ld, size_t elems) { return Mat{reinterpret_cast<double*>(w + off), ld, (int64_t)elems}; };
+  const Mat Pt = M_(l.off_Pt, npad, l.e_Pt), Dinv = M_(l.off_Dinv, NB, l.e_Dinv), Ap = M_(l.off_Ap, npad, l.e_Ap),
+            Y = M_(l.off_Y, mpad, l.e_Y), S = M_(l.off_S, mpad, l.e_S), DinvS = M_(l.off_DinvS, NB, l.e_DinvS),
+            Bp = M_(l.off_Bp, rpad, l.e_mr), T1 = M_(l.off_T1, rpad, l.e_mr), T2 = M_(l.off_T2, rpad, l.e_mr),
+            Lam = M_(l.off_Lam, rpad, l.e_mr), Z = M_(l.off_Z, rpad, l.e_nr), Xt = M_(l.off_Xt, rpad, l.e_nr),
+            X2 = M_(l.off_X2, rpad, l.e_nr);
+  const Mat Bw_m = M_(l.off_Bw, mpad, l.e_Bw);  // (npad x mpad) view
+  const Mat Bw_r = M_(l.off_Bw, rpad, l.e_Bw);  // (mpad x rpad) view
+  double* scal = reinterpret_cast<double*>(w + l.off_scal);  // 4 doubles per problem
+  hipStream_t st = c.stream;
+  const int np = nprob;
+  const int64_t g_ps = (int64_t)n * n, a_ps = (int64_t)m * n, b_ps = (int64_t)m * nrhs;
+
+  hipLaunchKernelGGL(init_stats_kernel, dim3((unsigned)ceil_div(4 * np, 64)), dim3(64), 0, st, stats, 4 * np);
+  hipLaunchKernelGGL(max_diag_kernel, dim3(1, np), dim3(256), 0, st, G, n, g_ps, l2, l2_diag, scal, (int64_t)4);
+  hipLaunchKernelGGL(copy_scalar_kernel, dim3(np), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
+  hipLaunchKernelGGL(build_pt_kernel, flat_grid((int64_t)npad * npad, np), dim3(256), 0, st, G, n, g_ps, npad, l2,
+                     l2_diag, scal, (int64_t)4, Pt.p, Pt.ps);
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad, np), dim3(256), 0, st, A, m, n, a_ps, 0, Ap.p,
+                     mpad, npad, Ap.ps);
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * rpad, np), dim3(256), 0, st, B,
+                     B ? m : (m < nrhs ? m : nrhs), nrhs, b_ps, 0, Bp.p, mpad, rpad, Bp.ps);
+  AGGF_LAUNCH_OK();
+  // P~ = P/s + A'A  (the factorisation reads the lower triangle only)
+  gemm<true, false>(c, npad, npad, mpad, 1.0, Ap, Ap, 1.0, Pt, 1);
+  cholesky(c, Pt, npad, Dinv, stats, 0);
+  // Y = L^-1 A'
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * mpad, np), dim3(256), 0, st, A, m, n, a_ps, 1, Bw_m.p,
+                     npad, mpad, Bw_m.ps);
+  solve_lower(c, Pt, npad, Dinv, Bw_m, Y, mpad);
+  // S = Y'Y (identity on the padding), factor it
+  gemm<true, false>(c, mpad, mpad, npad, 1.0, Y, Y, 0.0, S, 1);
+  if (mpad > m) hipLaunchKernelGGL(fix_pad_diag_kernel, dim3(1, np), dim3(64), 0, st, S.p, m, mpad, S.ps);
+  if (schur_reg > 0.0) hipLaunchKernelGGL(schur_reg_kernel, dim3(1, np), dim3(256), 0, st, S.p, m, mpad, S.ps, schur_reg);
+  cholesky(c, S, mpad, DinvS, stats, n);
+  // Lam = S^-1 Bp ; Xt = L^-T (Y Lam)
+  auto schur_solve = [&](Mat rhs, Mat out) {
+    if (hipMemcpyAsync(T1.p, rhs.p, (size_t)np * l.e_mr * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
+      c.rc = fail(AGGF_ERR_HIP, "%s: device copy failed", who);
+    solve_lower(c, S, mpad, DinvS, T1, T2, rpad);
+    solve_lower_t(c, S, mpad, DinvS, T2, out, rpad);
+  };
+  schur_solve(Bp, Lam);
+  gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, Lam, 0.0, Z);
+  solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
+  // refinement on the constraint residual R = A Xt - B:  Xt -= P~^-1 A' S^-1 R
+  for (int it = 0; it < n_refine; ++it) {
+    gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, Xt, 0.0, Lam);
+    hipLaunchKernelGGL(resid_kernel, dim3(1, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps,
+                       it == 0 ? stats + 2 : scal + 1, (int64_t)4);
+    // padded rows/cols of A Xt - Bp are exact zeros, so the padded residual needs no masking.
+    // Bw's storage is reused as the (mpad x rpad) scratch for S^-1 R: per problem it holds at least
+    // mpad * rpad elements, but with its own per-problem stride
+    const Mat SR{Bw_r.p, rpad, Bw_r.ps};
+    schur_solve(Lam, SR);
+    gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, SR, 0.0, Z);
+    solve_lower_t(c, Pt, npad, Dinv, Z, X2, rpad);
+    hipLaunchKernelGGL(axpy_kernel, flat_grid((int64_t)np * l.e_nr), dim3(256), 0, st, Xt.p, X2.p, -1.0,
+                       (int64_t)np * (int64_t)l.e_nr);
+  }
+  gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, Xt, 0.0, Lam);
+  hipLaunchKernelGGL(resid_kernel, dim3(1, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps, stats + 1, (int64_t)4);
+  hipLaunchKernelGGL(crop_transpose_kernel, flat_grid((int64_t)nrhs * n, np), dim3(256), 0, st, Xt.p, rpad, Xt.ps, n,
+                     nrhs, X);
+  AGGF_LAUNCH_OK();
+  return c.rc;
 }
 
 }  // namespace aggf
@@ -536,76 +672,28 @@ using namespace aggf;
 
 extern "C" size_t aggf_eq_qp_workspace_bytes(int32_t n, int32_t m, int32_t nrhs) {
   if (n <= 0 || m <= 0 || nrhs <= 0) return 0;
-  return solve_layout(n, m, nrhs).total;
+  return solve_layout(n, m, nrhs, 1).total;
 }
 
 extern "C" int aggf_eq_qp_solve(const double* G, int32_t n, double l2, const double* l2_diag,
                                 const double* A, int32_t m, const double* B, int32_t nrhs,
                                 double schur_reg, int32_t n_refine, double* X, double* stats,
                                 void* ws, size_t ws_bytes, void* stream_v) {
-  if (!G || !A || !X || !stats || !ws) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve: NULL pointer");
-  if (n <= 0 || m <= 0 || nrhs <= 0) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve: empty problem");
-  if (!B && nrhs != m) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve: B == NULL needs nrhs == m");
-  if (!(l2 >= 0.0)) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve: l2 must be >= 0");
-  if (!(schur_reg >= 0.0) || n_refine < 0 || n_refine > 100)
-    return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve: bad schur_reg / n_refine");
-  if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve: workspace not 256-byte aligned");
-  const SolveLayout l = solve_layout(n, m, nrhs);
-  if (ws_bytes < l.total) return fail(AGGF_ERR_WORKSPACE, "aggf_eq_qp_solve: workspace too small (%zu < %zu)", ws_bytes, l.total);
-  Ctx c;
-  c.stream = (hipStream_t)stream_v;
-  char* w = (char*)ws;
-  auto P = [&](size_t off) { return reinterpret_cast<double*>(w + off); };
-  double *Pt = P(l.off_Pt), *Dinv = P(l.off_Dinv), *Ap = P(l.off_Ap), *Y = P(l.off_Y), *Bw = P(l.off_Bw),
-         *S = P(l.off_S), *DinvS = P(l.off_DinvS), *Bp = P(l.off_Bp), *T1 = P(l.off_T1), *T2 = P(l.off_T2),
-         *Lam = P(l.off_Lam), *Z = P(l.off_Z), *Xt = P(l.off_Xt), *X2 = P(l.off_X2), *scal = P(l.off_scal);
-  const int npad = l.npad, mpad = l.mpad, rpad = l.rpad;
-  hipStream_t st = c.stream;
+  return eq_qp_solve_impl(G, n, l2, l2_diag, A, m, B, nrhs, schur_reg, n_refine, 1, X, stats, ws, ws_bytes, stream_v,
+                          "aggf_eq_qp_solve");
+}
 
-  hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(64), 0, st, stats);
-  hipLaunchKernelGGL(max_diag_kernel, dim3(1), dim3(256), 0, st, G, n, l2, l2_diag, scal);
-  hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, st, scal, stats + 3);
-  hipLaunchKernelGGL(build_pt_kernel, flat_grid((int64_t)npad * npad), dim3(256), 0, st, G, n, npad, l2, l2_diag, scal, Pt);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad), dim3(256), 0, st, A, m, n, 0, Ap, mpad, npad);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * rpad), dim3(256), 0, st, B, B ? m : (m < nrhs ? m : nrhs), nrhs, 0, Bp, mpad, rpad);
-  AGGF_LAUNCH_OK();
-  // P~ = P/s + A'A
-  gemm<true, false>(c, npad, npad, mpad, 1.0, Ap, npad, Ap, npad, 1.0, Pt, npad);
-  cholesky(c, Pt, npad, Dinv, stats, 0);
-  // Y = L^-1 A'
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * mpad), dim3(256), 0, st, A, m, n, 1, Bw, npad, mpad);
-  solve_lower(c, Pt, npad, Dinv, Bw, Y, mpad);
-  // S = Y'Y (identity on the padding), factor it
-  gemm<true, false>(c, mpad, mpad, npad, 1.0, Y, mpad, Y, mpad, 0.0, S, mpad);
-  if (mpad > m) hipLaunchKernelGGL(fix_pad_diag_kernel, dim3(1), dim3(64), 0, st, S, m, mpad);
-  if (schur_reg > 0.0) hipLaunchKernelGGL(schur_reg_kernel, dim3(1), dim3(256), 0, st, S, m, mpad, schur_reg);
-  cholesky(c, S, mpad, DinvS, stats, n);
-  // Lam = S^-1 Bp ; Xt = L^-T (Y Lam)
-  auto schur_solve = [&](const double* rhs, double* out) {
-    if (hipMemcpyAsync(T1, rhs, (size_t)mpad * rpad * sizeof(double), hipMemcpyDeviceToDevice, st) != hipSuccess)
-      c.rc = fail(AGGF_ERR_HIP, "aggf_eq_qp_solve: device copy failed");
-    solve_lower(c, S, mpad, DinvS, T1, T2, rpad);
-    solve_lower_t(c, S, mpad, DinvS, T2, out, rpad);
-  };
-  schur_solve(Bp, Lam);
-  gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, mpad, Lam, rpad, 0.0, Z, rpad);
-  solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
-  // refinement on the constraint residual R = A Xt - B:  Xt -= P~^-1 A' S^-1 R
-  for (int it = 0; it < n_refine; ++it) {
-    gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, npad, Xt, rpad, 0.0, Lam, rpad);
-    hipLaunchKernelGGL(resid_kernel, dim3(1), dim3(256), 0, st, Lam, Bp, m, nrhs, rpad,
-                       it == 0 ? stats + 2 : scal + 1);
-    // padded rows/cols of A Xt - Bp are exact zeros, so the padded residual needs no masking
-    schur_solve(Lam, Bw);  // Bw reused as (mpad x rpad) scratch for S^-1 R
-    gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, mpad, Bw, rpad, 0.0, Z, rpad);
-    solve_lower_t(c, Pt, npad, Dinv, Z, X2, rpad);
-    hipLaunchKernelGGL(axpy_kernel, flat_grid((int64_t)npad * rpad), dim3(256), 0, st, Xt, X2, -1.0, (int64_t)npad * rpad);
-  }
-  gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, npad, Xt, rpad, 0.0, Lam, rpad);
-  hipLaunchKernelGGL(resid_kernel, dim3(1), dim3(256), 0, st, Lam, Bp, m, nrhs, rpad, stats + 1);
-  hipLaunchKernelGGL(crop_transpose_kernel, flat_grid((int64_t)nrhs * n), dim3(256), 0, st, Xt, rpad, n, nrhs, X);
-  AGGF_LAUNCH_OK();
-  return c.rc;
+extern "C" size_t aggf_eq_qp_batched_workspace_bytes(int32_t n, int32_t m, int32_t nrhs, int32_t n_problems) {
+  if (n <= 0 || m <= 0 || nrhs <= 0 || n_problems <= 0) return 0;
+  return solve_layout(n, m, nrhs, n_problems).total;
+}
+
+extern "C" int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, const double* l2_diag,
+                                        const double* A, int32_t m, const double* B, int32_t nrhs,
+                                        double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
+                                        double* stats, void* ws, size_t ws_bytes, void* stream_v) {
+  return eq_qp_solve_impl(G, n, l2, l2_diag, A, m, B, nrhs, schur_reg, n_refine, n_problems, X, stats, ws, ws_bytes,
+                          stream_v, "aggf_eq_qp_solve_batched");
 }
 
 // ---- Gram algebra for cross-validation (project_forces_grid_cv with Gram reuse) ---------------
@@ -655,11 +743,12 @@ extern "C" int aggf_gram_quadform(const double* G, int32_t n, const double* X, i
   double* Gp = reinterpret_cast<double*>(ws);
   double* Xp = Gp + (size_t)npad * npad;
   double* Y = Xp + (size_t)mpad * npad;
-  Ctx c{st};
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * npad), dim3(256), 0, st, G, n, n, 0, Gp, npad, npad);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad), dim3(256), 0, st, X, m, n, 0, Xp, mpad, npad);
+  Ctx c;
+  c.stream = st;
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * npad), dim3(256), 0, st, G, n, n, (int64_t)0, 0, Gp, npad, npad, (int64_t)0);
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad), dim3(256), 0, st, X, m, n, (int64_t)0, 0, Xp, mpad, npad, (int64_t)0);
   AGGF_LAUNCH_OK();
-  gemm<false, false>(c, mpad, npad, npad, 1.0, Xp, npad, Gp, npad, 0.0, Y, npad);  // Y = X G
+  gemm<false, false>(c, mpad, npad, npad, 1.0, Mat{Xp, npad, 0}, Mat{Gp, npad, 0}, 0.0, Mat{Y, npad, 0});  // Y = X G
   if (c.rc) return c.rc;
   hipLaunchKernelGGL(rowdot_kernel, dim3(m), dim3(256), 0, st, Xp, (int64_t)npad, Y, (int64_t)npad, n, q);
   AGGF_LAUNCH_OK();

@@ -162,8 +162,19 @@ def recognise(featurizers) -> Optional[Tuple[bool, Optional[dict]]]:
     return None
 
 
-_SOLVE_STREAMS = 4  # side streams for the per-site solves (the hardware exposes a few concurrent queues)
-_SOLVE_CHUNK = 8    # sites per chunk: one (n_feat, n_feat) float64 Gram each is kept until its solve has run
+_SOLVE_MEMORY_FRACTION = 0.6  # share of the free HBM the batched solve of a chunk of sites may take
+
+
+def _sites_per_batch(n_cg: int, n_feat: int, m: int, device) -> int:
+    """How many cg sites are fitted side by side: each needs its Gram matrix, its constraint rows and one
+    problem's share of the batched solver workspace.  288 GB of HBM hold all 64 sites of BASELINE config 4
+    (n_feat 6139: 0.3 GB of Gram + 0.5 GB of workspace per site)."""
+    import torch
+
+    per_site = 8 * (n_feat * n_feat + m * n_feat + m) + K.eq_qp_batched_bytes(n_feat, m, 1, 1)
+    free, _ = torch.cuda.mem_get_info(device)
+    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # reusable cached blocks
+    return int(max(1, min(n_cg, (_SOLVE_MEMORY_FRACTION * free) // per_site)))
 
 
 def fit_id_gb(
@@ -197,8 +208,11 @@ def fit_id_gb(
     if n_feat == 0:
         raise ValueError("featuriser produces no features")
     Fg = geo.group_forces(traj.forces)
+    # The regression matrix goes straight into the Gram kernel's in-place layout: float64 storage (the
+    # float32 products of float32 forces widened on store -- K1 multiplies in float64, see below), feature
+    # columns padded with zeros to a multiple of the 128-wide tile.  No pack pass, no float32 round trip.
     ld = -(-n_feat // 128) * 128
-    R3 = torch.empty((geo.T, ld, 3), dtype=Fg.dtype, device=geo.dev)
+    R3 = torch.empty((geo.T, ld, 3), dtype=torch.float64, device=geo.dev)
     if ld > n_feat:
         R3[:, n_feat:, :] = 0
     Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).to(geo.dev)  # (n_cg, G) float64
@@ -219,54 +233,45 @@ def fit_id_gb(
     Pg_sel = take_global_frames(geo.Pg, flat_idx, comm)
     cg_sel = take_global_frames(geo.cg, flat_idx, comm)
     sel_begin = np.concatenate([[0], np.cumsum([len(u) for u in used])]).astype(np.int64)
-    # The per-site solve (K2) is a chain of small dependent kernels that leaves most of the GPU idle,
-    # while the per-site Gram (K1) fills it (and, once running, keeps later queues waiting).  Sites are
-    # therefore processed in chunks: all Grams of a chunk on the main stream, then the solves of the
-    # chunk side by side on a few streams.
-    main = torch.cuda.current_stream(geo.dev)
-    side = K.side_streams(geo.dev, _SOLVE_STREAMS)
-
-    def prepare(site: int):
-        K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
-        # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
-        # exceeds l2 = 10 relative to force-squared sums of ~1e8 and P is no longer numerically positive
-        # definite; the exact Gram of the float32 regression matrix always is
-        Gm = K.gram(R3, None, None, n_feat, torch.float64)
-        all_reduce_sum_(Gm, comm)
-        lo, hi = int(sel_begin[site]), int(sel_begin[site + 1])
-        S = hi - lo
-        gauss = None
-        if n_ch:
-            gauss, _ = K.gb_channels(Pg_sel[lo:hi].contiguous(), cg_sel[lo:hi].contiguous(), site, geo.sizes, n_ch,
-                                     centers, width, CLIP)
-        A2, b2 = K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site)  # K4b
-        return Gm, A2, b2
-
-    for c0 in range(0, n_cg, _SOLVE_CHUNK):
-        sites = list(range(c0, min(n_cg, c0 + _SOLVE_CHUNK)))
-        problems = [prepare(site) for site in sites]
-        ready = torch.cuda.Event()
-        ready.record(main)
-        results = []
-        for j, (Gm, A2, b2) in enumerate(problems):
-            st_side = side[j % _SOLVE_STREAMS]
-            st_side.wait_event(ready)
-            with torch.cuda.stream(st_side):
-                results.append(K.eq_qp_solve(Gm, float(l2_regularization), None, A2, b2, schur_reg=1e-12, n_refine=3))
-            for t in (Gm, A2, b2):
-                t.record_stream(st_side)  # allocated on the main stream, read on the side stream
-        for st_side in side:
-            main.wait_stream(st_side)     # the next chunk's Grams start after these solves
-            st_side.synchronize()
-        for site, (X, stats) in zip(sites, results):
-            st = stats.cpu().numpy()
+    n_sel = {len(u) for u in used}
+    # Sites are independent problems of identical shape (own P, own A, one right-hand side): a batch of them
+    # is fitted side by side -- K1 per site into one (sites, n_feat, n_feat) stack, ONE all-reduce of the
+    # stack, then ONE batched K2 in which every step of the factorisation is a single launch over all sites.
+    # (One solve alone is a chain of ~300 small dependent kernels that leaves the GPU idle: 20 ms per site at
+    # n_feat = 6139 against 37 ms for its Gram matrix.)
+    m_rows = max(n_sel) * n_cg if n_sel else 0
+    per_batch = _sites_per_batch(n_cg, n_feat, m_rows, geo.dev) if len(n_sel) == 1 else 1
+    for c0 in range(0, n_cg, per_batch):
+        sites = list(range(c0, min(n_cg, c0 + per_batch)))
+        S = len(used[sites[0]])
+        Gs = torch.empty((len(sites), n_feat, n_feat), dtype=torch.float64, device=geo.dev)
+        As = torch.empty((len(sites), S * n_cg, n_feat), dtype=torch.float64, device=geo.dev)
+        bs = torch.empty((len(sites), S * n_cg, 1), dtype=torch.float64, device=geo.dev)
+        for j, site in enumerate(sites):
+            K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
+            # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
+            # exceeds l2 = 10 relative to force-squared sums of ~1e8 and P is no longer numerically positive
+            # definite; the exact Gram of the float32 regression matrix always is
+            K.gram(R3, None, None, n_feat, torch.float64, out=Gs[j])
+            lo, hi = int(sel_begin[site]), int(sel_begin[site + 1])
+            gauss = None
+            if n_ch:
+                gauss, _ = K.gb_channels(Pg_sel[lo:hi].contiguous(), cg_sel[lo:hi].contiguous(), site, geo.sizes,
+                                         n_ch, centers, width, CLIP)
+            K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j])  # K4b
+        all_reduce_sum_(Gs, comm)
+        X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3)
+        st_all = stats.cpu().numpy()
+        X_host = X[:, 0, :].cpu().numpy()
+        for j, site in enumerate(sites):
+            st = st_all[j]
             if st[0] != 0 or not np.isfinite(st[1]):
                 raise ValueError(
                     f"Map optimization failed. (site {site}: pivot {int(st[0])}, "
                     f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
                 )
-            coefs[site] = X[0].cpu().numpy()
-        del problems, results
+            coefs[site] = X_host[j]
+        del Gs, As, bs, X, stats
     coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
 
     def apply_f(points, copoints):

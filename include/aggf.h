@@ -98,6 +98,20 @@ int aggf_eq_qp_solve(const double* G, int32_t n, double l2, const double* l2_dia
                      double schur_reg, int32_t n_refine, double* X, double* stats, void* ws,
                      size_t ws_bytes, void* stream);
 
+/* The same solve for n_problems INDEPENDENT problems of identical shape at once -- the
+ * per-site loop of the featurised fit, featlinearmap.py:349-384, where every cg site has
+ * its own P and A: problem p reads G + p*n*n, A + p*m*n, B + p*m*nrhs (B == NULL:
+ * identity for all), writes X + p*nrhs*n and stats + 4*p; l2 and l2_diag are shared.
+ * Every step of the factorisation is ONE launch over all problems (the problem index is
+ * a grid dimension), so the chain of small dependent kernels that bounds a single solve
+ * is paid once per batch instead of once per site.  Results are bit-identical to
+ * n_problems separate aggf_eq_qp_solve calls. */
+size_t aggf_eq_qp_batched_workspace_bytes(int32_t n, int32_t m, int32_t nrhs, int32_t n_problems);
+int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, const double* l2_diag,
+                             const double* A, int32_t m, const double* B, int32_t nrhs,
+                             double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
+                             double* stats, void* ws, size_t ws_bytes, void* stream);
+
 /* W[i, a] = X[i, group_of_atom[a]]  -- `con_mat @ gen_map`, qp/qplinear.py:86.
  * X: (n_rows, n_red) float64; group_of_atom: N int32; W: (n_rows, N) float64. */
 int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
@@ -188,7 +202,9 @@ int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int32_t G, int
                      int32_t site, const float* sizes, int32_t n_ch, const float* centers,
                      int32_t n_basis, double width, double clip, float* gauss, float* grad,
                      void* stream);
-/* R3 (T, ld_feat, 3) in f_dtype, the regression matrix of featlinearmap.py:361-369 in the
+/* R3 (T, ld_feat, 3) in out_dtype (f_dtype, or AGGF_F64 for float32 forces: the float32
+ * products widened on store, which with ld_feat % 128 == 0 is aggf_gram's in-place operand for
+ * float64 products), the regression matrix of featlinearmap.py:361-369 in the
  * layout aggf_gram consumes: columns [0, n_id) = Fg (id_feat block, n_id = 0 or G), then
  * R3[t, n_id + ch*n_basis + k, d] = g_k(r) Fg[t,ch,d] + kbt |ch| g_k'(r) u_d for ch < n_ch.
  * Fg: (T, G, 3) group force sums in f_dtype.  Columns beyond n_id + n_ch*n_basis are not
@@ -196,7 +212,7 @@ int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int32_t G, int
 int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
                    int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
                    int32_t n_ch, const float* centers, int32_t n_basis, double width, double clip,
-                   double kbt, int32_t ld_feat, void* R3, void* stream);
+                   double kbt, int32_t ld_feat, void* R3, int out_dtype, void* stream);
 /* out (T, n_cg, 3) float64: application of the feature-linear force map
  * (featlinearmap.py:512-520 + map/core.py:428-430) for all sites;
  * coef: (n_cg, n_feat) float64, n_feat = n_id + n_ch*n_basis. */

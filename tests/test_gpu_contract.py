@@ -75,21 +75,25 @@ def test_clamap_call_with_user_scale_and_trans_matches_reference_formula():
 
 
 def _dense_featuriser(points, cmap, constraints):
-    """A user-written featuriser following the reference protocol (featlinearmap.py:49-67): per site,
-    three smooth functions of the distance to the mapped site per atom, and their divergences."""
+    """A user-written featuriser following the reference protocol (featlinearmap.py:49-67): per site, a
+    one-hot atom "type" (a % 7; makes the sampled constraint rows feasible, as id_feat does for the
+    reference) and two smooth functions of the distance to the mapped site, with their divergences."""
     pts = np.asarray(points, dtype=np.float64)
+    T, N, _ = pts.shape
     cg = orc.linearmap_apply(pts, np.asarray(cmap.standard_matrix, dtype=np.float64))
+    types = np.zeros((T, N, 7))
+    types[:, np.arange(N), np.arange(N) % 7] = 1.0
     feats, divs = [], []
     for c in range(cmap.n_cg_sites):
         disp = pts - cg[:, c:c + 1, :]
         r2 = (disp ** 2).sum(-1)
-        f = np.stack([np.ones_like(r2), np.exp(-r2 / 9.0), 1.0 / (1.0 + r2)], axis=-1)  # (T, N, 3 feats)
-        d0 = np.zeros(disp.shape)
+        f = np.concatenate([types, np.exp(-r2 / 9.0)[..., None], (1.0 / (1.0 + r2))[..., None]], axis=-1)
         d1 = (np.exp(-r2 / 9.0) * (-2.0 / 9.0))[..., None] * disp
         d2 = (-2.0 / (1.0 + r2) ** 2)[..., None] * disp
+        d = np.concatenate([np.zeros((T, 7, 3)), d1.sum(1)[:, None, :], d2.sum(1)[:, None, :]], axis=1)
         feats.append(f.astype(np.float32))
-        divs.append(np.stack([d0.sum(1), d1.sum(1), d2.sum(1)], axis=1).astype(np.float32))  # (T, 3 feats, 3)
-    return {"feats": feats, "divs": divs, "names": ["one", "gauss", "lorentz"]}
+        divs.append(d.astype(np.float32))  # (T, n_feat, 3)
+    return {"feats": feats, "divs": divs, "names": [f"type{i}" for i in range(7)] + ["gauss", "lorentz"]}
 
 
 def _feat_system(T=90, N=21, seed=1, dtype=np.float32):
@@ -185,7 +189,7 @@ def test_generic_featuriser_fit_and_apply_match_oracle(dtype):
     ocoef = orc.qp_feat_linear_map(f64, cmat, [f.astype(np.float64) for f in res["feats"]],
                                    [d.astype(np.float64) for d in res["divs"]], KBT, frames, 10.0)
     coefs = np.stack(tm.force_map.tags["coef_list"])
-    assert tm.force_map.tags["feat_names"] == ["one", "gauss", "lorentz"]
+    assert tm.force_map.tags["feat_names"][-2:] == ["gauss", "lorentz"]
     # float32 inputs: the regression matrix is float32 as in the reference (featlinearmap.py:361-369 on
     # float32 arrays); BASELINE's float32 tolerance is 1e-3.  float64: the same arithmetic as the oracle.
     tol = 1e-3 if dtype == np.float32 else 1e-6

@@ -1,0 +1,68 @@
+"""GPU: the batched equality-QP solve (one launch per factorisation step over all cg sites of the
+featurised fit, featlinearmap.py:349-384) against separate solves and against the oracle."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from aggforce_amd import _kernels as K  # noqa: E402
+from oracle import aggforce_oracle as orc  # noqa: E402
+
+
+def _problems(p, n, m, nrhs, seed, redundant=False):
+    rng = np.random.default_rng(seed)
+    Gs, As, Bs = [], [], []
+    for _ in range(p):
+        R = rng.standard_normal((3 * n + 5, n)) * rng.uniform(1, 50)
+        Gs.append(R.T @ R)
+        A = rng.standard_normal((m, n))
+        if redundant:  # consistent but dependent rows, as the sampled constraint rows of the featurised fit
+            A[m // 2:] = A[: m - m // 2] * 1.0
+        As.append(A)
+        x0 = rng.standard_normal((n, nrhs))
+        Bs.append(A @ x0)
+    return np.stack(Gs), np.stack(As), np.stack(Bs)
+
+
+@pytest.mark.parametrize("p,n,m,nrhs", [(1, 40, 3, 3), (5, 70, 9, 1), (3, 300, 20, 2), (7, 64, 64, 1), (2, 513, 130, 4)])
+def test_batched_solve_equals_separate_solves_and_oracle(p, n, m, nrhs):
+    G, A, B = _problems(p, n, m, nrhs, seed=p * 1000 + n)
+    Gd, Ad, Bd = (torch.from_numpy(x).cuda() for x in (G, A, B))
+    X, st = K.eq_qp_solve_batched(Gd, 0.5, None, Ad, Bd, schur_reg=0.0, n_refine=1)
+    assert X.shape == (p, nrhs, n) and st.shape == (p, 4)
+    for j in range(p):
+        Xj, sj = K.eq_qp_solve(Gd[j].contiguous(), 0.5, None, Ad[j].contiguous(), Bd[j].contiguous(), schur_reg=0.0,
+                               n_refine=1)
+        assert torch.equal(X[j], Xj) and torch.equal(st[j], sj)  # bit-identical: same kernels, same order
+        ref = orc.eq_qp_solve(G[j] + 0.5 * np.eye(n), None, A[j], B[j])
+        got = X[j].cpu().numpy().T
+        assert np.max(np.abs(got - ref)) < 1e-8 * max(1.0, np.max(np.abs(ref)))
+        assert float(st[j, 0]) == 0.0 and float(st[j, 1]) < 1e-9
+
+
+def test_batched_solve_redundant_rows_and_identity_rhs():
+    """Redundant sampled rows (schur_reg > 0, three refinement steps) and B = None (identity right-hand sides)."""
+    p, n, m = 4, 90, 12
+    G, A, B = _problems(p, n, m, 1, seed=11, redundant=True)
+    Gd, Ad, Bd = (torch.from_numpy(x).cuda() for x in (G, A, B))
+    X, st = K.eq_qp_solve_batched(Gd, 10.0, None, Ad, Bd, schur_reg=1e-12, n_refine=3)
+    for j in range(p):
+        Xj, sj = K.eq_qp_solve(Gd[j].contiguous(), 10.0, None, Ad[j].contiguous(), Bd[j].contiguous(), schur_reg=1e-12,
+                               n_refine=3)
+        assert torch.equal(X[j], Xj) and torch.equal(st[j], sj)
+        assert float(st[j, 0]) == 0.0 and float(st[j, 1]) < 1e-8
+        ref = orc.eq_qp_solve(G[j] + 10.0 * np.eye(n), None, A[j], B[j][:, 0])
+        assert np.max(np.abs(X[j, 0].cpu().numpy() - ref)) < 1e-6 * max(1.0, np.max(np.abs(ref)))
+    G2, A2, _ = _problems(3, 50, 6, 6, seed=12)
+    X2, st2 = K.eq_qp_solve_batched(torch.from_numpy(G2).cuda(), 0.0, None, torch.from_numpy(A2).cuda(), None)
+    for j in range(3):
+        assert np.max(np.abs(A2[j] @ X2[j].cpu().numpy().T - np.eye(6))) < 1e-9
+    # a non-positive pivot in ONE problem is reported for that problem only
+    G3 = G2.copy()
+    G3[1] = -G3[1]
+    _, st3 = K.eq_qp_solve_batched(torch.from_numpy(G3).cuda(), 0.0, None, torch.from_numpy(A2).cuda(), None)
+    st3 = st3.cpu().numpy()
+    assert st3[0, 0] == 0 and st3[2, 0] == 0 and st3[1, 0] != 0
+    with pytest.raises(ValueError):
+        K.eq_qp_solve_batched(torch.from_numpy(G2).cuda(), 0.0, None, torch.from_numpy(A2[:2]).cuda(), None)
