@@ -589,15 +589,47 @@ def feat_constraint_rows(feat: torch.Tensor, frame_idx: np.ndarray, M: torch.Ten
 
 
 def gb_constraint_rows(Mg: torch.Tensor, gauss: Optional[torch.Tensor], S: int, n_id: int, n_ch: int, n_basis: int,
-                       site: int, out_A: Optional[torch.Tensor] = None, out_b: Optional[torch.Tensor] = None):
-    """Constraint rows of the fused [id | gb] features; see aggf_gb_constraint_rows."""
+                       site: int, out_A: Optional[torch.Tensor] = None, out_b: Optional[torch.Tensor] = None,
+                       cols: Optional[torch.Tensor] = None):
+    """Constraint rows of the fused [id | gb] features; see aggf_gb_constraint_rows.  ``cols`` (int32 device
+    array of kept Gaussian columns ch*n_basis + k) gives the compacted layout; ``out_A`` may be wider than
+    the feature count (trailing columns are zeroed)."""
     n_cg, G = Mg.shape
-    n_feat = n_id + n_ch * n_basis
+    n_cols = n_ch * n_basis if cols is None else int(cols.numel())
+    n_feat = n_id + n_cols
     A = out_A if out_A is not None else torch.empty((S * n_cg, n_feat), dtype=torch.float64, device=Mg.device)
     b = out_b if out_b is not None else torch.empty((S * n_cg, 1), dtype=torch.float64, device=Mg.device)
-    check(lib().aggf_gb_constraint_rows(ptr(Mg), ptr(gauss), S, n_cg, G, n_id, n_ch, n_basis, int(site), ptr(A), ptr(b),
-                                        stream_ptr()), "aggf_gb_constraint_rows")
+    ld = A.shape[-1]
+    check(lib().aggf_gb_constraint_rows(ptr(Mg), ptr(gauss), S, n_cg, G, n_id, n_ch, n_basis, ptr(cols), n_cols, ld,
+                                        int(site), ptr(A), ptr(b), stream_ptr()), "aggf_gb_constraint_rows")
     return A, b
+
+
+def gb_distance_range(Pg: torch.Tensor, cg: torch.Tensor, n_ch: int):
+    """(rmin, rmax) (n_cg, G) float32: range over frames of every channel's distance to every cg site."""
+    T, G, _ = Pg.shape
+    n_cg = cg.shape[1]
+    rmin = torch.full((n_cg, G), float("inf"), dtype=torch.float32, device=Pg.device)
+    rmax = torch.zeros((n_cg, G), dtype=torch.float32, device=Pg.device)
+    if T and n_ch:
+        check(lib().aggf_gb_distance_range(ptr(Pg), ptr(cg), T, G, n_cg, n_ch, ptr(rmin), ptr(rmax), stream_ptr()),
+              "aggf_gb_distance_range")
+    return rmin, rmax
+
+
+def gb_regmat_cols(Fg, Pg, cg, site: int, sizes, n_id: int, cols: torch.Tensor, centers, width: float, clip: float,
+                   kbt: float, out: torch.Tensor) -> torch.Tensor:
+    """Compact regression matrix of one cg site (listed Gaussian columns only); see aggf_gb_regmat_cols."""
+    T, G, _ = Fg.shape
+    with _timed("gb_regmat"):
+        check(
+            lib().aggf_gb_regmat_cols(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, cg.shape[1], site,
+                                      ptr(sizes), n_id, ptr(cols), int(cols.numel()), ptr(centers), centers.numel(),
+                                      float(width), float(clip), float(kbt), out.shape[1], ptr(out),
+                                      dtype_code(out.dtype), stream_ptr()),
+            "aggf_gb_regmat_cols",
+        )
+    return out
 
 
 def feat_weights(feat: torch.Tensor, coef: torch.Tensor, out: torch.Tensor, site: int) -> None:

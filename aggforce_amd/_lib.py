@@ -50,13 +50,19 @@ PROTOTYPES = {
     "aggf_trjdot_frames": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp]),
     "aggf_feat_contract": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dbl, _i64, _i32, _i32, _i32, _vp, C.c_int, _vp]),
     "aggf_feat_constraint_rows": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "aggf_gb_constraint_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_gb_constraint_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_gb_distance_range": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_gb_regmat_cols": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
     "aggf_feat_weights": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "aggf_pair_dist_var_workspace_bytes": (_sz, [_i64, _i32]),
     "aggf_pair_dist_var": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _sz, _vp]),
     "aggf_gram_quadform_workspace_bytes": (_sz, [_i32, _i32]),
     "aggf_gram_quadform": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "aggf_daxpby": (C.c_int, [_i64, _dbl, _vp, _dbl, _vp, _vp, _vp]),
+    "aggf_comm_unique_id": (C.c_int, [_vp, _sz]),
+    "aggf_comm_init": (C.c_int, [_vp, _sz, _i32, _i32, C.POINTER(_vp)]),
+    "aggf_comm_destroy": (C.c_int, [_vp]),
+    "aggf_allreduce_sum": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "aggf_synth_normal": (C.c_int, [_vp, _i64, _i32, C.c_int, _u64, _i64, _dbl, _dbl, _dbl, _vp]),
 }
 

@@ -172,23 +172,27 @@ __global__ __launch_bounds__(256) void feat_rows_kernel(const TX* __restrict__ f
     b[(int64_t)s * n_cg + c0 + threadIdx.x] = (c0 + (int)threadIdx.x == site) ? 1.0 : 0.0;
 }
 
-// A[(s,c), g] = Mg[c,g] (g < n_id);  A[(s,c), n_id + ch*nb + k] = Mg[c,ch] gauss[s,ch,k];  b one-hot on `site`
+// A[(s,c), g] = Mg[c,g] (g < n_id);  A[(s,c), n_id + j] = Mg[c,ch] gauss[s,ch,k] with (ch,k) the j-th
+// Gaussian column (all n_ch*nb of them if cols == NULL, else cols[j] = ch*nb + k);  b one-hot on `site`.
+// A has row stride ld >= n_id + n_cols; columns beyond are written as zeros.
 __global__ __launch_bounds__(256) void gb_rows_kernel(const double* __restrict__ Mg, const float* __restrict__ gauss,
                                                       int32_t S, int32_t n_cg, int32_t G, int32_t n_id, int32_t n_ch,
-                                                      int32_t nb, int32_t site, double* __restrict__ A,
+                                                      int32_t nb, const int32_t* __restrict__ cols, int32_t n_cols,
+                                                      int32_t ld, int32_t site, double* __restrict__ A,
                                                       double* __restrict__ b) {
-  const int n_feat = n_id + n_ch * nb;
-  const int64_t total = (int64_t)S * n_cg * n_feat;
+  const int n_feat = n_id + n_cols;
+  const int64_t total = (int64_t)S * n_cg * ld;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    const int f = (int)(e % n_feat);
-    const int64_t sc = e / n_feat;
+    const int f = (int)(e % ld);
+    const int64_t sc = e / ld;
     const int c = (int)(sc % n_cg);
     const int64_t s = sc / n_cg;
-    double v;
+    double v = 0.0;
     if (f < n_id) {
       v = Mg[(int64_t)c * G + f];
-    } else {
-      const int ch = (f - n_id) / nb, k = (f - n_id) - ch * nb;
+    } else if (f < n_feat) {
+      const int full = cols ? cols[f - n_id] : f - n_id;
+      const int ch = full / nb, k = full - ch * nb;
       v = Mg[(int64_t)c * G + ch] * (double)gauss[(s * n_ch + ch) * nb + k];
     }
     A[e] = v;
@@ -292,16 +296,18 @@ extern "C" int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t 
 }
 
 extern "C" int aggf_gb_constraint_rows(const double* Mg, const float* gauss, int32_t S, int32_t n_cg, int32_t G,
-                                       int32_t n_id, int32_t n_ch, int32_t n_basis, int32_t site, double* A,
-                                       double* b, void* stream_v) {
+                                       int32_t n_id, int32_t n_ch, int32_t n_basis, const int32_t* cols,
+                                       int32_t n_cols, int32_t ld, int32_t site, double* A, double* b,
+                                       void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
-  if (!Mg || !A || !b || (n_ch > 0 && !gauss)) return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: NULL pointer");
-  if (S <= 0 || n_cg <= 0 || G <= 0 || n_id < 0 || n_id > G || n_ch < 0 || n_ch > G || n_basis <= 0 ||
-      n_id + n_ch * n_basis <= 0 || site < 0 || site >= n_cg)
+  if (!cols) n_cols = n_ch * n_basis;
+  if (!Mg || !A || !b || (n_cols > 0 && !gauss)) return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: NULL pointer");
+  if (S <= 0 || n_cg <= 0 || G <= 0 || n_id < 0 || n_id > G || n_ch < 0 || n_ch > G || n_basis <= 0 || n_cols < 0 ||
+      n_cols > n_ch * n_basis || n_id + n_cols <= 0 || ld < n_id + n_cols || site < 0 || site >= n_cg)
     return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: bad shape");
-  const int64_t total = (int64_t)S * n_cg * (n_id + n_ch * n_basis);
+  const int64_t total = (int64_t)S * n_cg * ld;
   hipLaunchKernelGGL(gb_rows_kernel, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg, gauss, S, n_cg, G,
-                     n_id, n_ch, n_basis, site, A, b);
+                     n_id, n_ch, n_basis, cols, n_cols, ld, site, A, b);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

@@ -135,6 +135,80 @@ __global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ F
   }
 }
 
+// ---------------------------------------------------------------------------
+// Column compaction of the fused fit.  A clipped Gaussian column (ch, k) is identically zero over the
+// whole trajectory when the channel never comes within w sqrt(ln(1/clip)) of centre c_k (the point of a
+// cut-off basis); such a column contributes a zero row/column to P and zeros to every constraint row, so
+// its coefficient in the minimiser is exactly 0 (l2 > 0) and it can be left out of the Gram matrix and of
+// the solve.  gb_range_kernel finds, per (site, channel), the range of distances over the frames.
+
+__device__ __forceinline__ void atomic_min_pos_float(float* addr, float v) {
+  atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));  // order-preserving for v >= 0
+}
+__device__ __forceinline__ void atomic_max_pos_float(float* addr, float v) {
+  atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+}
+
+// rmin/rmax (n_cg, G) must be initialised to +inf / 0.  grid = (channel blocks, sites, frame slices).
+// A NaN distance (non-finite coordinates) marks the channel as spanning everything.
+__global__ __launch_bounds__(256) void gb_range_kernel(const float* __restrict__ Pg, const float* __restrict__ cg,
+                                                       int64_t T, int32_t G, int32_t n_cg, int32_t n_ch,
+                                                       float* __restrict__ rmin, float* __restrict__ rmax) {
+  const int ch = blockIdx.x * blockDim.x + threadIdx.x;
+  const int site = blockIdx.y;
+  if (ch >= n_ch) return;
+  float lo = INFINITY, hi = 0.0f;
+  for (int64_t t = blockIdx.z; t < T; t += gridDim.z) {
+    const float* p = Pg + (t * G + ch) * 3;
+    const float* c = cg + (t * n_cg + site) * 3;
+    const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+    const float r = sqrtf(dx * dx + dy * dy + dz * dz);
+    if (!(r == r)) { lo = 0.0f; hi = INFINITY; }
+    lo = fminf(lo, r);
+    hi = fmaxf(hi, r);
+  }
+  atomic_min_pos_float(rmin + (int64_t)site * G + ch, lo);
+  atomic_max_pos_float(rmax + (int64_t)site * G + ch, hi);
+}
+
+// Compact regression matrix: column j < n_id = group force sums; column n_id + j = the Gaussian column
+// cols[j] = ch * n_basis + k (only the listed ones).  One thread per (frame, compact column): consecutive
+// threads write consecutive 3-vectors (coalesced), the distance of a channel is recomputed per listed k.
+template <typename TF, typename TO>
+__global__ __launch_bounds__(256) void gb_regmat_cols_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
+                                                             const float* __restrict__ cg, int64_t T, int32_t G,
+                                                             int32_t n_cg, int32_t site,
+                                                             const float* __restrict__ sizes, int32_t n_id,
+                                                             const int32_t* __restrict__ cols, int32_t n_cols,
+                                                             GbParams gp, TF kbt, int32_t ld_feat,
+                                                             TO* __restrict__ R3) {
+  const int per_frame = n_id + n_cols;
+  const int64_t total = T * per_frame;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = i / per_frame;
+    const int j = (int)(i - t * per_frame);
+    TO* o = R3 + (t * (int64_t)ld_feat + j) * 3;
+    if (j < n_id) {
+      const TF* f = Fg + (t * G + j) * 3;
+      o[0] = (TO)f[0];
+      o[1] = (TO)f[1];
+      o[2] = (TO)f[2];
+      continue;
+    }
+    const int full = cols[j - n_id];
+    const int ch = full / gp.n_basis, k = full - ch * gp.n_basis;
+    float r, u[3], g, dg;
+    gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
+    gb_gauss(gp, r, k, g, dg);
+    const TF* f = Fg + (t * G + ch) * 3;
+    const float s = sizes[ch] * dg;
+    o[0] = (TO)((TF)g * f[0] + kbt * (TF)(s * u[0]));
+    o[1] = (TO)((TF)g * f[1] + kbt * (TF)(s * u[1]));
+    o[2] = (TO)((TF)g * f[2] + kbt * (TF)(s * u[2]));
+  }
+}
+
 // CLAMap application of the [id | gb] feature-linear map (featlinearmap.py:512-520,
 // map/core.py:428-430): out[t,c,:] = sum_f coef[c,f] * (feat_c[t]' F[t] + div_c[t])[f,:]
 // -- the divergence enters WITHOUT kbt, exactly as in the reference's trans_f.
@@ -288,6 +362,47 @@ extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const
     hipLaunchKernelGGL(gb_apply_kernel<double>, grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat, out);
   else
     return fail(AGGF_ERR_ARG, "aggf_gb_apply: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_distance_range(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
+                                      int32_t n_ch, float* rmin, float* rmax, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Pg || !cg || !rmin || !rmax) return fail(AGGF_ERR_ARG, "aggf_gb_distance_range: NULL pointer");
+  if (T <= 0 || G <= 0 || n_cg <= 0 || n_cg > 65535 || n_ch <= 0 || n_ch > G)
+    return fail(AGGF_ERR_ARG, "aggf_gb_distance_range: bad shape");
+  int64_t slices = ceil_div(T, 256);
+  if (slices > 256) slices = 256;
+  const dim3 grid((unsigned)ceil_div(n_ch, 256), (unsigned)n_cg, (unsigned)slices);
+  hipLaunchKernelGGL(gb_range_kernel, grid, dim3(256), 0, stream, Pg, cg, T, G, n_cg, n_ch, rmin, rmax);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+                                   int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
+                                   const int32_t* cols, int32_t n_cols, const float* centers, int32_t n_basis,
+                                   double width, double clip, double kbt, int32_t ld_feat, void* R3,
+                                   int out_dtype, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Fg || !Pg || !cg || !sizes || !R3 || (n_cols > 0 && !cols))
+    return fail(AGGF_ERR_ARG, "aggf_gb_regmat_cols: NULL pointer");
+  if (T <= 0 || G <= 0 || n_cols < 0 || n_id < 0 || n_id > G || n_id + n_cols <= 0 || site < 0 || site >= n_cg ||
+      ld_feat < n_id + n_cols)
+    return fail(AGGF_ERR_ARG, "aggf_gb_regmat_cols: bad shape");
+  int rc = check_gb(centers, n_basis, width);
+  if (rc) return rc;
+  GbParams gp{centers, n_basis, (float)width, (float)clip};
+  const dim3 grid = feat_grid(T * (n_id + n_cols));
+  if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((gb_regmat_cols_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, (float)kbt, ld_feat, (float*)R3);
+  else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((gb_regmat_cols_kernel<float, double>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, (float)kbt, ld_feat, (double*)R3);
+  else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((gb_regmat_cols_kernel<double, double>), grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, (double)kbt, ld_feat, (double*)R3);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_gb_regmat_cols: bad dtype (out must be the force dtype or float64)");
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

@@ -226,21 +226,36 @@ __global__ __launch_bounds__(GRAM_THREADS, 2) void gram_tile_kernel(
 // (global_load_lds_dwordx4: no VGPR round trip, no ds_write -- the register-staged refill
 // costs 6-12 % of the MFMA time, tools/gram_ablate.hip) through a 3-stage LDS ring with a
 // counted vmcnt, so the DMAs of stage s+2 stay in flight across the barrier of stage s.
-// One DMA piece = one wave-instruction = 64 lanes x 16 B = 1 KiB contiguous in LDS; a panel
-// row (384 elements) is 3 pieces (f64) or 1.5 pieces (f32: the second one uses lanes 0-31),
-// so no piece crosses an LDS row and the padded row stride of the read pattern is kept.
+// One DMA piece = one wave-instruction = 64 lanes x 16 B = 1 KiB contiguous in LDS (every lane brings
+// its own global address).  f64: a panel row (384 elements = 3 KiB) is 3 pieces.  f32: a row is 1.5 KiB,
+// so rows are staged in PAIRS (r, r+4) that lie back to back in LDS -- 3 KiB = exactly 3 full pieces, the
+// middle one gathering the tail of row r (lanes 0-31) and the head of row r+4 (lanes 32-63).  (The first
+// f32 version used one full and one half-used piece per row: 32 instead of 24 DMA instructions per stage,
+// and the waves stall in the DMA *issue*.)  An MFMA operand read touches rows kk*4 + 0..3, i.e. the four
+// pairs at the same member, so the padded stride that keeps the stride-3 reads conflict-free is the one
+// between PAIRS (784 floats = 16 banks mod 64, like the 400-element row stride of the f64 layout).
 template <typename T>
 struct DmaCfg;
 template <>
 struct DmaCfg<double> {
-  static constexpr int ROW_PIECES = 3;       // pieces per panel row
-  static constexpr int PIECE_ELEMS = 128;    // elements per full piece
+  static constexpr int ROW_PIECES = 3;       // (row-wise staging of the opt-in pair-tile kernel: pieces per row)
+  static constexpr int UNITS = 4;            // LDS units per panel and stage: the KB = 4 rows
+  static constexpr int UNIT_STRIDE = ROW_STRIDE;
+  static constexpr int PIECE_ELEMS = 128;    // elements per piece
+  static constexpr int KK_STRIDE = 4 * ROW_STRIDE;  // LDS distance between the row groups kk and kk+1
+  __host__ __device__ static constexpr int row_off(int r) { return r * ROW_STRIDE; }
 };
 template <>
 struct DmaCfg<float> {
-  static constexpr int ROW_PIECES = 2;
+  static constexpr int ROW_PIECES = 2;       // (pair-tile kernel: one full and one half-used piece per row)
+  static constexpr int UNITS = 4;            // the 4 row pairs (r, r+4) of the KB = 8 rows
+  static constexpr int UNIT_STRIDE = 2 * ROW_ELEMS + ROW_PAD;  // 784
   static constexpr int PIECE_ELEMS = 256;
+  static constexpr int KK_STRIDE = ROW_ELEMS;       // member 1 of every pair follows member 0 directly
+  __host__ __device__ static constexpr int row_off(int r) { return (r & 3) * UNIT_STRIDE + (r >> 2) * ROW_ELEMS; }
 };
+template <typename T>
+constexpr int dma_panel_elems() { return DmaCfg<T>::UNITS * DmaCfg<T>::UNIT_STRIDE; }  // 1600 (f64) / 3136 (f32)
 
 template <int N>
 __device__ __forceinline__ void wait_vmcnt() {
@@ -271,11 +286,12 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   constexpr int KB = GramCfg<T>::KB;
-  constexpr int RP = DmaCfg<T>::ROW_PIECES;
+  constexpr bool F32 = sizeof(T) == 4;
   constexpr int PE = DmaCfg<T>::PIECE_ELEMS;
+  constexpr int UNITS = DmaCfg<T>::UNITS;
   constexpr int PANELS = 2;  // diagonal tiles stage their panel twice (one code path, fixed vmcnt)
-  constexpr int PIECES = PANELS * KB * RP;           // per stage: 24/12 (f64), 32/16 (f32)
-  constexpr int PPW = PIECES / NW;                   // per wave: 6 (f64) / 8 (f32) with 4 waves, 3 / 4 with 8
+  constexpr int PIECES = PANELS * UNITS * 3;         // per stage: 24 for both dtypes
+  constexpr int PPW = PIECES / NW;                   // per wave: 6 with 4 waves, 3 with 8
   static_assert(PIECES % NW == 0, "piece split");
   // NW waves tile the 128x128 output as 2 x (NW/2): wave tile 64 x 64 (NW = 4) or 64 x 32 (NW = 8,
   // four waves per SIMD with two workgroups per CU: half the accumulators and half the DMA
@@ -284,7 +300,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   constexpr int WCOLS = TILE / WN;                   // columns per wave: 64 / 32
   constexpr int NACC = WCOLS / 16;                   // 16-column accumulator tiles per wave: 4 / 2
   constexpr int NTHREADS = 64 * NW;
-  constexpr int PANEL_ELEMS = KB * ROW_STRIDE;
+  constexpr int PANEL_ELEMS = dma_panel_elems<T>();
   constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
   constexpr int AHEAD = NBUF - 1;  // stages in flight ahead of the one being computed
 
@@ -314,21 +330,31 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   if (t_end > n_rows) t_end = n_rows;
   const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KB - 1) / KB) : 0;
 
-  // this wave's DMA pieces: global element offset within a stage and LDS element offset
+  // this wave's DMA pieces: global element offset within a stage (per lane), the frame row the lane
+  // reads (for the ragged last stage) and the LDS element offset of the piece
   int64_t g_off[PPW];
   int l_off[PPW], p_row[PPW];
-  bool p_half[PPW];
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int p = wave + NW * q;
-    const int panel = p / (KB * RP);
-    const int r = (p - panel * KB * RP) / RP;
-    const int cp = p % RP;
+    const int panel = p / (UNITS * 3);
+    const int unit = (p - panel * UNITS * 3) / 3;
+    const int cp = p % 3;
+    int r, elem;
+    if (F32) {
+      // pair (unit, unit + 4): piece 0 = row unit [0, 256); piece 1 = row unit [256, 384) | row unit+4 [0, 128);
+      // piece 2 = row unit+4 [128, 384)
+      const bool second = cp == 2 || (cp == 1 && lane >= 32);
+      r = unit + (second ? 4 : 0);
+      elem = cp == 0 ? lane * 4 : cp == 2 ? 128 + lane * 4 : (lane < 32 ? 256 + lane * 4 : (lane - 32) * 4);
+    } else {
+      r = unit;
+      elem = cp * PE + lane * 2;
+    }
     p_row[q] = r;
-    p_half[q] = (sizeof(T) == 4) && (cp == 1);
-    const int64_t col = (int64_t)(panel ? tj : ti) * ROW_ELEMS + cp * PE;
-    g_off[q] = (int64_t)r * ld + col + lane * (16 / (int)sizeof(T));
-    l_off[q] = panel * PANEL_ELEMS + r * ROW_STRIDE + cp * PE;
+    const int64_t col = (int64_t)(panel ? tj : ti) * ROW_ELEMS;
+    g_off[q] = (int64_t)r * ld + col + elem;
+    l_off[q] = panel * PANEL_ELEMS + unit * DmaCfg<T>::UNIT_STRIDE + cp * PE;
   }
 
   // rows past the end of this split's frame range must read as zeros (last stage only)
@@ -351,7 +377,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
         const int panel = e / ((KB - first) * ROW_ELEMS);
         const int rem = e - panel * (KB - first) * ROW_ELEMS;
         const int r = first + rem / ROW_ELEMS, c = rem % ROW_ELEMS;
-        lbase[panel * PANEL_ELEMS + r * ROW_STRIDE + c] = 0;
+        lbase[panel * PANEL_ELEMS + DmaCfg<T>::row_off(r) + c] = 0;
       }
     }
   };
@@ -360,8 +386,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     // ABL 4: cycle over 8 stages -> DMAs miss the L1 but hit the L2
     const int64_t t0 = t_begin + (ABL == 3 ? 0 : ABL == 4 ? (int64_t)(stage_of(s) & 7) * KB : (int64_t)stage_of(s) * KB);
     const bool row_ok = t0 + p_row[q] < t_end;
-    const bool lane_ok = !p_half[q] || lane < 32;
-    if (row_ok && lane_ok) {
+    if (row_ok) {
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)(X + t0 * ld + g_off[q]),
           (__attribute__((address_space(3))) void*)(smem + (s % NBUF) * BUF_ELEMS + l_off[q]), 16, 0, 0);
@@ -379,8 +404,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[m][n] = acc_zero<T>();
 
-  const int offA = (lane >> 4) * ROW_STRIDE + 3 * (wm * 64 + (lane & 15));
-  const int offB = PANEL_ELEMS + (lane >> 4) * ROW_STRIDE + 3 * (wn * WCOLS + (lane & 15));
+  // MFMA operand of row group kk: rows kk*4 + (lane >> 4) -- f64: four consecutive rows; f32: member kk of
+  // the four pairs
+  const int offA = (lane >> 4) * DmaCfg<T>::UNIT_STRIDE + 3 * (wm * 64 + (lane & 15));
+  const int offB = PANEL_ELEMS + (lane >> 4) * DmaCfg<T>::UNIT_STRIDE + 3 * (wn * WCOLS + (lane & 15));
+  constexpr int KKS = DmaCfg<T>::KK_STRIDE;
 
   if (n_it > 0) issue_stage(0);
   if (AHEAD > 1 && n_it > 1) issue_stage(1);
@@ -413,9 +441,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
       for (int d = 0; d < 3; ++d) {
         T a[4], bb[NACC];
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * 4 * ROW_STRIDE + 48 * m + d];
+        for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * KKS + 48 * m + d];
 #pragma unroll
-        for (int n = 0; n < NACC; ++n) bb[n] = pa[offB + kk * 4 * ROW_STRIDE + 48 * n + d];
+        for (int n = 0; n < NACC; ++n) bb[n] = pa[offB + kk * KKS + 48 * n + d];
         // between the operand reads and the MFMAs of the group: the reads are in flight while the DMA
         // waits to be accepted (before the reads: +3.5 %, after the MFMAs: +1 %, tools/clock_probe.hip)
         if (SPREAD && issue_now) {
@@ -788,7 +816,174 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3 };
+// Small systems: n_red <= 128 (one output tile), e.g. CLN025 (175 atoms, 97 reduced variables).
+// There the Gram build is HBM-bound (n_red (n_red+1) / (N s) = 6.8 flop/B at CLN025 against a machine
+// balance of ~10), so the kernel is organised around ONE pass over the forces, read the way they lie
+// in HBM: the 8 frames of a stage are one contiguous run of 8 x 3N elements, fetched with 16-byte
+// loads into registers while the MFMAs of the previous stage run (2 workgroups per CU x 8 frames:
+// ~64 KB per CU in flight), parked in LDS as they are, and only there turned into the panel the
+// MFMAs read -- constraint-group column sums (`@ con_mat`), dtype conversion and zero padding, all
+// LDS -> LDS.  No packed copy of the trajectory exists (the pack + tile pipeline above reads F,
+// writes a padded copy and reads that again: 3.4x the bytes at CLN025), and only the 16x16 blocks
+// of the upper triangle are multiplied (8 waves, <= 5 blocks each, dealt round-robin).
+// Two shapes: 8 frames per stage x 8 waves (default: 60 KB of LDS at CLN025, two workgroups per CU, 67 KB in
+// flight per CU) and 4 frames x 4 waves (AGGF_GRAM_SMALL=4: three smaller workgroups per CU; measured slower,
+// 10.2 against 7.5 ms at CLN025 x 4e6 frames before the group sums lost their loops).
+constexpr int SM_KB = 8;            // frame granularity of the split ranges (both shapes divide it)
+constexpr int SM_MAXVEC = 8;        // 16-byte loads per thread and stage (template NV = 3, 5 or 8)
+constexpr int SM_FAST_MEMBERS = 4;  // group members summed without a loop (larger groups: generic tail loop)
+
+template <typename TIn>
+static size_t small_raw_bytes(int32_t N, int kbs) { return (size_t)round_up((int64_t)kbs * 3 * N * sizeof(TIn), 16) + 16; }
+
+template <typename TIn, typename TC, int NV, int KBS, int NWV>
+__global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
+    const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
+    const int32_t* __restrict__ grp_atoms, int32_t n_red, int64_t frames_per_split, int32_t raw_bytes,
+    TC* __restrict__ slabs) {
+  using M = Mfma<TC>;
+  using acc_t = typename M::acc_t;
+  constexpr int SM_THREADS = 64 * NWV;
+  constexpr int SM_ENT = KBS * ROW_ELEMS / SM_THREADS;      // panel entries per thread and stage: 6
+  constexpr int SM_MAXBLK = (36 + NWV - 1) / NWV;           // upper-triangle blocks per wave: 9 / 5
+  static_assert(KBS * ROW_ELEMS % SM_THREADS == 0, "entry split");
+  typedef float __attribute__((ext_vector_type(4))) v16_t;  // one 16-byte piece, whatever the dtype
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  TC* panel = reinterpret_cast<TC*>(smem_raw);                         // [SM_KB][ROW_STRIDE]
+  TIn* raw = reinterpret_cast<TIn*>(smem_raw + KBS * ROW_STRIDE * sizeof(TC));  // SM_KB frames as in HBM
+  // (raw_bytes includes one extra zeroed 16-byte piece: the "no member" slot of the table below)
+  int32_t* atoms_s = reinterpret_cast<int32_t*>(smem_raw + KBS * ROW_STRIDE * sizeof(TC) + raw_bytes);  // [N]
+  int32_t* ptr_s = atoms_s + N;                                                                           // [129]
+  // per panel column c = 3 g + d: offsets (3 atom + d) of the first 4 members of group g inside a frame,
+  // 0xFFFF = none -- one 8-byte LDS read instead of a chain of dependent ones per member
+  unsigned short* memb_s = reinterpret_cast<unsigned short*>(smem_raw + KBS * ROW_STRIDE * sizeof(TC) + raw_bytes +
+                                                             (((int64_t)N + TILE + 1) * 4 + 15) / 16 * 16);  // [384][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t t_begin = (int64_t)blockIdx.x * frames_per_split;
+  int64_t t_end = t_begin + frames_per_split;
+  if (t_end > T) t_end = T;
+  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KBS - 1) / KBS) : 0;
+  const int64_t row_in = (int64_t)N * 3;
+  // column -> member atoms (CSR) in LDS; without constraint groups column g is atom g
+  for (int a = tid; a < N; a += SM_THREADS) atoms_s[a] = grp_atoms ? grp_atoms[a] : a;
+  for (int g = tid; g <= TILE; g += SM_THREADS) ptr_s[g] = g <= n_red ? (grp_ptr ? grp_ptr[g] : g) : (grp_ptr ? grp_ptr[n_red] : n_red);
+  const int zero_idx = (raw_bytes - 16) / (int)sizeof(TIn);
+  if (tid < 16 / (int)sizeof(TIn)) raw[zero_idx + tid] = (TIn)0;
+  __syncthreads();
+  bool big_groups = false;  // uniform: some group has more than SM_FAST_MEMBERS members
+  for (int g = 0; g < n_red; ++g) big_groups |= ptr_s[g + 1] - ptr_s[g] > SM_FAST_MEMBERS;
+  for (int c = tid; c < ROW_ELEMS; c += SM_THREADS) {
+    const int g = c / 3, d = c - 3 * g;
+#pragma unroll
+    for (int j = 0; j < SM_FAST_MEMBERS; ++j)
+      memb_s[c * 4 + j] = (ptr_s[g] + j < ptr_s[g + 1]) ? (unsigned short)(3 * atoms_s[ptr_s[g] + j] + d) : (unsigned short)0xFFFF;
+  }
+
+  // stage s+1 travels HBM -> registers (16-byte pieces of the contiguous run of frames) during the
+  // MFMAs of stage s.  fps is a multiple of 8 frames, so every stage starts 16-byte aligned.
+  const int n_vec = raw_bytes / 16 - 1;  // (the last piece is the zero slot)
+  v16_t hold[NV];
+  auto fetch = [&](int s) {
+    const int64_t t0 = t_begin + (int64_t)s * KBS;
+    const int64_t valid = (t_end - t0 < KBS ? t_end - t0 : KBS) * row_in * (int64_t)sizeof(TIn);  // bytes
+    const char* src = reinterpret_cast<const char*>(F + t0 * row_in);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + SM_THREADS * i;
+      v16_t x = {0.f, 0.f, 0.f, 0.f};
+      if (v < n_vec) {
+        const int64_t off = (int64_t)v * 16;
+        if (off + 16 <= valid) {
+          x = *reinterpret_cast<const v16_t*>(src + off);
+        } else if (off < valid) {  // the ragged end of the trajectory: element by element
+          TIn tmp[16 / sizeof(TIn)];
+#pragma unroll
+          for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
+            tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
+          x = *reinterpret_cast<v16_t*>(tmp);
+        }
+      }
+      hold[i] = x;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int v = tid + SM_THREADS * i;
+      if (v < n_vec) reinterpret_cast<v16_t*>(raw)[v] = hold[i];
+    }
+  };
+  // raw frames -> MFMA panel: group sums in the compute dtype (frames past t_end were fetched as zeros)
+  auto reduce_groups = [&]() {
+#pragma unroll
+    for (int i = 0; i < SM_ENT; ++i) {
+      const int e = tid + SM_THREADS * i;  // (frame in stage, reduced column, xyz); padding columns sum nothing
+      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
+      const int base = r * (int)row_in;
+      const uint2 m = *reinterpret_cast<const uint2*>(memb_s + c * 4);
+      const int o0 = m.x & 0xFFFF, o1 = m.x >> 16, o2 = m.y & 0xFFFF, o3 = m.y >> 16;
+      const TC v0 = (TC)raw[o0 == 0xFFFF ? zero_idx : base + o0], v1 = (TC)raw[o1 == 0xFFFF ? zero_idx : base + o1],
+               v2 = (TC)raw[o2 == 0xFFFF ? zero_idx : base + o2], v3 = (TC)raw[o3 == 0xFFFF ? zero_idx : base + o3];
+      TC acc = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
+      if (big_groups) {
+        const int g = c / 3, d = c - 3 * g;
+        for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) acc += (TC)raw[base + 3 * atoms_s[j] + d];
+      }
+      panel[r * ROW_STRIDE + c] = acc;
+    }
+  };
+
+  // this wave's 16x16 blocks of the upper triangle: q = wave, wave + NWV, ... in row-major order
+  const int nb = (n_red + 15) / 16;
+  int b_i[SM_MAXBLK], b_j[SM_MAXBLK];
+#pragma unroll
+  for (int k = 0; k < SM_MAXBLK; ++k) {
+    int q = wave + NWV * k, bi = 0, rowlen = nb;
+    while (bi < nb && q >= rowlen) {
+      q -= rowlen;
+      --rowlen;
+      ++bi;
+    }
+    b_i[k] = bi < nb ? bi : -1;
+    b_j[k] = bi + q;
+  }
+  acc_t acc[SM_MAXBLK];
+#pragma unroll
+  for (int k = 0; k < SM_MAXBLK; ++k) acc[k] = acc_zero<TC>();
+  const int off = (lane >> 4) * ROW_STRIDE + 3 * (lane & 15);
+
+  if (n_it > 0) fetch(0);
+  for (int s = 0; s < n_it; ++s) {
+    __syncthreads();       // the MFMAs of stage s-1 are done with the panel, its group sums with `raw`
+    park();
+    __syncthreads();
+    if (s + 1 < n_it) fetch(s + 1);
+    reduce_groups();
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KBS / 4; ++kk)
+#pragma unroll
+      for (int d = 0; d < 3; ++d)
+#pragma unroll
+        for (int k = 0; k < SM_MAXBLK; ++k)
+          if (b_i[k] >= 0) {
+            const TC a = panel[off + kk * 4 * ROW_STRIDE + 48 * b_i[k] + d];
+            const TC b = panel[off + kk * 4 * ROW_STRIDE + 48 * b_j[k] + d];
+            acc[k] = M::mma(a, b, acc[k]);
+          }
+  }
+  TC* slab = slabs + (int64_t)blockIdx.x * (TILE * TILE);
+#pragma unroll
+  for (int k = 0; k < SM_MAXBLK; ++k)
+    if (b_i[k] >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(b_i[k] * 16 + M::row(lane, r)) * TILE + b_j[k] * 16 + (lane & 15)] = acc[k][r];
+    }
+}
+
+// ---------------------------------------------------------------------------
+enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3, STAGE_SMALL = 4 };
 
 struct GramPlan {
   int32_t n_pad, nt1, n_tiles;
@@ -851,6 +1046,33 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
   p->direct = !has_groups && (N % TILE == 0) && in_dtype == compute_dtype && aligned;
   p->staging = choose_staging(compute_dtype, p->nt1);
+  static const char* no_small = getenv("AGGF_GRAM_NO_SMALL");  // tests: force the tiled pipeline on small systems
+  static const char* small_shape = getenv("AGGF_GRAM_SMALL");
+  const int small_kbs = (small_shape && small_shape[0] == '4') ? 4 : 8;
+  const size_t raw_small = (size_t)round_up((int64_t)small_kbs * 3 * N * (int64_t)dtype_size(in_dtype), 16);
+  // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
+  if (p->nt1 == 1 && !no_small && raw_small <= (size_t)SM_MAXVEC * 64 * small_kbs * 16 && N < 21000 && aligned) {
+    // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
+    // triangle blocks only); one slab per workgroup, ~4 workgroups per CU over the frame axis
+    p->staging = STAGE_SMALL;
+    p->n_entries = 1;
+    p->direct = true;
+    p->chunk_frames = T;
+    p->pack_bytes = 0;
+    int64_t fps = round_up(ceil_div(T, (int64_t)(small_kbs == 8 ? 4 : 8) * device_cu_count()), SM_KB);
+    if (fps < SM_KB) fps = SM_KB;
+    const size_t slab1s = (size_t)TILE * TILE * dtype_size(compute_dtype);
+    if (!query) {
+      // fit the slabs into the given workspace: fewer, longer frame ranges
+      if (ws_bytes < table_bytes(*p) + slab1s + 512) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
+      const int64_t max_splits = (int64_t)((ws_bytes - table_bytes(*p) - 512) / slab1s);
+      if (ceil_div(T, fps) > max_splits) fps = round_up(ceil_div(T, max_splits), SM_KB);
+    }
+    p->frames_per_split = fps;
+    p->ksplit = (int)ceil_div(T, fps);
+    p->slab_bytes = (size_t)p->ksplit * slab1s;
+    return AGGF_OK;
+  }
   const bool pair = p->staging == STAGE_PAIR;
   p->n_entries = pair ? pair_entry_count(p->nt1) : p->n_tiles;
   const int upw = pair ? 2 : 1;
@@ -930,7 +1152,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
     return AGGF_OK;
   }
   if (p.staging == STAGE_DMA8) {
-    const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);
+    const size_t lds3 = (size_t)3 * 2 * dma_panel_elems<T>() * sizeof(T);
     static thread_local PerDeviceOnce attr_once;
     bool& attr_done = *attr_once.flag();
     if (!attr_done) {
@@ -950,7 +1172,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   }
   const bool use_dma = p.staging == STAGE_DMA;
   if (use_dma) {
-    const size_t lds3 = (size_t)3 * 2 * KB * ROW_STRIDE * sizeof(T);  // 3-stage ring, 76.8 KB
+    const size_t lds3 = (size_t)3 * 2 * dma_panel_elems<T>() * sizeof(T);  // 3-stage ring, 76.8 / 75.3 KB
     static thread_local PerDeviceOnce attr_once;
     bool& attr_done = *attr_once.flag();
     if (!attr_done) {
@@ -983,6 +1205,46 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   int32_t* tile_table = reinterpret_cast<int32_t*>(ws);
   ws += table_bytes(p);
   TC* slabs = reinterpret_cast<TC*>(ws);
+  if (p.staging == STAGE_SMALL) {
+    static const char* shape = getenv("AGGF_GRAM_SMALL");
+    const bool big = !(shape && shape[0] == '4');
+    const int kbs = big ? 8 : 4, threads = big ? 512 : 256;
+    const size_t raw_bytes = small_raw_bytes<TIn>(N, kbs);
+    const size_t lds = (size_t)kbs * ROW_STRIDE * sizeof(TC) + raw_bytes + (size_t)round_up(((int64_t)N + TILE + 1) * 4, 16) +
+                       (size_t)ROW_ELEMS * 4 * sizeof(unsigned short);
+    const int nv = (int)ceil_div((int64_t)(raw_bytes / 16 - 1), threads);
+    if (nv > SM_MAXVEC) return fail(AGGF_ERR_ARG, "aggf_gram: small-system kernel: frame too large");
+#define AGGF_SMALL(NVC, KBC, NWC)                                                                                    \
+  do {                                                                                                               \
+    if (lds > 65536) {                                                                                               \
+      static thread_local PerDeviceOnce attr_once;                                                                   \
+      bool& attr_done = *attr_once.flag();                                                                           \
+      if (!attr_done) {                                                                                              \
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_kernel<TIn, TC, NVC, KBC, NWC>,                      \
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));             \
+        attr_done = true;                                                                                            \
+      }                                                                                                              \
+    }                                                                                                                \
+    hipLaunchKernelGGL((gram_small_kernel<TIn, TC, NVC, KBC, NWC>), dim3((unsigned)p.ksplit), dim3(64 * NWC), lds,   \
+                       stream, reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red,                    \
+                       p.frames_per_split, (int32_t)raw_bytes, slabs);                                               \
+  } while (0)
+    if (big) {
+      if (nv <= 3) AGGF_SMALL(3, 8, 8);
+      else if (nv <= 5) AGGF_SMALL(5, 8, 8);
+      else AGGF_SMALL(8, 8, 8);
+    } else {
+      if (nv <= 3) AGGF_SMALL(3, 4, 4);
+      else if (nv <= 5) AGGF_SMALL(5, 4, 4);
+      else AGGF_SMALL(8, 4, 4);
+    }
+#undef AGGF_SMALL
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_reduce_kernel<TC>), dim3(1, TILE / 8), dim3(256), 0, stream, slabs, 1, p.ksplit, n_red,
+                       accumulate, G);
+    AGGF_LAUNCH_OK();
+    return AGGF_OK;
+  }
   if (p.direct) {
     // only reachable with TIn == TC
     return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,

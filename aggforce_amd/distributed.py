@@ -45,6 +45,18 @@ def all_reduce_sum_(t: torch.Tensor, comm) -> torch.Tensor:
     return t
 
 
+def all_reduce_minmax_(lo: torch.Tensor, hi: torch.Tensor, comm) -> None:
+    """In place: elementwise minimum of ``lo`` and maximum of ``hi`` over the ranks of ``comm``."""
+    group = resolve_comm(comm)
+    if group is None:
+        return
+    import torch.distributed as dist
+
+    if dist.get_world_size(group) > 1:
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN, group=group)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
+
+
 def frame_shard(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [begin, end) frame range of ``rank``; sizes differ by at most one frame."""
     if not 0 <= rank < world:

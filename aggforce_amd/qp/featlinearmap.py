@@ -313,7 +313,8 @@ def qp_feat_linear_map(
     return CLAFTMap(coord_map=coord_map, force_map=force_map)
 
 
-def _feat_linear_mapping(featurizer, coefs: List[np.ndarray], mapping: LinearMap, constraints, **kwargs) -> CLAMap:
+def _feat_linear_mapping(featurizer, coefs: List[np.ndarray], mapping: LinearMap, constraints, zeroes_check: bool = True,
+                         **kwargs) -> CLAMap:
     """CLAMap of a feature-linear map (reference featlinearmap.py:462-530).
 
     ``scale``/``trans`` follow the reference (each re-runs the featuriser).  ``apply`` is the
@@ -354,5 +355,5 @@ def _feat_linear_mapping(featurizer, coefs: List[np.ndarray], mapping: LinearMap
             cols.append(K.linearmap_apply(y, _coef_dev(c, F.device).reshape(1, -1)))
         return K.like_input(torch.cat(cols, dim=1), points)
 
-    return CLAMap(scale=scale_f, trans=trans_f, n_fg_sites=mapping.n_fg_sites, zeroes_check=True,
-                  apply=apply_f, **kwargs)
+    return CLAMap(scale=scale_f, trans=trans_f, n_fg_sites=mapping.n_fg_sites, zeroes_check=zeroes_check,
+                  n_cg_sites=None if zeroes_check else len(coefs), apply=apply_f, **kwargs)

@@ -30,7 +30,7 @@ import numpy as np
 
 from .. import _kernels as K
 from ..constraints import Constraints
-from ..distributed import agree_on_indices, all_reduce_sum_, shard_extent, take_global_frames
+from ..distributed import agree_on_indices, all_reduce_minmax_, all_reduce_sum_, shard_extent, take_global_frames
 from ..map import CLAFTMap, CLAMap, LinearMap
 from .featlinearmap import KNAME_DIVS, KNAME_FEATS, KNAME_NAMES, constraint_group_labels, id_feat
 
@@ -162,6 +162,9 @@ def recognise(featurizers) -> Optional[Tuple[bool, Optional[dict]]]:
     return None
 
 
+# Leave Gaussian columns that are identically zero over the trajectory out of the Gram matrix and the solve
+# (their coefficients are exactly zero in the minimiser); tests switch it off to compare with the full system.
+COMPACT_ZERO_COLUMNS = True
 _SOLVE_MEMORY_FRACTION = 0.6  # share of the free HBM the batched solve of a chunk of sites may take
 
 
@@ -208,13 +211,6 @@ def fit_id_gb(
     if n_feat == 0:
         raise ValueError("featuriser produces no features")
     Fg = geo.group_forces(traj.forces)
-    # The regression matrix goes straight into the Gram kernel's in-place layout: float64 storage (the
-    # float32 products of float32 forces widened on store -- K1 multiplies in float64, see below), feature
-    # columns padded with zeros to a multiple of the 128-wide tile.  No pack pass, no float32 round trip.
-    ld = -(-n_feat // 128) * 128
-    R3 = torch.empty((geo.T, ld, 3), dtype=torch.float64, device=geo.dev)
-    if ld > n_feat:
-        R3[:, n_feat:, :] = 0
     Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).to(geo.dev)  # (n_cg, G) float64
     n_cg = coord_map.n_cg_sites
     gen = np.random.default_rng() if rng is None else rng
@@ -234,31 +230,61 @@ def fit_id_gb(
     cg_sel = take_global_frames(geo.cg, flat_idx, comm)
     sel_begin = np.concatenate([[0], np.cumsum([len(u) for u in used])]).astype(np.int64)
     n_sel = {len(u) for u in used}
-    # Sites are independent problems of identical shape (own P, own A, one right-hand side): a batch of them
-    # is fitted side by side -- K1 per site into one (sites, n_feat, n_feat) stack, ONE all-reduce of the
-    # stack, then ONE batched K2 in which every step of the factorisation is a single launch over all sites.
-    # (One solve alone is a chain of ~300 small dependent kernels that leaves the GPU idle: 20 ms per site at
-    # n_feat = 6139 against 37 ms for its Gram matrix.)
+    # Which Gaussian columns can be non-zero at all?  Column (ch, k) of site c is identically zero when the
+    # channel's distance to the site stays outside (c_k - h, c_k + h), h = width sqrt(ln(1/clip)), in every
+    # frame (of every rank).  Such a column adds a zero row/column to P and zeros to A: its coefficient in
+    # the minimiser is exactly 0, so it is left out (for a cut-off basis most columns are: BASELINE config 4
+    # keeps ~2100 of 6139).  The distance range per (site, channel) is a superset test -- it can only keep
+    # columns that are zero after all, never drop one that is not.
+    keep = np.ones((n_cg, n_ch * n_basis), dtype=bool)
+    if n_ch and COMPACT_ZERO_COLUMNS:
+        rmin, rmax = K.gb_distance_range(geo.Pg, geo.cg, n_ch)
+        all_reduce_minmax_(rmin, rmax, comm)
+        lo = rmin.cpu().numpy()[:, :n_ch].astype(np.float64)
+        hi = rmax.cpu().numpy()[:, :n_ch].astype(np.float64)
+        reach = width * np.sqrt(np.log(1.0 / CLIP)) * (1.0 + 1e-5) + 1e-5  # float32 evaluation of the test: margin
+        c = centers_h.astype(np.float64)[None, None, :]
+        keep = ((lo[:, :, None] < c + reach) & (hi[:, :, None] > c - reach)).reshape(n_cg, n_ch * n_basis)
+    cols_of = [np.nonzero(keep[site])[0].astype(np.int32) for site in range(n_cg)]
+    n_act = [n_id + len(cols) for cols in cols_of]
+    n_max = max(n_act)
+    # The regression matrix goes straight into the Gram kernel's in-place layout: float64 storage (the
+    # float32 products of float32 forces widened on store -- K1 multiplies in float64, see below), feature
+    # columns padded to a multiple of the 128-wide tile.  No pack pass, no float32 round trip.
+    ld = -(-n_max // 128) * 128
+    R3 = torch.zeros((geo.T, ld, 3), dtype=torch.float64, device=geo.dev)
+    # Sites are independent problems (own P, own A, one right-hand side): a batch of them is fitted side by
+    # side -- K1 per site into one (sites, n_max, n_max) stack, ONE all-reduce of the stack, then ONE batched
+    # K2 in which every step of the factorisation is a single launch over all sites.  (One solve alone is a
+    # chain of ~300 small dependent kernels that leaves the GPU idle: 20 ms per site at n_feat = 6139.)
+    # A site with fewer kept columns than n_max is padded with unit diagonal entries and zero constraint
+    # columns: those variables come out as exact zeros.
     m_rows = max(n_sel) * n_cg if n_sel else 0
-    per_batch = _sites_per_batch(n_cg, n_feat, m_rows, geo.dev) if len(n_sel) == 1 else 1
+    per_batch = _sites_per_batch(n_cg, n_max, m_rows, geo.dev) if len(n_sel) == 1 else 1
     for c0 in range(0, n_cg, per_batch):
         sites = list(range(c0, min(n_cg, c0 + per_batch)))
         S = len(used[sites[0]])
-        Gs = torch.empty((len(sites), n_feat, n_feat), dtype=torch.float64, device=geo.dev)
-        As = torch.empty((len(sites), S * n_cg, n_feat), dtype=torch.float64, device=geo.dev)
+        Gs = torch.zeros((len(sites), n_max, n_max), dtype=torch.float64, device=geo.dev)
+        As = torch.empty((len(sites), S * n_cg, n_max), dtype=torch.float64, device=geo.dev)
         bs = torch.empty((len(sites), S * n_cg, 1), dtype=torch.float64, device=geo.dev)
         for j, site in enumerate(sites):
-            K.gb_regmat(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, n_ch, centers, width, CLIP, kbt, R3)
+            cols = torch.from_numpy(cols_of[site]).to(geo.dev)
+            na = n_act[site]
+            K.gb_regmat_cols(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, cols, centers, width, CLIP, kbt, R3)
             # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
             # exceeds l2 = 10 relative to force-squared sums of ~1e8 and P is no longer numerically positive
             # definite; the exact Gram of the float32 regression matrix always is
-            K.gram(R3, None, None, n_feat, torch.float64, out=Gs[j])
-            lo, hi = int(sel_begin[site]), int(sel_begin[site + 1])
+            if na == n_max:
+                K.gram(R3, None, None, na, torch.float64, out=Gs[j])
+            else:
+                Gs[j, :na, :na] = K.gram(R3, None, None, na, torch.float64)
+                Gs[j].diagonal()[na:] = 1.0
+            lo_s, hi_s = int(sel_begin[site]), int(sel_begin[site + 1])
             gauss = None
             if n_ch:
-                gauss, _ = K.gb_channels(Pg_sel[lo:hi].contiguous(), cg_sel[lo:hi].contiguous(), site, geo.sizes,
-                                         n_ch, centers, width, CLIP)
-            K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j])  # K4b
+                gauss, _ = K.gb_channels(Pg_sel[lo_s:hi_s].contiguous(), cg_sel[lo_s:hi_s].contiguous(), site,
+                                         geo.sizes, n_ch, centers, width, CLIP)
+            K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j], cols=cols)  # K4b
         all_reduce_sum_(Gs, comm)
         X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3)
         st_all = stats.cpu().numpy()
@@ -270,8 +296,12 @@ def fit_id_gb(
                     f"Map optimization failed. (site {site}: pivot {int(st[0])}, "
                     f"constraint residual {st[1]:.3e}, before refinement {st[2]:.3e}, scale {st[3]:.3e})"
                 )
-            coefs[site] = X_host[j]
+            full = np.zeros(n_feat, dtype=np.float64)
+            full[:n_id] = X_host[j, :n_id]
+            full[n_id + cols_of[site]] = X_host[j, n_id:n_act[site]]
+            coefs[site] = full
         del Gs, As, bs, X, stats
+    fit_info = {"kept_columns": n_act, "n_feat": n_feat, "sites_per_batch": per_batch}
     coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
 
     def apply_f(points, copoints):
@@ -282,9 +312,11 @@ def fit_id_gb(
 
     from .featlinearmap import _feat_linear_mapping
 
+    # only the scale/trans closures are borrowed (the reference's protocol for inspecting the map); the zero
+    # test of CLAMap's constructor would run the DENSE featuriser once per site for nothing
     dense = _feat_linear_mapping(featurizer=dense_featurizer, coefs=coefs, mapping=coord_map,
-                                 constraints=constraints)
+                                 constraints=constraints, zeroes_check=False)
     force_map = CLAMap(scale=dense.scale, trans=dense.trans, n_fg_sites=coord_map.n_fg_sites,
                        n_cg_sites=n_cg, zeroes_check=False, apply=apply_f,
-                       tags={"feat_names": None, "coef_list": coefs, "constraint_frames": used})
+                       tags={"feat_names": None, "coef_list": coefs, "constraint_frames": used, "fit_info": fit_info})
     return CLAFTMap(coord_map=coord_map, force_map=force_map)

@@ -62,6 +62,21 @@ def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndar
     A = torch.from_numpy(np.ascontiguousarray(A_host, dtype=np.float64)).to(dev)
     X, stats = K.eq_qp_solve(G, l2_regularization, l2_diag, A)
     st = stats.cpu().numpy()
+    if st[0] != 0 and st[0] <= G.shape[0] and np.isfinite(st[3]):
+        # P = G + l2 C'C is singular on null(A): fewer independent frames than free variables and no
+        # regularisation.  The minimiser is then not unique, but every minimiser maps the training frames
+        # identically (the objective is strictly convex in the mapped forces), and the reference's OSQP hands
+        # back one of them.  Do the same: a relative Tikhonov shift of 1e-10 picks the (nearly) minimum-norm one.
+        import warnings
+
+        warnings.warn(
+            f"{what}: the normal matrix is singular on the feasible set (pivot {int(st[0])}); the force map is not "
+            "unique -- returning a minimum-norm minimiser. Add frames or use l2_regularization > 0.",
+            stacklevel=3,
+        )
+        X, stats = K.eq_qp_solve(G, l2_regularization + 1e-10 * float(st[3]), None if l2_diag is None else l2_diag, A,
+                                 n_refine=2)
+        st = stats.cpu().numpy()
     if st[0] != 0 or not np.isfinite(st[1]):
         raise ValueError(
             f"{what} failed: the shifted normal matrix is not positive definite "

@@ -43,6 +43,10 @@ WORKLOADS = {
     "tiny": (4096, 256, 16, "f64"),        # plumbing check
     "c4": (20_000, 1024, 64, "f32"),       # configs[3]: featurised id_feat + gb_feat (n_basis 8, cutoff 8)
     "c5": (500_000, 2048, 128, "f32"),     # configs[4]: joptgauss_map, var 0.01 (4 GPUs in BASELINE)
+    # configs[0] at GPU scale: CLN025's topology (175 atoms, 10 CA beads, 59 constraint groups -> 97 reduced
+    # variables; tests/golden/g4_cln025.npz) with many synthetic frames.  Intensity 97*98/(175*8) = 6.8 flop/B
+    # is below the machine balance: the HBM-bound regime of the Gram build
+    "c1": (4_000_000, 175, 10, "f64"),
 }
 METHOD_LABEL = {
     "c3": "linear qp_linear_map, no constraints",
@@ -50,6 +54,7 @@ METHOD_LABEL = {
     "tiny": "linear qp_linear_map, no constraints",
     "c4": "featurised qp_feat_linear_map (id_feat + gb_feat, n_basis 8), bond-pair constraints, fp64 Gram products",
     "c5": "noised joptgauss_map (var 0.01), no constraints",
+    "c1": "linear qp_linear_map, CLN025 topology: 59 constraint groups (n_red 97), l2_regularization 1",
 }
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (MI355X_MICROARCH.md / SURVEY 8(d))
 SEED = 42100
@@ -279,6 +284,11 @@ def main():
         from aggforce_amd import joptgauss_map
 
         kwargs.update(method=joptgauss_map, var=0.01, kbt=KBT, seed=SEED, frame_offset=begin)
+    elif args.workload == "c1":
+        topo = np.load(os.path.join(ROOT, "tests", "golden", "g4_cln025.npz"))
+        constraints = {frozenset(int(x) for x in row if x >= 0) for row in topo["pairs"]}
+        cmap = LinearMap([[int(i)] for i in topo["ca"]], n_fg_sites=N)
+        kwargs.update(l2_regularization=1.0)
 
     def step():
         return project_forces(coords=coords, forces=forces, coord_map=cmap, constrained_inds=constraints, **kwargs)
@@ -312,9 +322,12 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = tmax.item()
     fmap = getattr(out["tmap"], "force_map", None)
+    if fmap is None and hasattr(out["tmap"], "tmap"):  # noised maps: the linear map of the extended system
+        fmap = getattr(out["tmap"].tmap, "force_map", None)
     if hasattr(fmap, "standard_matrix"):
         W = fmap.standard_matrix
-        cons_resid = float(np.max(np.abs(cmap.standard_matrix @ W.T - np.eye(n_cg))))
+        cons_resid = (float(np.max(np.abs(cmap.standard_matrix @ W.T - np.eye(n_cg))))
+                      if W.shape[1] == cmap.standard_matrix.shape[1] else None)
         solved = np.asarray(W, dtype=np.float64)
     else:
         cons_resid = None
@@ -330,14 +343,42 @@ def main():
     if rank == 0:
         gram = stages.get("gram", {"ms": float("nan"), "calls": 1})
         gram_ms = gram["ms"] / max(1, gram["calls"])
-        n_gram = N
-        if args.workload == "c4":
-            n_gram = (N - N // 3) * 9 - 8   # G id columns + 8 (G - 1) Gaussian columns, G = N - N/3 groups
-        elif args.workload == "c5":
-            n_gram = N + n_cg
-        flops = 3.0 * T_local * n_gram * (n_gram + 1)  # SYRK, upper triangle, per launch (SURVEY 8(d))
-        achieved = flops / (gram_ms * 1e-3) / 1e12
         gdt = "f64" if args.workload == "c4" else dt  # arithmetic type of the Gram products
+        s_bytes = 8 if dt == "f64" else 4
+        n_gram = N
+        if args.workload == "c5":
+            n_gram = N + n_cg
+        elif args.workload == "c1":
+            n_gram = 97
+        flops = 3.0 * T_local * n_gram * (n_gram + 1)  # SYRK, upper triangle, per launch (SURVEY 8(d))
+        gram_note = None
+        if args.workload == "c4":
+            # one launch per cg site, over the feature columns that site keeps (columns that vanish over the whole
+            # trajectory are left out, qp/gbfeat.py); flops_per_launch = mean over the sites' launches
+            kept = out["tmap"].force_map.tags["fit_info"]["kept_columns"]
+            flops = float(np.mean([3.0 * T_local * k * (k + 1) for k in kept]))
+            gram_note = (f"{len(kept)} launches per step over {min(kept)}..{max(kept)} kept feature columns of "
+                         f"{out['tmap'].force_map.tags['fit_info']['n_feat']} (mean {np.mean(kept):.0f})")
+        if args.workload == "c1":
+            # HBM-bound: algorithmic bytes of the Gram pass = one read of the forces (3 N s per frame)
+            algo_bytes = 3.0 * N * s_bytes * T_local
+            achieved = algo_bytes / (gram_ms * 1e-3) / 1e9
+            roof = {"kernel": "aggf_gram (pack_groups_kernel + gram_tile_dma_kernel<double, 0, 3, 2, 8, true> + gram_reduce_kernel)",
+                    "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "traffic": None, "ms_per_launch": gram_ms, "bytes_per_launch": algo_bytes,
+                    "flops_per_launch": flops, "mfma_tflops": flops / (gram_ms * 1e-3) / 1e12}
+        else:
+            achieved = flops / (gram_ms * 1e-3) / 1e12
+            kname = "gram_tile_dma_kernel<%s, 0, 3, 2, 8, true> (+ gram_reduce_kernel) = aggf_gram" % (
+                "double" if gdt == "f64" else "float")
+            roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",
+                    "frac": achieved / PEAK_TFLOPS[gdt], "traffic": profiled_traffic(args.workload, world),
+                    "traffic_source": "profiles/r01_c3_rocprof_summary.json (separate rocprofv3 --pmc passes; not measured in this run)"
+                    if profiled_traffic(args.workload, world) is not None else None,
+                    "mfma_busy_frac_pmc": profiled_mfma_busy(args.workload, world), "ms_per_launch": gram_ms,
+                    "flops_per_launch": flops}
+            if gram_note:
+                roof["launches"] = gram_note
         line = {
             "metric": "frames/sec through project_forces (Gram+solve), 1e6x4096-atom traj, 1/2/4/8 GPU",
             "value": T_total * args.steps / elapsed,
@@ -363,25 +404,16 @@ def main():
                 "rccl_world_size_seen": world_seen if comm is not None else None,
                 "replicated_solve_max_abs_diff_across_ranks": w_spread,
             },
-            "roofline": {
-                "kernel": "gram_tile_dma_kernel<double> (+ slab reduce) = aggf_gram" if gdt == "f64" else "gram_tile_kernel<float> (+ slab reduce) = aggf_gram",
-                "bound": "mfma",
-                "achieved": achieved,
-                "peak": PEAK_TFLOPS[gdt],
-                "unit": "TFLOP/s",
-                "frac": achieved / PEAK_TFLOPS[gdt],
-                "traffic": profiled_traffic(args.workload, world),
-                "mfma_busy_frac_pmc": profiled_mfma_busy(args.workload, world),
-                "ms_per_launch": gram_ms,
-                "flops_per_launch": flops,
-            },
+            "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and args.workload in ("c3", "c2", "tiny"):
             del out
             cb = cpu_baseline(N, n_cg, np.float64 if dt == "f64" else np.float32, T_total,
                               min(args.cpu_frames, T_total), blas_threads())
             cb.pop("_check")
             line["cpu_baseline"] = cb
+        elif world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = None  # the NumPy port times the linear unconstrained path only (c2/c3)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:

@@ -34,6 +34,7 @@ extern "C" {
 #define AGGF_ERR_ARG (-1)       /* bad argument (shape, dtype, alignment, NULL) */
 #define AGGF_ERR_HIP (-2)       /* HIP runtime error */
 #define AGGF_ERR_WORKSPACE (-3) /* workspace too small */
+#define AGGF_ERR_COMM (-4)      /* RCCL unavailable or a collective failed */
 
 #define AGGF_F32 0
 #define AGGF_F64 1
@@ -213,6 +214,23 @@ int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg
                    int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
                    int32_t n_ch, const float* centers, int32_t n_basis, double width, double clip,
                    double kbt, int32_t ld_feat, void* R3, int out_dtype, void* stream);
+/* Column compaction of the fused fit (no reference counterpart: the reference multiplies the
+ * zeros).  A clipped Gaussian column (ch, k) of gb_feat (jaxfeat.py:272-276) is identically
+ * zero over the trajectory if channel ch never comes within width*sqrt(ln(1/clip)) of centre
+ * c_k; it then contributes nothing to P = R'R nor to the constraint rows, its coefficient in
+ * the minimiser of featlinearmap.py:370-381 is exactly 0 (l2 > 0), and it can be dropped.
+ * aggf_gb_distance_range: rmin/rmax (n_cg, G) float32, caller-initialised to +inf / 0, receive
+ *   the min / max over frames of |Pg[t,ch] - cg[t,site]| for ch < n_ch (atomic min/max, so
+ *   several calls -- frame chunks, ranks -- accumulate).
+ * aggf_gb_regmat_cols: aggf_gb_regmat restricted to the Gaussian columns cols[j] = ch*n_basis+k
+ *   (j < n_cols), stored compactly: R3[t, n_id + j, :]. */
+int aggf_gb_distance_range(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
+                           int32_t n_ch, float* rmin, float* rmax, void* stream);
+int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+                        int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
+                        const int32_t* cols, int32_t n_cols, const float* centers, int32_t n_basis,
+                        double width, double clip, double kbt, int32_t ld_feat, void* R3,
+                        int out_dtype, void* stream);
 /* out (T, n_cg, 3) float64: application of the feature-linear force map
  * (featlinearmap.py:512-520 + map/core.py:428-430) for all sites;
  * coef: (n_cg, n_feat) float64, n_feat = n_id + n_ch*n_basis. */
@@ -249,10 +267,13 @@ int aggf_trjdot_frames(const void* points, int p_dtype, const void* factor, int 
  *   feat (T, N, n_feat); frame_idx[S] int64 device array; M (n_cg, N) float64;
  *   A (S*n_cg, n_feat), b (S*n_cg) float64.
  * aggf_gb_constraint_rows: the same rows for the fused [id_feat | gb_feat] features:
- *     A[(s,c), g]              = Mg[c,g]                       g  < n_id
- *     A[(s,c), n_id+ch*nb+k]   = Mg[c,ch] * gauss[s,ch,k]      ch < n_ch
+ *     A[(s,c), g]        = Mg[c,g]                        g < n_id
+ *     A[(s,c), n_id+j]   = Mg[c,ch] * gauss[s,ch,k]       j-th Gaussian column = (ch, k)
  *   Mg (n_cg, G) float64 = coordinate map summed over each constraint group, gauss
- *   (S, n_ch, nb) float32 from aggf_gb_channels on the sampled frames.
+ *   (S, n_ch, nb) float32 from aggf_gb_channels on the sampled frames.  cols == NULL: all
+ *   n_ch*nb Gaussian columns in (ch, k) order; else cols[j] = ch*nb + k for the n_cols
+ *   columns kept by the compacted fit (see aggf_gb_distance_range).  A has row stride
+ *   ld >= n_id + n_cols; columns beyond are zero.
  * aggf_feat_weights: scale_f of _feat_linear_mapping (featlinearmap.py:512-515):
  *     w[t*ld_t + a] = sum_f feat[t,a,f] * coef[f]     (ld_t >= N lets the caller stack sites)
  * ------------------------------------------------------------------------- */
@@ -263,8 +284,8 @@ int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t T, int32_t 
                               const int64_t* frame_idx, int32_t S, const double* M, int32_t n_cg,
                               int32_t site, double* A, double* b, void* stream);
 int aggf_gb_constraint_rows(const double* Mg, const float* gauss, int32_t S, int32_t n_cg, int32_t G,
-                            int32_t n_id, int32_t n_ch, int32_t n_basis, int32_t site, double* A,
-                            double* b, void* stream);
+                            int32_t n_id, int32_t n_ch, int32_t n_basis, const int32_t* cols,
+                            int32_t n_cols, int32_t ld, int32_t site, double* A, double* b, void* stream);
 int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32_t N, int32_t n_feat,
                       const double* coef, int64_t ld_t, double* w, void* stream);
 
@@ -295,6 +316,25 @@ int aggf_gram_quadform(const double* G, int32_t n, const double* X, int32_t m, d
                        size_t ws_bytes, void* stream);
 int aggf_daxpby(int64_t n, double a, const double* x, double b, const double* y, double* out,
                 void* stream);
+
+/* ---------------------------------------------------------------------------
+ * C1  The path's one collective: sum over the GPUs of a node of the per-shard Gram
+ * matrices (and of the residual's two scalars).  No reference counterpart (the reference is
+ * single-process); the objective of qplinear.py:66-77 is a sum over frames, so frames shard
+ * over ranks, every rank calls aggf_gram on its shard, ONE all-reduce combines G, and every
+ * rank runs the identical aggf_eq_qp_solve (replicated, no broadcast).  RCCL over xGMI,
+ * loaded on first use (librccl.so.1).  One process per GPU: rank 0 calls
+ * aggf_comm_unique_id and passes the 128 bytes to the other ranks by any host channel;
+ * every rank calls aggf_comm_init with the same id (collective), then
+ *     aggf_gram(...);  aggf_allreduce_sum(G, n_red*n_red, AGGF_F64, comm, stream);  aggf_eq_qp_solve(...)
+ * in place, asynchronous on `stream`.  (The Python host does the same through
+ * torch.distributed, backend "nccl" = RCCL: aggforce_amd/distributed.py.)
+ * ------------------------------------------------------------------------- */
+#define AGGF_COMM_ID_BYTES 128
+int aggf_comm_unique_id(void* id_out, size_t id_bytes);
+int aggf_comm_init(const void* id, size_t id_bytes, int32_t rank, int32_t world, void** comm_out);
+int aggf_comm_destroy(void* comm);
+int aggf_allreduce_sum(void* buf, int64_t count, int dtype, void* comm, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Synthetic trajectories for benchmarks and full-size property tests (no

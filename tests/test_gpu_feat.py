@@ -203,3 +203,54 @@ def test_gb_feat_kernels_match_autodiff_fixture(golden):
                 assert f.shape == g[f"{name}__feats"][c].shape and d.shape == ref_d[c].shape
                 assert np.max(np.abs(f - g[f"{name}__feats"][c])) < 5e-6, (name, c)
                 assert np.max(np.abs(d - ref_d[c])) < 1e-4, (name, c, method)
+
+
+def test_zero_column_compaction_is_exact():
+    """Gaussian columns that vanish over the whole trajectory (channels beyond the cut-off of a site) are left out
+    of the Gram matrix and the solve; the fit must equal the full system's: same coefficients (exact zeros at
+    the dropped columns), same mapped forces, and the oracle's solution of the FULL dense problem."""
+    from aggforce_amd.qp import gbfeat
+
+    rng = np.random.default_rng(21)
+    T, N = 80, 24
+    # two clusters 40 apart: every atom of one cluster is beyond outer + reach of the sites in the other
+    base = np.concatenate([3.0 * rng.random((N // 2, 3)), 3.0 * rng.random((N // 2, 3)) + 40.0])
+    coords = (base[None] + 0.2 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    forces = (25 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    cons = {frozenset([1, 2]), frozenset([13, 14]), frozenset([14, 15]), frozenset([20, 23])}
+    cmat = orc.list_mapping_matrix([[0, 1], [4, 7], [12, 13], [18, 22]], N)
+    cmap = LinearMap(cmat)
+    kw = dict(outer=6.0, inner=0.0, n_basis=5, width=1.0)
+    feat = Multifeaturize([id_feat, Curry(gb_feat, **kw)])
+    frames = [np.array([k]) for k in (3, 17, 40, 66)]
+    traj = Trajectory(coords=coords, forces=forces)
+    assert gbfeat.COMPACT_ZERO_COLUMNS
+    small = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=frames, l2_regularization=10.0)
+    info = small.force_map.tags["fit_info"]
+    assert max(info["kept_columns"]) < 0.7 * info["n_feat"]  # the far cluster's columns are gone
+    try:
+        gbfeat.COMPACT_ZERO_COLUMNS = False
+        full = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=frames, l2_regularization=10.0)
+    finally:
+        gbfeat.COMPACT_ZERO_COLUMNS = True
+    assert full.force_map.tags["fit_info"]["kept_columns"] == [info["n_feat"]] * 4
+    cs, cf = np.stack(small.force_map.tags["coef_list"]), np.stack(full.force_map.tags["coef_list"])
+    assert cs.shape == cf.shape == (4, info["n_feat"])
+    assert rel(cs, cf) < 1e-7
+    assert rel(small(traj).forces, full(traj).forces) < 1e-7
+    # dropped columns: exact zeros, and the dense features really vanish there in every frame
+    ids = orc.id_feat_ids(N, cons)
+    G = int(ids.max()) + 1
+    gf, gd = oracle_feats(coords, cmat, cons, ids, G - 1, dist_power=0.5, **kw)
+    for c in range(4):
+        dead = np.abs(gf[c]).max(axis=(0, 1)) == 0
+        assert dead.sum() > 0 and np.all(cs[c, G:][dead] == 0.0)
+    # oracle on the full dense problem
+    onehot = np.zeros((T, N, G), dtype=np.float32)
+    onehot[:, np.arange(N), ids] = 1
+    feats = [np.concatenate([onehot, g], axis=2) for g in gf]
+    divs = [np.concatenate([np.zeros((T, G, 3), np.float32), d], axis=1) for d in gd]
+    ocoef = orc.qp_feat_linear_map(forces, cmat, feats, divs, KBT, frames, 10.0)
+    # (float32 features: K4 and NumPy differ in the last bits of the Gaussians, which the fit amplifies)
+    assert rel(cs, np.stack(ocoef)) < 1e-2
+    assert rel(small(traj).forces, orc.cla_apply(forces, feats, divs, ocoef)) < 2e-3
