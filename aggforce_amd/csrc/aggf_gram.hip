@@ -829,7 +829,6 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
 // Two shapes: 8 frames per stage x 8 waves (default: 60 KB of LDS at CLN025, two workgroups per CU, 67 KB in
 // flight per CU) and 4 frames x 4 waves (AGGF_GRAM_SMALL=4: three smaller workgroups per CU; measured slower,
 // 10.2 against 7.5 ms at CLN025 x 4e6 frames before the group sums lost their loops).
-constexpr int SM_KB = 8;            // frame granularity of the split ranges (both shapes divide it)
 constexpr int SM_MAXVEC = 8;        // 16-byte loads per thread and stage (template NV = 3, 5 or 8)
 constexpr int SM_FAST_MEMBERS = 4;  // group members summed without a loop (larger groups: generic tail loop)
 
@@ -860,10 +859,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
                                                              (((int64_t)N + TILE + 1) * 4 + 15) / 16 * 16);  // [384][4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t t_begin = (int64_t)blockIdx.x * frames_per_split;
-  int64_t t_end = t_begin + frames_per_split;
-  if (t_end > T) t_end = T;
-  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KBS - 1) / KBS) : 0;
+  // Stages are dealt round-robin to the workgroups (stage = blockIdx.x + k * gridDim.x): the workgroups that run
+  // at the same time then read one contiguous window of the trajectory.  With a private contiguous range per
+  // workgroup, 512 far-apart streams hit the HBM channels at once and the row-buffer locality is gone
+  // (measured: 2.2 TB/s at CLN025 however the loads were issued).
+  (void)frames_per_split;
+  const int64_t n_stage_all = (T + KBS - 1) / KBS;
+  const int n_it = blockIdx.x < n_stage_all ? (int)((n_stage_all - 1 - blockIdx.x) / gridDim.x + 1) : 0;
+  const int64_t t_end = T;
+  auto stage_t0 = [&](int k) { return ((int64_t)blockIdx.x + (int64_t)k * gridDim.x) * KBS; };
   const int64_t row_in = (int64_t)N * 3;
   // column -> member atoms (CSR) in LDS; without constraint groups column g is atom g
   for (int a = tid; a < N; a += SM_THREADS) atoms_s[a] = grp_atoms ? grp_atoms[a] : a;
@@ -885,7 +889,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   const int n_vec = raw_bytes / 16 - 1;  // (the last piece is the zero slot)
   v16_t hold[NV];
   auto fetch = [&](int s) {
-    const int64_t t0 = t_begin + (int64_t)s * KBS;
+    const int64_t t0 = stage_t0(s);
     const int64_t valid = (t_end - t0 < KBS ? t_end - t0 : KBS) * row_in * (int64_t)sizeof(TIn);  // bytes
     const char* src = reinterpret_cast<const char*>(F + t0 * row_in);
 #pragma unroll
@@ -983,6 +987,174 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 }
 
 // ---------------------------------------------------------------------------
+// The same small-system kernel with the frames travelling HBM -> LDS by LDS-DMA into a 3-stage ring.
+// Why: with register staging the loads of a stage are issued in one burst and waited for before the next
+// burst goes out, so the bytes in flight per CU (2 x 33 KB) are only in flight part of the time: 2.2 TB/s
+// at CLN025 (7.5 ms for 4e6 frames), bound by latency.  With the ring, two stages per workgroup are in flight
+// WHILE a third is being consumed, nothing is held in registers, and the waves wait on a counted vmcnt exactly
+// like K1.  4 frames per stage, 8 waves, 2 workgroups per CU (67 KB of LDS at CLN025).
+constexpr int SD_KB = 4, SD_NW = 8, SD_NBUF = 3, SD_THREADS = 64 * SD_NW;
+constexpr int SD_ENT = SD_KB * ROW_ELEMS / SD_THREADS;  // 3
+constexpr int SD_MAXBLK = (36 + SD_NW - 1) / SD_NW;     // 5
+constexpr int SD_MAXPPW = 8;                            // DMA pieces per wave and stage (64 KB per stage)
+
+// ABL (ablation, AGGF_SMALL_ABL; measurements only): 1 = no MFMAs, 2 = no group sums, 3 = no DMAs
+template <typename TIn, typename TC, int ABL = 0>
+__global__ __launch_bounds__(SD_THREADS, 4) void gram_small_dma_kernel(
+    const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
+    const int32_t* __restrict__ grp_atoms, int32_t n_red, int64_t frames_per_split, int32_t raw_bytes,
+    TC* __restrict__ slabs) {
+  using M = Mfma<TC>;
+  using acc_t = typename M::acc_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  TC* panel = reinterpret_cast<TC*>(smem_raw);                              // [SD_KB][ROW_STRIDE]
+  char* ring = smem_raw + SD_KB * ROW_STRIDE * sizeof(TC);                  // [SD_NBUF][raw_bytes]: frames as in HBM
+  TIn* zero_s = reinterpret_cast<TIn*>(ring + SD_NBUF * raw_bytes);         // 16 bytes of zeros ("no member")
+  int32_t* atoms_s = reinterpret_cast<int32_t*>(ring + SD_NBUF * raw_bytes + 16);  // [N]
+  int32_t* ptr_s = atoms_s + N;                                                      // [129]
+  unsigned short* memb_s = reinterpret_cast<unsigned short*>(ring + SD_NBUF * raw_bytes + 16 +
+                                                             (((int64_t)N + TILE + 1) * 4 + 15) / 16 * 16);  // [384][4]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // stages dealt round-robin to the workgroups (see gram_small_kernel): co-running workgroups read one window
+  (void)frames_per_split;
+  const int64_t n_stage_all = (T + SD_KB - 1) / SD_KB;
+  const int n_it = blockIdx.x < n_stage_all ? (int)((n_stage_all - 1 - blockIdx.x) / gridDim.x + 1) : 0;
+  const int64_t t_end = T;
+  auto stage_t0 = [&](int k) { return ((int64_t)blockIdx.x + (int64_t)k * gridDim.x) * SD_KB; };
+  const int64_t row_in = (int64_t)N * 3;
+  const int64_t row_bytes = row_in * (int64_t)sizeof(TIn);
+
+  for (int a = tid; a < N; a += SD_THREADS) atoms_s[a] = grp_atoms ? grp_atoms[a] : a;
+  for (int g = tid; g <= TILE; g += SD_THREADS) ptr_s[g] = g <= n_red ? (grp_ptr ? grp_ptr[g] : g) : (grp_ptr ? grp_ptr[n_red] : n_red);
+  if (tid < 16 / (int)sizeof(TIn)) zero_s[tid] = (TIn)0;
+  __syncthreads();
+  bool big_groups = false;
+  for (int g = 0; g < n_red; ++g) big_groups |= ptr_s[g + 1] - ptr_s[g] > SM_FAST_MEMBERS;
+  for (int c = tid; c < ROW_ELEMS; c += SD_THREADS) {
+    const int g = c / 3, d = c - 3 * g;
+#pragma unroll
+    for (int j = 0; j < SM_FAST_MEMBERS; ++j)
+      memb_s[c * 4 + j] = (ptr_s[g] + j < ptr_s[g + 1]) ? (unsigned short)(3 * atoms_s[ptr_s[g] + j] + d) : (unsigned short)0xFFFF;
+  }
+
+  // DMA pieces of a stage: piece p = bytes [1024 p, 1024 (p+1)) of the contiguous run of SD_KB frames;
+  // wave w issues pieces w, w + 8, ...; my_pieces = how many of them exist (the same for every full stage)
+  const int n_pieces = (raw_bytes + 1023) / 1024;
+  const int my_pieces = wave < n_pieces ? (n_pieces - 1 - wave) / SD_NW + 1 : 0;
+  // the last stage of the trajectory may have fewer than SD_KB frames; it is the last stage of whoever owns it
+  const bool ragged = n_it > 0 && T % SD_KB != 0 && (n_stage_all - 1) % gridDim.x == blockIdx.x;
+  auto issue_stage = [&](int s) {
+    const int64_t t0 = stage_t0(s);
+    const int64_t valid = (t_end - t0 < SD_KB ? t_end - t0 : SD_KB) * row_bytes;  // bytes that exist
+    const char* src = reinterpret_cast<const char*>(F + t0 * row_in);
+    char* dst = ring + (s % SD_NBUF) * raw_bytes;
+    if (valid < raw_bytes) {
+      // the ragged last stage: missing frames read as zeros; a 16-byte piece that straddles the end of the
+      // data is copied element-wise instead of by DMA (no read past the end of the trajectory)
+      const int64_t whole = valid / 16 * 16;
+      for (int64_t b = whole + (int64_t)tid * sizeof(TIn); b < raw_bytes; b += (int64_t)SD_THREADS * sizeof(TIn))
+        *reinterpret_cast<TIn*>(dst + b) = b < valid ? *reinterpret_cast<const TIn*>(src + b) : (TIn)0;
+    }
+#pragma unroll
+    for (int q = 0; q < SD_MAXPPW; ++q) {
+      const int p = wave + SD_NW * q;
+      if (p < n_pieces) {
+        const int64_t off = (int64_t)p * 1024 + lane * 16;
+        if (ABL != 3 && off + 16 <= valid)
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + off),
+                                           (__attribute__((address_space(3))) void*)(dst + p * 1024), 16, 0, 0);
+      }
+    }
+  };
+  // wait until at most `my_pieces` of this wave's DMAs (= the newest stage) are outstanding
+  auto wait_older = [&](bool newest_is_full) {
+    if (!newest_is_full) { wait_vmcnt<0>(); return; }
+    switch (my_pieces) {
+      case 0: wait_vmcnt<0>(); break;
+      case 1: wait_vmcnt<1>(); break;
+      case 2: wait_vmcnt<2>(); break;
+      case 3: wait_vmcnt<3>(); break;
+      case 4: wait_vmcnt<4>(); break;
+      case 5: wait_vmcnt<5>(); break;
+      case 6: wait_vmcnt<6>(); break;
+      case 7: wait_vmcnt<7>(); break;
+      default: wait_vmcnt<8>(); break;
+    }
+  };
+  auto reduce_groups = [&](const TIn* raw) {
+#pragma unroll
+    for (int i = 0; i < SD_ENT; ++i) {
+      const int e = tid + SD_THREADS * i;  // (frame in stage, reduced column, xyz); padding columns sum nothing
+      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
+      const TIn* fr = raw + r * (int)row_in;
+      const uint2 m = *reinterpret_cast<const uint2*>(memb_s + c * 4);
+      const int o0 = m.x & 0xFFFF, o1 = m.x >> 16, o2 = m.y & 0xFFFF, o3 = m.y >> 16;
+      const TC v0 = (TC) * (o0 == 0xFFFF ? zero_s : fr + o0), v1 = (TC) * (o1 == 0xFFFF ? zero_s : fr + o1),
+               v2 = (TC) * (o2 == 0xFFFF ? zero_s : fr + o2), v3 = (TC) * (o3 == 0xFFFF ? zero_s : fr + o3);
+      TC acc = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
+      if (big_groups) {
+        const int g = c / 3, d = c - 3 * g;
+        for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) acc += (TC)fr[3 * atoms_s[j] + d];
+      }
+      panel[r * ROW_STRIDE + c] = acc;
+    }
+  };
+
+  const int nb = (n_red + 15) / 16;
+  int b_i[SD_MAXBLK], b_j[SD_MAXBLK];
+#pragma unroll
+  for (int k = 0; k < SD_MAXBLK; ++k) {
+    int q = wave + SD_NW * k, bi = 0, rowlen = nb;
+    while (bi < nb && q >= rowlen) {
+      q -= rowlen;
+      --rowlen;
+      ++bi;
+    }
+    b_i[k] = bi < nb ? bi : -1;
+    b_j[k] = bi + q;
+  }
+  acc_t acc[SD_MAXBLK];
+#pragma unroll
+  for (int k = 0; k < SD_MAXBLK; ++k) acc[k] = acc_zero<TC>();
+  const int off = (lane >> 4) * ROW_STRIDE + 3 * (lane & 15);
+
+  __syncthreads();  // tables complete
+  if (n_it > 0) issue_stage(0);
+  if (n_it > 1) issue_stage(1);
+  wait_older(n_it > 1 && !(ragged && n_it == 2));  // stage 0 has landed (this wave's pieces)
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __syncthreads();
+  for (int it = 0; it < n_it; ++it) {
+    if (ABL != 2) reduce_groups(reinterpret_cast<const TIn*>(ring + (it % SD_NBUF) * raw_bytes));
+    __syncthreads();  // panel complete; slot (it + 2) % 3 was last read in iteration it - 1
+    const bool more = it + 2 < n_it;
+    if (more) issue_stage(it + 2);
+#pragma unroll
+    for (int d = 0; d < 3; ++d)
+#pragma unroll
+      for (int k = 0; k < SD_MAXBLK; ++k)
+        if (ABL != 1 && b_i[k] >= 0) {
+          const TC a = panel[off + 48 * b_i[k] + d];
+          const TC b = panel[off + 48 * b_j[k] + d];
+          acc[k] = M::mma(a, b, acc[k]);
+        }
+    // stage it + 1 must have landed; stage it + 2 may stay in flight (unless it is the ragged one: its DMA
+    // count is not the usual one)
+    wait_older(more && !(ragged && it + 2 == n_it - 1));
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+  TC* slab = slabs + (int64_t)blockIdx.x * (TILE * TILE);
+#pragma unroll
+  for (int k = 0; k < SD_MAXBLK; ++k)
+    if (b_i[k] >= 0) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) slab[(b_i[k] * 16 + M::row(lane, r)) * TILE + b_j[k] * 16 + (lane & 15)] = acc[k][r];
+    }
+}
+
+// ---------------------------------------------------------------------------
 enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3, STAGE_SMALL = 4 };
 
 struct GramPlan {
@@ -990,6 +1162,7 @@ struct GramPlan {
   int staging;         // GramStaging
   int32_t n_entries;   // work items per split: n_tiles (unit kernels) or pair entries
   bool direct;         // gram kernel reads F in place
+  bool small_dma = false;  // STAGE_SMALL: LDS-DMA ring variant
   int ksplit;
   int64_t frames_per_split;
   int64_t chunk_frames;  // frames per pack chunk (direct: T)
@@ -1047,11 +1220,21 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->direct = !has_groups && (N % TILE == 0) && in_dtype == compute_dtype && aligned;
   p->staging = choose_staging(compute_dtype, p->nt1);
   static const char* no_small = getenv("AGGF_GRAM_NO_SMALL");  // tests: force the tiled pipeline on small systems
+  // small-system variants (AGGF_GRAM_SMALL): default "8" = register-staged, 8 frames x 8 waves (6.5 ms at CLN025 x
+  // 4e6 frames); "dma" = LDS-DMA ring, 4 frames per stage (6.8-7.0 ms); "4" = register-staged 4 x 4 waves.
+  // tools/c1_ablate.sh (DMA variant): 7.0 ms complete, 5.65 ms without any DMA, 4.2 ms without the MFMAs, 5.6 ms
+  // without the group sums -- the three phases (HBM 2.1 ms at 8 TB/s, MFMA 2.2 ms for the 28 upper-triangle
+  // blocks = 1.5x the algorithmic flops, LDS ~2.2 ms) are of equal size and overlap only partly.
   static const char* small_shape = getenv("AGGF_GRAM_SMALL");
-  const int small_kbs = (small_shape && small_shape[0] == '4') ? 4 : 8;
+  const bool small_dma_wanted = small_shape && small_shape[0] == 'd';
+  const size_t raw4 = (size_t)SD_KB * 3 * N * dtype_size(in_dtype);
+  const size_t lds_dma = (size_t)SD_KB * ROW_STRIDE * dtype_size(compute_dtype) + SD_NBUF * raw4 + 16 +
+                         (size_t)round_up(((int64_t)N + TILE + 1) * 4, 16) + (size_t)ROW_ELEMS * 8;
+  const bool small_dma = small_dma_wanted && raw4 % 16 == 0 && raw4 <= (size_t)SD_MAXPPW * SD_NW * 1024 && lds_dma <= 159 * 1024;
+  const int small_kbs = small_dma ? SD_KB : (small_shape && small_shape[0] == '4') ? 4 : 8;
   const size_t raw_small = (size_t)round_up((int64_t)small_kbs * 3 * N * (int64_t)dtype_size(in_dtype), 16);
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
-  if (p->nt1 == 1 && !no_small && raw_small <= (size_t)SM_MAXVEC * 64 * small_kbs * 16 && N < 21000 && aligned) {
+  if (p->nt1 == 1 && !no_small && (small_dma || raw_small <= (size_t)SM_MAXVEC * 64 * small_kbs * 16) && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
     // triangle blocks only); one slab per workgroup, ~4 workgroups per CU over the frame axis
     p->staging = STAGE_SMALL;
@@ -1059,17 +1242,19 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->direct = true;
     p->chunk_frames = T;
     p->pack_bytes = 0;
-    int64_t fps = round_up(ceil_div(T, (int64_t)(small_kbs == 8 ? 4 : 8) * device_cu_count()), SM_KB);
-    if (fps < SM_KB) fps = SM_KB;
+    p->small_dma = small_dma;
+    // one resident generation of workgroups (2 per CU; 3 for the 4 x 4 shape), each looping over strided stages
+    int64_t nwg = (int64_t)(small_kbs == 4 && !small_dma ? 3 : 2) * device_cu_count();
+    const int64_t n_stage_all = ceil_div(T, small_kbs);
+    if (nwg > n_stage_all) nwg = n_stage_all;
     const size_t slab1s = (size_t)TILE * TILE * dtype_size(compute_dtype);
     if (!query) {
-      // fit the slabs into the given workspace: fewer, longer frame ranges
       if (ws_bytes < table_bytes(*p) + slab1s + 512) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
       const int64_t max_splits = (int64_t)((ws_bytes - table_bytes(*p) - 512) / slab1s);
-      if (ceil_div(T, fps) > max_splits) fps = round_up(ceil_div(T, max_splits), SM_KB);
+      if (nwg > max_splits) nwg = max_splits;
     }
-    p->frames_per_split = fps;
-    p->ksplit = (int)ceil_div(T, fps);
+    p->frames_per_split = 0;
+    p->ksplit = (int)nwg;
     p->slab_bytes = (size_t)p->ksplit * slab1s;
     return AGGF_OK;
   }
@@ -1205,6 +1390,41 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   int32_t* tile_table = reinterpret_cast<int32_t*>(ws);
   ws += table_bytes(p);
   TC* slabs = reinterpret_cast<TC*>(ws);
+  if (p.staging == STAGE_SMALL && p.small_dma) {
+    const size_t raw_bytes = (size_t)SD_KB * 3 * N * sizeof(TIn);
+    const size_t lds = (size_t)SD_KB * ROW_STRIDE * sizeof(TC) + SD_NBUF * raw_bytes + 16 +
+                       (size_t)round_up(((int64_t)N + TILE + 1) * 4, 16) + (size_t)ROW_ELEMS * 4 * sizeof(unsigned short);
+    static thread_local PerDeviceOnce attr_once;
+    bool& attr_done = *attr_once.flag();
+    if (!attr_done) {
+      AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_dma_kernel<TIn, TC>,
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      attr_done = true;
+    }
+    static const char* abl_env = getenv("AGGF_SMALL_ABL");
+    const int abl = abl_env ? atoi(abl_env) : 0;
+#define AGGF_SD(A)                                                                                                  \
+  do {                                                                                                               \
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_dma_kernel<TIn, TC, A>,                                  \
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));                 \
+    hipLaunchKernelGGL((gram_small_dma_kernel<TIn, TC, A>), dim3((unsigned)p.ksplit), dim3(SD_THREADS), lds, stream, \
+                       reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red, p.frames_per_split,        \
+                       (int32_t)raw_bytes, slabs);                                                                   \
+  } while (0)
+    if (abl == 1) AGGF_SD(1);
+    else if (abl == 2) AGGF_SD(2);
+    else if (abl == 3) AGGF_SD(3);
+    else
+      hipLaunchKernelGGL((gram_small_dma_kernel<TIn, TC>), dim3((unsigned)p.ksplit), dim3(SD_THREADS), lds, stream,
+                         reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red, p.frames_per_split,
+                         (int32_t)raw_bytes, slabs);
+#undef AGGF_SD
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL((gram_reduce_kernel<TC>), dim3(1, TILE / 8), dim3(256), 0, stream, slabs, 1, p.ksplit, n_red,
+                       accumulate, G);
+    AGGF_LAUNCH_OK();
+    return AGGF_OK;
+  }
   if (p.staging == STAGE_SMALL) {
     static const char* shape = getenv("AGGF_GRAM_SMALL");
     const bool big = !(shape && shape[0] == '4');

@@ -189,12 +189,20 @@ def project_forces_streamed(
         up_f.release(hf)
         if i + 1 < len(spans):  # next uploads overlap the kernels queued above
             pend = (up_c.stage(*spans[i + 1]), up_f.stage(*spans[i + 1]))
-        mc_h, mf_h = mc.cpu().numpy(), mf.cpu().numpy()
+        # download on its own stream into PINNED host arrays: the copy of chunk i overlaps the kernels of
+        # chunk i+1 (a pageable `.cpu()` per chunk blocked the host for every chunk: 21.9 GB/s of a 63 GB/s link)
         if mapped_c is None:
-            mapped_c = np.empty((T, n_cg, 3), dtype=mc_h.dtype)
-            mapped_f = np.empty((T, n_cg, 3), dtype=mf_h.dtype)
-        mapped_c[b:e] = mc_h
-        mapped_f[b:e] = mf_h
+            mapped_c = torch.empty((T, n_cg, 3), dtype=mc.dtype, pin_memory=True)
+            mapped_f = torch.empty((T, n_cg, 3), dtype=mf.dtype, pin_memory=True)
+            down = torch.cuda.Stream(device=dev)
+        down.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(down):
+            mapped_c[b:e].copy_(mc, non_blocking=True)
+            mapped_f[b:e].copy_(mf, non_blocking=True)
+        mc.record_stream(down)
+        mf.record_stream(down)
+    down.synchronize()
+    mapped_c, mapped_f = mapped_c.numpy(), mapped_f.numpy()
     cnt = torch.tensor([float(T) * n_cg * 3], dtype=torch.float64, device=dev)
     both = torch.cat([acc, cnt])
     all_reduce_sum_(both, comm)
