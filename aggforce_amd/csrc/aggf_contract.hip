@@ -35,7 +35,8 @@ constexpr int TRJ_RW = 4;
 template <typename TFa, typename TP, typename TO>
 __global__ __launch_bounds__(256) void trjdot_frames_kernel(const TP* __restrict__ P, const TFa* __restrict__ Fa,
                                                             int64_t T, int32_t N, int32_t n_cg,
-                                                            const TO* __restrict__ trans, TO* __restrict__ out) {
+                                                            const TO* __restrict__ trans, TO* __restrict__ out,
+                                                            int vec_ok) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
@@ -49,6 +50,37 @@ __global__ __launch_bounds__(256) void trjdot_frames_kernel(const TP* __restrict
     double acc[TRJ_RW][3];
 #pragma unroll
     for (int r = 0; r < TRJ_RW; ++r) acc[r][0] = acc[r][1] = acc[r][2] = 0.0;
+    if (vec_ok && (3 * (16 / (int)sizeof(TFa))) % (16 / (int)sizeof(TP)) == 0) {
+      // 16-byte loads: lane = VF consecutive sites (VF = 4 floats / 2 doubles of the factor); their 3 VF point
+      // values are 3 VF consecutive elements
+      constexpr int VF = 16 / (int)sizeof(TFa);
+      typedef TFa __attribute__((ext_vector_type(VF))) vfa_t;
+      constexpr int VP = 16 / (int)sizeof(TP);
+      typedef TP __attribute__((ext_vector_type(VP))) vp_t;
+      for (int f0 = lane * VF; f0 < N; f0 += 64 * VF) {
+        double xyz[3 * VF];
+        const TP* pp = p + (int64_t)f0 * 3;
+#pragma unroll
+        for (int v = 0; v < 3 * VF / VP; ++v) {
+          const vp_t pv = *reinterpret_cast<const vp_t*>(pp + v * VP);
+#pragma unroll
+          for (int e = 0; e < VP; ++e) xyz[v * VP + e] = (double)pv[e];
+        }
+#pragma unroll
+        for (int r = 0; r < TRJ_RW; ++r) {
+          if (c0 + r < n_cg) {
+            const vfa_t wv = *reinterpret_cast<const vfa_t*>(fa + (int64_t)r * N + f0);
+#pragma unroll
+            for (int e = 0; e < VF; ++e) {
+              const double w = (double)wv[e];
+              acc[r][0] = fma(w, xyz[3 * e + 0], acc[r][0]);
+              acc[r][1] = fma(w, xyz[3 * e + 1], acc[r][1]);
+              acc[r][2] = fma(w, xyz[3 * e + 2], acc[r][2]);
+            }
+          }
+        }
+      }
+    } else
     for (int f = lane; f < N; f += 64) {
       const double x = (double)p[(int64_t)f * 3 + 0], y = (double)p[(int64_t)f * 3 + 1],
                    z = (double)p[(int64_t)f * 3 + 2];
@@ -204,14 +236,24 @@ __global__ __launch_bounds__(256) void gb_rows_kernel(const double* __restrict__
 template <typename TX>
 __global__ __launch_bounds__(256) void feat_weights_kernel(const TX* __restrict__ feat, int64_t T, int32_t N,
                                                            int32_t n_feat, const double* __restrict__ coef,
-                                                           int64_t ld_t, double* __restrict__ w) {
+                                                           int64_t ld_t, double* __restrict__ w, int vec_ok) {
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
   for (int64_t row = wid; row < T * N; row += nw) {
     const TX* x = feat + row * n_feat;
     double acc = 0.0;
-    for (int f = lane; f < n_feat; f += 64) acc = fma((double)x[f], coef[f], acc);
+    if (vec_ok) {
+      constexpr int VX = 16 / (int)sizeof(TX);
+      typedef TX __attribute__((ext_vector_type(VX))) vx_t;
+      for (int f0 = lane * VX; f0 < n_feat; f0 += 64 * VX) {
+        const vx_t xv = *reinterpret_cast<const vx_t*>(x + f0);
+#pragma unroll
+        for (int e = 0; e < VX; ++e) acc = fma((double)xv[e], coef[f0 + e], acc);
+      }
+    } else {
+      for (int f = lane; f < n_feat; f += 64) acc = fma((double)x[f], coef[f], acc);
+    }
     acc = wave_sum<double>(acc);
     if (lane == 0) {
       const int64_t t = row / N;
@@ -241,9 +283,14 @@ extern "C" int aggf_trjdot_frames(const void* points, int p_dtype, const void* f
     return fail(AGGF_ERR_ARG, "aggf_trjdot_frames: bad dtype");
   if (of != (pf || ff)) return fail(AGGF_ERR_ARG, "aggf_trjdot_frames: out dtype must be the promoted dtype");
   const dim3 grid = stream_grid(ceil_div(T * ceil_div(n_cg, TRJ_RW), 4)), block(256);
+  // 16-byte loads need every factor row and every frame of points to start 16-byte aligned and hold whole vectors
+  const int vf = ff ? 2 : 4;
+  // (double factor with float points: a lane's 2 sites are 6 floats = 24 bytes of points, not whole vectors)
+  const int vec_ok = !(ff && !pf) && (N % vf == 0) && (((uintptr_t)factor & 15) == 0) &&
+                     (((uintptr_t)points & 15) == 0) && (((int64_t)N * 3 * (pf ? 8 : 4)) % 16 == 0);
 #define AGGF_TRJ(TFa, TP, TO)                                                                                    \
   hipLaunchKernelGGL((trjdot_frames_kernel<TFa, TP, TO>), grid, block, 0, stream, (const TP*)points,               \
-                     (const TFa*)factor, T, N, n_cg, (const TO*)trans, (TO*)out)
+                     (const TFa*)factor, T, N, n_cg, (const TO*)trans, (TO*)out, vec_ok)
   if (!pf && !ff) AGGF_TRJ(float, float, float);
   else if (pf && !ff) AGGF_TRJ(float, double, double);
   else if (!pf && ff) AGGF_TRJ(double, float, double);
@@ -318,10 +365,11 @@ extern "C" int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32
   if (!feat || !coef || !w) return fail(AGGF_ERR_ARG, "aggf_feat_weights: NULL pointer");
   if (T <= 0 || N <= 0 || n_feat <= 0 || ld_t < N) return fail(AGGF_ERR_ARG, "aggf_feat_weights: bad shape");
   const dim3 grid = stream_grid(ceil_div(T * N, 4)), block(256);
+  const int vec_ok = (((uintptr_t)feat & 15) == 0) && (n_feat % (x_dtype == AGGF_F64 ? 2 : 4) == 0);
   if (x_dtype == AGGF_F32)
-    hipLaunchKernelGGL(feat_weights_kernel<float>, grid, block, 0, stream, (const float*)feat, T, N, n_feat, coef, ld_t, w);
+    hipLaunchKernelGGL(feat_weights_kernel<float>, grid, block, 0, stream, (const float*)feat, T, N, n_feat, coef, ld_t, w, vec_ok);
   else if (x_dtype == AGGF_F64)
-    hipLaunchKernelGGL(feat_weights_kernel<double>, grid, block, 0, stream, (const double*)feat, T, N, n_feat, coef, ld_t, w);
+    hipLaunchKernelGGL(feat_weights_kernel<double>, grid, block, 0, stream, (const double*)feat, T, N, n_feat, coef, ld_t, w, vec_ok);
   else
     return fail(AGGF_ERR_ARG, "aggf_feat_weights: bad dtype");
   AGGF_LAUNCH_OK();

@@ -154,12 +154,12 @@ def replicated_spread(t, world):
 
 def profiled_traffic(workload, world):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
-    (profiles/r01_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
+    (profiles/r02_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
     and counts 128-byte requests as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM): x 2."""
     if workload != "c3" or world != 1:
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_c3_rocprof_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_rocprof_summary.json")))
         rd = [e["FETCH_SIZE"]["per_dispatch"] for e in d["pmc_fetch"] if "gram_tile" in e["kernel"]][0]
         wr = [e["WRITE_SIZE"]["per_dispatch"] for e in d.get("pmc_write", []) if "gram_tile" in e["kernel"]]
         return 2.0 * rd * 1024 + (wr[0] * 1024 if wr else 0.0)
@@ -169,11 +169,11 @@ def profiled_traffic(workload, world):
 
 def profiled_mfma_busy(workload, world):
     """Fraction of the Gram kernel's cycles in which the MFMA pipes were busy, from the committed PMC pass
-    (profiles/r01_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    (profiles/r02_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
     if workload != "c3" or world != 1:
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r01_c3_mfma_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_mfma_counters.json")))
         return [v["mfma_utilisation"] for k, v in d["kernels"].items() if "gram_tile" in k][0]
     except Exception:
         return None
@@ -373,7 +373,7 @@ def main():
                 "double" if gdt == "f64" else "float")
             roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS[gdt], "traffic": profiled_traffic(args.workload, world),
-                    "traffic_source": "profiles/r01_c3_rocprof_summary.json (separate rocprofv3 --pmc passes; not measured in this run)"
+                    "traffic_source": "profiles/r02_c3_rocprof_summary.json (separate rocprofv3 --pmc passes; not measured in this run)"
                     if profiled_traffic(args.workload, world) is not None else None,
                     "mfma_busy_frac_pmc": profiled_mfma_busy(args.workload, world), "ms_per_launch": gram_ms,
                     "flops_per_launch": flops}

@@ -319,3 +319,51 @@ def test_bench_launcher_dry_run_two_ranks():
                             "assert 'torch' not in sys.modules; print('clean')"], capture_output=True, env=env,
                            cwd=ROOT, timeout=120)
     assert probe.stdout.decode().strip() == "clean", probe.stderr.decode()[-2000:]
+
+
+def _helpers_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+
+    sys.path.insert(0, ROOT)
+    from aggforce_amd.distributed import (agree_on_indices, all_reduce_minmax_, frame_shard, shard_extent,
+                                          take_global_frames, world_size)
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    T = 23
+    full = torch.arange(T * 4 * 3, dtype=torch.float32).reshape(T, 4, 3) * 0.5 - 7.0
+    b, e = frame_shard(T, rank, world)
+    local = full[b:e].clone()
+    first, total = shard_extent(local.shape[0], True, local.device)
+    assert (first, total) == (b, T) and world_size(True) == world
+    # an unseeded draw differs per rank: rank 0's wins everywhere
+    mine = np.random.default_rng(100 + rank).choice(T, size=7, replace=False)
+    idx = agree_on_indices(mine, True, local.device)
+    got = take_global_frames(local, idx, True)
+    lo = torch.tensor([float(rank), 5.0 - rank])
+    hi = lo.clone()
+    all_reduce_minmax_(lo, hi, dist.group.WORLD)
+    np.save(os.path.join(out_dir, f"idx{rank}.npy"), idx)
+    np.save(os.path.join(out_dir, f"got{rank}.npy"), got.numpy())
+    np.save(os.path.join(out_dir, f"mm{rank}.npy"), torch.stack([lo, hi]).numpy())
+    try:
+        take_global_frames(local, np.array([T]), True)
+        raise SystemExit("expected IndexError")
+    except IndexError:
+        pass
+    dist.destroy_process_group()
+
+
+def test_sharded_frame_helpers_gloo(tmp_path):
+    """The product's own multi-rank plumbing of the featurised fit on CPU tensors (gloo, 2 ranks): shard extents,
+    rank 0's frame draw on every rank, frames fetched from whichever rank owns them (bit for bit), min/max reduce."""
+    import torch.multiprocessing as mp
+
+    world, T = 2, 23
+    mp.spawn(_helpers_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    full = (np.arange(T * 4 * 3, dtype=np.float32).reshape(T, 4, 3) * 0.5 - 7.0)
+    i0, i1 = np.load(tmp_path / "idx0.npy"), np.load(tmp_path / "idx1.npy")
+    assert np.array_equal(i0, i1) and np.array_equal(i0, np.random.default_rng(100).choice(T, size=7, replace=False))
+    g0, g1 = np.load(tmp_path / "got0.npy"), np.load(tmp_path / "got1.npy")
+    assert np.array_equal(g0, g1) and np.array_equal(g0, full[i0])
+    for r in range(world):
+        assert np.array_equal(np.load(tmp_path / f"mm{r}.npy"), [[0.0, 4.0], [1.0, 5.0]])
