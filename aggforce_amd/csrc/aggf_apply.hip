@@ -287,6 +287,198 @@ __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict
   }
 }
 
+// ---------------------------------------------------------------------------
+// Few coarse-grained sites (n_cg <= 16, e.g. CLN025's 10 beads): the apply is HBM-bound (2 * 3 * n_cg flop per
+// 3 s bytes read), and the tile kernel above would multiply 64-site tiles that are 5/6 padding.  Same plan as the
+// small-system Gram kernel: a stage = 8 frames = ONE contiguous run of 8 * 3N elements, fetched with 16-byte loads
+// into registers during the previous stage's MFMAs and parked in LDS as it lies in HBM; the MFMA operands are read
+// straight from there -- rows = sites (the map, zero padded, in LDS), columns = (frame, xyz) pairs, K = atoms:
+//   D[c][(t,d)] += M[c][a] * P[t][a][d].
+// 8 frames x 3 = 24 columns = two 16-column blocks (waves 0 and 1 multiply, all 8 waves fetch and park); stages are
+// dealt round-robin to 2 resident workgroups per CU.  NaN policy, fused NaN scan and sum of squares as in the tile
+// kernel.
+constexpr int AS_KB = 8, AS_THREADS = 512, AS_NV = 5;   // 5 x 16 B x 512 threads = 40 KB of frames per stage
+
+template <typename TIn, typename TC, bool NANREP>
+__global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
+    const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg, TC nan_fill,
+    int32_t raw_bytes, int32_t n_pad, TC* __restrict__ out, double* __restrict__ sumsq_partials,
+    int32_t* __restrict__ nan_seen) {
+  using MF = Mfma<TC>;
+  using acc_t = typename MF::acc_t;
+  typedef float __attribute__((ext_vector_type(4))) v16_t;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  TIn* raw = reinterpret_cast<TIn*>(smem_raw);                       // AS_KB frames as in HBM (+ 64 zero bytes)
+  TC* ms = reinterpret_cast<TC*>(smem_raw + raw_bytes + 64);         // [16][n_pad + 2]: the map, zero padded
+  const int ms_ld = n_pad + 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t row_in = (int64_t)N * 3;
+  const int64_t n_stage_all = (T + AS_KB - 1) / AS_KB;
+  const int n_it = blockIdx.x < n_stage_all ? (int)((n_stage_all - 1 - blockIdx.x) / gridDim.x + 1) : 0;
+  auto stage_t0 = [&](int k) { return ((int64_t)blockIdx.x + (int64_t)k * gridDim.x) * AS_KB; };
+
+  for (int e = tid; e < 16 * ms_ld; e += AS_THREADS) {
+    const int c = e / ms_ld, a = e - c * ms_ld;
+    ms[e] = (c < n_cg && a < N) ? Mx[(int64_t)c * N + a] : (TC)0;
+  }
+  if (tid < 64 / (int)sizeof(TIn)) raw[raw_bytes / (int)sizeof(TIn) + tid] = (TIn)0;  // reads past the last frame: zeros
+
+  const int n_vec = raw_bytes / 16;
+  v16_t hold[AS_NV];
+  bool saw_nan = false;
+  auto fetch = [&](int s) {
+    const int64_t t0 = stage_t0(s);
+    const int64_t valid = (T - t0 < AS_KB ? T - t0 : AS_KB) * row_in * (int64_t)sizeof(TIn);
+    const char* src = reinterpret_cast<const char*>(P + t0 * row_in);
+#pragma unroll
+    for (int i = 0; i < AS_NV; ++i) {
+      const int v = tid + AS_THREADS * i;
+      v16_t x = {0.f, 0.f, 0.f, 0.f};
+      if (v < n_vec) {
+        const int64_t off = (int64_t)v * 16;
+        if (off + 16 <= valid) {
+          x = *reinterpret_cast<const v16_t*>(src + off);
+        } else if (off < valid) {
+          TIn tmp[16 / sizeof(TIn)];
+#pragma unroll
+          for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
+            tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
+          x = *reinterpret_cast<v16_t*>(tmp);
+        }
+      }
+      hold[i] = x;
+    }
+  };
+  auto park = [&]() {
+#pragma unroll
+    for (int i = 0; i < AS_NV; ++i) {
+      const int v = tid + AS_THREADS * i;
+      if (v < n_vec) {
+        TIn tmp[16 / sizeof(TIn)];
+        *reinterpret_cast<v16_t*>(tmp) = hold[i];
+#pragma unroll
+        for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k) {
+          saw_nan |= (tmp[k] != tmp[k]);
+          if (NANREP && tmp[k] != tmp[k]) tmp[k] = (TIn)nan_fill;
+        }
+        reinterpret_cast<v16_t*>(raw)[v] = *reinterpret_cast<v16_t*>(tmp);
+      }
+    }
+  };
+
+  // MFMA operands.  A[i = site][k = atom]: lane reads ms[lane & 15][a0 + (lane >> 4)].
+  // B[k = atom][j = column]: column j = 16 blk + (lane & 15) = 3 t + d (j < 24; others: the zero slot).
+  // All 8 waves multiply: wave = (column block blk = wave & 1) x (K quarter kq = wave >> 1: K steps kq, kq + 4,
+  // ...); the 4 partial accumulators of a block are summed through LDS in a fixed order.  (With only the two
+  // block waves multiplying, the 44 dependent LDS-read + MFMA steps of a stage were the critical path: 7.1 ms at
+  // CLN025 x 4e6 frames.)
+  const int blk = wave & 1, kq = wave >> 1;
+  const int offA = (lane & 15) * ms_ld + (lane >> 4);
+  const int j = 16 * blk + (lane & 15);
+  const bool col_ok = j < AS_KB * 3;
+  const int jt = j / 3, jd = j - 3 * jt;
+  const int offB = col_ok ? jt * (int)row_in + jd + 3 * (lane >> 4) : -1;
+  const int zero_off = raw_bytes / (int)sizeof(TIn);
+  TC* part = ms + 16 * ms_ld;  // [8 waves][4][64]: partial accumulators
+  double ss = 0.0;
+
+  if (n_it > 0) fetch(0);
+  for (int s = 0; s < n_it; ++s) {
+    __syncthreads();
+    park();
+    __syncthreads();
+    if (s + 1 < n_it) fetch(s + 1);
+    acc_t acc = acc_zero<TC>();
+    // two K steps per trip: both pairs of operand reads are in flight before the first MFMA
+    for (int a0 = 4 * kq; a0 < n_pad; a0 += 32) {
+      const int a1 = a0 + 16;
+      const bool second = a1 < n_pad;
+      const TC xa = ms[offA + a0];
+      // atoms past N (the last K step): the element at that address belongs to the NEXT frame -- read the zero
+      // slot instead, or a NaN there would leak into this frame (0 x NaN)
+      const TC xb = (TC)((offB >= 0 && a0 + (lane >> 4) < N) ? raw[offB + 3 * a0] : raw[zero_off]);
+      const TC ya = second ? ms[offA + a1] : (TC)0;
+      const TC yb = (TC)((second && offB >= 0 && a1 + (lane >> 4) < N) ? raw[offB + 3 * a1] : raw[zero_off]);
+      acc = MF::mma(xa, xb, acc);
+      acc = MF::mma(ya, yb, acc);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) part[(wave * 4 + r) * 64 + lane] = acc[r];
+    __syncthreads();
+    if (kq == 0) {
+      const int64_t t = stage_t0(s) + jt;
+      if (col_ok && t < T) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int c = MF::row(lane, r);
+          if (c < n_cg) {
+            TC v = part[((blk + 0) * 4 + r) * 64 + lane];
+            v += part[((blk + 2) * 4 + r) * 64 + lane];
+            v += part[((blk + 4) * 4 + r) * 64 + lane];
+            v += part[((blk + 6) * 4 + r) * 64 + lane];
+            out[(t * n_cg + c) * 3 + jd] = v;
+            ss += (double)v * (double)v;
+          }
+        }
+      }
+    }
+  }
+  if (nan_seen && __any(saw_nan) && lane == 0) atomicOr(nan_seen, 1);
+  if (sumsq_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    __shared__ double wsum[2];
+    if (lane == 0 && wave < 2) wsum[wave] = ss;  // (waves 0 and 1 wrote the outputs)
+    __syncthreads();
+    if (tid == 0) sumsq_partials[blockIdx.x] = wsum[0] + wsum[1];
+  }
+}
+
+template <typename TIn, typename TC>
+static int apply_small_launch(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg, int nan_mode,
+                              double nan_fill, void* out, double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes,
+                              hipStream_t stream) {
+  const int32_t raw_bytes = (int32_t)((int64_t)AS_KB * 3 * N * sizeof(TIn));  // a multiple of 16 for 4- and 8-byte elements
+  const int32_t n_pad = (int32_t)round_up(N, 4);
+  const size_t lds = (size_t)raw_bytes + 64 + (size_t)16 * (n_pad + 2) * sizeof(TC) + (size_t)8 * 4 * 64 * sizeof(TC);
+  int64_t nwg = 2 * (int64_t)device_cu_count();
+  const int64_t n_stage_all = ceil_div(T, AS_KB);
+  if (nwg > n_stage_all) nwg = n_stage_all;
+  double* partials = nullptr;
+  if (sumsq) {
+    if (!ws || ws_bytes < (size_t)nwg * sizeof(double))
+      return fail(AGGF_ERR_WORKSPACE, "aggf_linearmap_apply: workspace too small for sumsq");
+    partials = reinterpret_cast<double*>(ws);
+  }
+  const bool rep = nan_mode == AGGF_NAN_REPLACE;
+  if (lds > 65536) {
+    static thread_local PerDeviceOnce once_t, once_f;
+    bool& done = rep ? *once_t.flag() : *once_f.flag();
+    if (!done) {
+      if (rep)
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_small_kernel<TIn, TC, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      else
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_small_kernel<TIn, TC, false>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+      done = true;
+    }
+  }
+  if (rep)
+    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, true>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
+                       (const TIn*)P, T, N, (const TC*)Mx, n_cg, (TC)nan_fill, raw_bytes, n_pad, (TC*)out, partials, nan_seen);
+  else
+    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, false>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
+                       (const TIn*)P, T, N, (const TC*)Mx, n_cg, (TC)0, raw_bytes, n_pad, (TC*)out, partials, nan_seen);
+  AGGF_LAUNCH_OK();
+  if (sumsq) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nwg, sumsq);
+    AGGF_LAUNCH_OK();
+  }
+  return AGGF_OK;
+}
+
 template <typename TIn, typename TC, int THREADS, int TCB, int WFR = 4>
 static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg, int nan_mode,
                         double nan_fill, void* out, double* sumsq, int32_t* nan_seen, void* ws,
@@ -342,6 +534,10 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   // 64 frames x 128 sites with 16 waves (4 per SIMD; c3: 102.4 ms, 8 waves: 104.5 ms) when n_cg > 64,
   // else 64 x 64 with 4 waves.  AGGF_APPLY_TILE = "wide" | "big" (8 waves) | "small" overrides (benchmarks).
   static const char* force = getenv("AGGF_APPLY_TILE");
+  // few sites: the streaming kernel (frames of a stage must fit AS_NV 16-byte loads per thread; P 16-byte aligned)
+  if (!force && n_cg <= 16 && (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) <= (int64_t)AS_NV * AS_THREADS * 16 &&
+      (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) >= 16 && (((uintptr_t)P & 15) == 0) && T >= 64)
+    return apply_small_launch<TIn, TC>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   // (32 frames x 128 sites with 8 waves -- two independent workgroups per CU -- measured the same 103 ms)
   const int tile = force ? (force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
   if (tile == 2)
@@ -361,7 +557,8 @@ using namespace aggf;
 extern "C" size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg) {
   (void)N;
   if (T <= 0 || n_cg <= 0) return 256;
-  return (size_t)round_up(ceil_div(T, 32) * ceil_div(n_cg, 64) * 8, 256);
+  // one partial per workgroup: tile kernel ceil(T/32) x ceil(n_cg/64) at most, streaming kernel 2 per CU
+  return (size_t)round_up(ceil_div(T, 32) * ceil_div(n_cg, 64) * 8 + 2 * 8 * (int64_t)device_cu_count(), 256);
 }
 
 extern "C" int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype,
