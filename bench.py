@@ -363,7 +363,7 @@ def main():
             # HBM-bound: algorithmic bytes of the Gram pass = one read of the forces (3 N s per frame)
             algo_bytes = 3.0 * N * s_bytes * T_local
             achieved = algo_bytes / (gram_ms * 1e-3) / 1e9
-            roof = {"kernel": "aggf_gram (pack_groups_kernel + gram_tile_dma_kernel<double, 0, 3, 2, 8, true> + gram_reduce_kernel)",
+            roof = {"kernel": "aggf_gram = gram_small_kernel<double, double, 5, 8, 8> (fused group sums, one pass over F) + gram_reduce_small_kernel",
                     "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "ms_per_launch": gram_ms, "bytes_per_launch": algo_bytes,
                     "flops_per_launch": flops, "mfma_tflops": flops / (gram_ms * 1e-3) / 1e12}
