@@ -136,8 +136,11 @@ def gram(
     out: Optional[torch.Tensor] = None,
     accumulate: bool = False,
     ws_limit_bytes: Optional[int] = None,
+    first_col: int = 0,
 ) -> torch.Tensor:
-    """G (n_red, n_red) float64 from forces (T, N, 3); see aggf_gram in include/aggf.h."""
+    """G (n_red, n_red) float64 from forces (T, N, 3); see aggf_gram in include/aggf.h.  ``first_col`` > 0
+    (a multiple of 128, no constraint groups): the leading first_col x first_col block of ``out`` is the
+    caller's and is not computed (aggf_gram_from_column)."""
     l = lib()
     T, N, D = forces.shape
     if D != 3:
@@ -154,11 +157,20 @@ def gram(
         need = min(need, int(ws_limit_bytes))
     ws = workspace(need, dev, "gram")
     with _timed("gram"):
-        check(
-            l.aggf_gram(ptr(forces), T, N, ind, cd, ptr(grp_ptr), ptr(grp_atoms), n_red, ptr(out),
-                        1 if accumulate else 0, ptr(ws), need, stream_ptr()),
-            "aggf_gram",
-        )
+        if first_col:
+            if grp_ptr is not None:
+                raise ValueError("first_col needs a regression matrix without constraint groups")
+            check(
+                l.aggf_gram_from_column(ptr(forces), T, N, ind, cd, n_red, int(first_col), ptr(out),
+                                        1 if accumulate else 0, ptr(ws), need, stream_ptr()),
+                "aggf_gram_from_column",
+            )
+        else:
+            check(
+                l.aggf_gram(ptr(forces), T, N, ind, cd, ptr(grp_ptr), ptr(grp_atoms), n_red, ptr(out),
+                            1 if accumulate else 0, ptr(ws), need, stream_ptr()),
+                "aggf_gram",
+            )
     return out
 
 

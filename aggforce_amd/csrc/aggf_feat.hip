@@ -241,9 +241,10 @@ __global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg
       const TF* f = Fg + (t * G + ch) * 3;
       const float m = sizes[ch];
       for (int k = 0; k < gp.n_basis; ++k) {
+        const double c = cf[n_id + ch * gp.n_basis + k];
+        if (c == 0.0) continue;  // columns the fit left out (identically zero over the training frames): no expf
         float g, dg;
         gb_gauss(gp, r, k, g, dg);
-        const double c = cf[n_id + ch * gp.n_basis + k];
         const float s = m * dg;
         a0 += c * ((double)((TF)g * f[0]) + (double)(s * u[0]));
         a1 += c * ((double)((TF)g * f[1]) + (double)(s * u[1]));

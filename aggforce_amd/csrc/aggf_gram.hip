@@ -497,7 +497,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
 }
 
 // tile_table[k] = (ti << 16) | tj of the k-th upper-triangle tile in 8x8 super-block order
-__global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table) {
+// (tiles with tj < first_tile -- a leading block the caller already has -- are left out)
+__global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table, int32_t first_tile = 0) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
   const int nsb = (nt1 + 7) / 8;
   int k = 0;
@@ -505,7 +506,7 @@ __global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table
     for (int sj = si; sj < nsb; ++sj)
       for (int ti = si * 8; ti < si * 8 + 8 && ti < nt1; ++ti)
         for (int tj = sj * 8; tj < sj * 8 + 8 && tj < nt1; ++tj)
-          if (tj >= ti) table[k++] = (ti << 16) | tj;
+          if (tj >= ti && tj >= first_tile) table[k++] = (ti << 16) | tj;
 }
 
 // ---------------------------------------------------------------------------
@@ -779,7 +780,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ slabs,
                                                           int32_t nt1, int32_t ksplit,
                                                           int32_t n_red, int accumulate,
-                                                          double* __restrict__ G) {
+                                                          double* __restrict__ G, int32_t first_tile = 0) {
   int tile = blockIdx.x;
   const int tile_lin = tile;
   int ti = 0;
@@ -792,6 +793,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
     }
   }
   const int tj = ti + tile;
+  if (tj < first_tile) return;  // a tile of the leading block the caller keeps: no slabs were written for it
   const T* base = slabs + (int64_t)tile_lin * ksplit * (TILE * TILE);
   const int r0 = blockIdx.y * 8;
   for (int e = threadIdx.x; e < 8 * TILE; e += blockDim.x) {
@@ -1188,6 +1190,7 @@ enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3,
 
 struct GramPlan {
   int32_t n_pad, nt1, n_tiles;
+  int32_t first_tile = 0;  // tiles with tj < first_tile are skipped (aggf_gram_from_column; DMA8 direct path only)
   int staging;         // GramStaging
   int32_t n_entries;   // work items per split: n_tiles (unit kernels) or pair entries
   bool direct;         // gram kernel reads F in place
@@ -1242,7 +1245,7 @@ static int choose_staging(int compute_dtype, int nt1) {
 }
 
 static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
-                     bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p) {
+                     bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p, int32_t first_col = 0) {
   p->n_pad = (int32_t)round_up(n_red, TILE);
   p->nt1 = p->n_pad / TILE;
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
@@ -1289,6 +1292,12 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   }
   const bool pair = p->staging == STAGE_PAIR;
   p->n_entries = pair ? pair_entry_count(p->nt1) : p->n_tiles;
+  p->first_tile = 0;
+  if (first_col >= TILE && p->staging == STAGE_DMA8 && p->direct) {
+    p->first_tile = first_col / TILE;
+    if (p->first_tile >= p->nt1) p->first_tile = p->nt1 - 1;  // always at least the last tile column
+    p->n_entries = p->n_tiles - p->first_tile * (p->first_tile + 1) / 2;
+  }
   const int upw = pair ? 2 : 1;
   const int kb = compute_dtype == AGGF_F64 ? GramCfg<double>::KB : GramCfg<float>::KB;
   const size_t cs = dtype_size(compute_dtype);
@@ -1374,13 +1383,14 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       attr_done = true;
     }
-    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table);
+    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, p.first_tile);
     AGGF_LAUNCH_OK();
-    hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblocks, 512)), dim3(512),
-                       lds3, stream, X, rows, ld, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs);
+    const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
+    hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
+                       lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
-                       slabs, p.nt1, ksplit, n_red, accumulate, G);
+                       slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
     AGGF_LAUNCH_OK();
     return AGGF_OK;
   }
@@ -1528,9 +1538,9 @@ extern "C" size_t aggf_gram_workspace_bytes(int64_t T, int32_t N, int32_t n_red,
   return table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 1024;
 }
 
-extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
-                         const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red,
-                         double* G, int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
+static int gram_impl(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+                     const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red, int32_t first_col,
+                     double* G, int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!F || !G || !ws) return fail(AGGF_ERR_ARG, "aggf_gram: NULL pointer");
   if (T <= 0 || N <= 0 || n_red <= 0) return fail(AGGF_ERR_ARG, "aggf_gram: empty problem");
@@ -1543,10 +1553,11 @@ extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int 
   if (has_groups != (grp_atoms != nullptr))
     return fail(AGGF_ERR_ARG, "aggf_gram: grp_ptr and grp_atoms must be given together");
   if (n_red > N) return fail(AGGF_ERR_ARG, "aggf_gram: n_red > N");
+  if (first_col < 0 || first_col % TILE != 0) return fail(AGGF_ERR_ARG, "aggf_gram_from_column: first_col must be a multiple of 128");
   if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram: workspace not 256-byte aligned");
   const bool aligned = ((uintptr_t)F & 15) == 0;
   GramPlan p;
-  int rc = make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups, aligned, ws_bytes, false, &p);
+  int rc = make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups, aligned, ws_bytes, false, &p, first_col);
   if (rc) return rc;
   if (table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes > ws_bytes)
     return fail(AGGF_ERR_WORKSPACE, "aggf_gram: workspace too small");
@@ -1556,4 +1567,17 @@ extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int 
   if (compute_dtype == AGGF_F64)
     return gram_typed<float, double>(F, T, N, grp_ptr, grp_atoms, n_red, G, accumulate, p, w, stream);
   return gram_typed<float, float>(F, T, N, grp_ptr, grp_atoms, n_red, G, accumulate, p, w, stream);
+}
+
+extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+                         const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red,
+                         double* G, int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
+  return gram_impl(F, T, N, in_dtype, compute_dtype, grp_ptr, grp_atoms, n_red, 0, G, accumulate, ws, ws_bytes, stream_v);
+}
+
+extern "C" int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+                                     int32_t n_red, int32_t first_col, double* G, int accumulate, void* ws,
+                                     size_t ws_bytes, void* stream_v) {
+  return gram_impl(F, T, N, in_dtype, compute_dtype, nullptr, nullptr, n_red, first_col, G, accumulate, ws, ws_bytes,
+                   stream_v);
 }

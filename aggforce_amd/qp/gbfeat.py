@@ -261,6 +261,7 @@ def fit_id_gb(
     # columns: those variables come out as exact zeros.
     m_rows = max(n_sel) * n_cg if n_sel else 0
     per_batch = _sites_per_batch(n_cg, n_max, m_rows, geo.dev) if len(n_sel) == 1 else 1
+    shared_lead = None  # leading (id x id) Gram block, identical for all sites
     for c0 in range(0, n_cg, per_batch):
         sites = list(range(c0, min(n_cg, c0 + per_batch)))
         S = len(used[sites[0]])
@@ -274,10 +275,21 @@ def fit_id_gb(
             # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
             # exceeds l2 = 10 relative to force-squared sums of ~1e8 and P is no longer numerically positive
             # definite; the exact Gram of the float32 regression matrix always is
+            # the id block of the regression matrix (the group force sums) is the same for every site: its
+            # Gram block is taken from the first site's matrix (whole 128-tiles of it) and not computed again
+            lead = (n_id // 128) * 128 if (shared_lead is not None and na >= 256) else 0
             if na == n_max:
-                K.gram(R3, None, None, na, torch.float64, out=Gs[j])
+                K.gram(R3, None, None, na, torch.float64, out=Gs[j], first_col=lead)
+                Gsite = Gs[j]
             else:
-                Gs[j, :na, :na] = K.gram(R3, None, None, na, torch.float64)
+                Gsite = torch.empty((na, na), dtype=torch.float64, device=geo.dev)
+                K.gram(R3, None, None, na, torch.float64, out=Gsite, first_col=lead)
+            if lead:
+                Gsite[:lead, :lead] = shared_lead
+            elif shared_lead is None and n_id >= 128:
+                shared_lead = Gsite[: (n_id // 128) * 128, : (n_id // 128) * 128].clone()
+            if na != n_max:
+                Gs[j, :na, :na] = Gsite
                 Gs[j].diagonal()[na:] = 1.0
             lo_s, hi_s = int(sel_begin[site]), int(sel_begin[site + 1])
             gauss = None

@@ -356,7 +356,10 @@ def main():
             # one launch per cg site, over the feature columns that site keeps (columns that vanish over the whole
             # trajectory are left out, qp/gbfeat.py); flops_per_launch = mean over the sites' launches
             kept = out["tmap"].force_map.tags["fit_info"]["kept_columns"]
-            flops = float(np.mean([3.0 * T_local * k * (k + 1) for k in kept]))
+            # the id x id block (whole 128-tiles of it) is identical for all sites: formed by the first launch only
+            lead = ((N - N // 3) // 128) * 128
+            flops = float(np.mean([3.0 * T_local * (k * (k + 1) - (lead * (lead + 1) if i else 0))
+                                   for i, k in enumerate(kept)]))
             gram_note = (f"{len(kept)} launches per step over {min(kept)}..{max(kept)} kept feature columns of "
                          f"{out['tmap'].force_map.tags['fit_info']['n_feat']} (mean {np.mean(kept):.0f})")
         if args.workload == "c1":

@@ -72,6 +72,18 @@ int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dty
               const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red, double* G,
               int accumulate, void* ws, size_t ws_bytes, void* stream);
 
+/* The same Gram matrix when the caller already holds its leading first_col x first_col block
+ * (first_col a multiple of 128): only the 128 x 128 tiles that reach column first_col or beyond
+ * are computed and written (both triangles); G[0:first_col, 0:first_col] is left untouched.
+ * Used by the featurised fit (featlinearmap.py:361-372 per cg site): the id_feat block of the
+ * regression matrix -- the group force sums -- is the same for every site, so its Gram block is
+ * formed once and pasted.  No constraint groups here (F is a regression matrix).  Layouts that
+ * do not take the in-place tile kernel compute everything (still correct: G is overwritten with
+ * the same values). */
+int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+                          int32_t n_red, int32_t first_col, double* G, int accumulate, void* ws,
+                          size_t ws_bytes, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K2  Equality-constrained least squares shared by all coarse-grained sites.
  *
