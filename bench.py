@@ -72,6 +72,9 @@ def parse(argv=None):
     p.add_argument("--dry-run", action="store_true",
                    help="launcher self-test on CPU (gloo, no GPU, no product compute): NOT a measurement")
     p.add_argument("--dry-run-fail-rank", type=int, default=-1, help=argparse.SUPPRESS)
+    p.add_argument("--rehearse-on-one-gpu", action="store_true",
+                   help="N > 1 ranks that all use cuda:0 and talk over gloo (RCCL refuses two ranks on one device): "
+                        "exercises the multi-rank code path on a one-GPU box; NOT a measurement")
     return p.parse_args(argv)
 
 
@@ -243,13 +246,18 @@ def main():
         return dry_run(args, world, rank, result_fd)
     import torch
 
+    if args.rehearse_on_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     comm = None
     if world > 1 or "TORCHELASTIC_RUN_ID" in os.environ:  # under torch.distributed.run: always RCCL
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse_on_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         comm = dist.group.WORLD
 
     from aggforce_amd import LinearMap, project_forces
@@ -402,7 +410,8 @@ def main():
                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
                 "constraint_residual": cons_resid,
                 "residual": out["residual"],
-                "collective": ("RCCL all-reduce of the Gram matrix (torch.distributed backend nccl)" if comm is not None
+                "collective": ("REHEARSAL: gloo, all ranks on cuda:0 -- not a measurement" if args.rehearse_on_one_gpu
+                               else "RCCL all-reduce of the Gram matrix (torch.distributed backend nccl)" if comm is not None
                                else "none (single process)"),
                 "rccl_world_size_seen": world_seen if comm is not None else None,
                 "replicated_solve_max_abs_diff_across_ranks": w_spread,
