@@ -669,3 +669,24 @@ def pair_dist_var(x: torch.Tensor) -> torch.Tensor:
         check(l.aggf_pair_dist_var(ptr(x), T, N, dtype_code(x.dtype), ptr(var), ptr(ws), need, stream_ptr()),
               "aggf_pair_dist_var")
     return var
+
+
+def pair_dist_moments(x: torch.Tensor):
+    """(mean, var) (N, N) float64 of every pair distance over the frames; see aggf_pair_dist_moments."""
+    l = lib()
+    T, N, _ = x.shape
+    mean = torch.empty((N, N), dtype=torch.float64, device=x.device)
+    var = torch.empty((N, N), dtype=torch.float64, device=x.device)
+    need = l.aggf_pair_dist_var_workspace_bytes(T, N)
+    ws = workspace(need, x.device, "pairs")
+    with _timed("pair_var"):
+        check(l.aggf_pair_dist_moments(ptr(x), T, N, dtype_code(x.dtype), ptr(mean), ptr(var), ptr(ws), need, stream_ptr()),
+              "aggf_pair_dist_moments")
+    return mean, var
+
+
+def pair_pool_term(var_r: torch.Tensor, mean_r: torch.Tensor, mean: torch.Tensor, weight: float) -> torch.Tensor:
+    """weight * (var_r + (mean_r - mean)^2), in place of var_r; see aggf_pair_pool_term."""
+    check(lib().aggf_pair_pool_term(ptr(var_r), ptr(mean_r), ptr(mean), float(weight), var_r.numel(), ptr(var_r),
+                                    stream_ptr()), "aggf_pair_pool_term")
+    return var_r

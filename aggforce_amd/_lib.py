@@ -57,6 +57,8 @@ PROTOTYPES = {
     "aggf_feat_weights": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "aggf_pair_dist_var_workspace_bytes": (_sz, [_i64, _i32]),
     "aggf_pair_dist_var": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _sz, _vp]),
+    "aggf_pair_dist_moments": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_pair_pool_term": (C.c_int, [_vp, _vp, _vp, _dbl, _i64, _vp, _vp]),
     "aggf_gram_quadform_workspace_bytes": (_sz, [_i32, _i32]),
     "aggf_gram_quadform": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _vp, _sz, _vp]),
     "aggf_daxpby": (C.c_int, [_i64, _dbl, _vp, _dbl, _vp, _vp, _vp]),

@@ -82,15 +82,8 @@ def project_forces(
             raise ValueError(
                 f"If constrained_inds is {PROJECT_FORCES_CNSTR_AUTO}, coords cannot be None."
             )
-        from .distributed import world_size
-
-        if world_size(kwargs.get("comm")) > 1:
-            # each rank would guess from its own frames: the sets (and n_red, the all-reduce shape) could differ
-            raise ValueError(
-                f"constrained_inds={PROJECT_FORCES_CNSTR_AUTO!r} cannot be combined with comm= (frames sharded over "
-                "ranks): guess the constraints once with guess_pairwise_constraints and pass the same set on every rank."
-            )
-        constrained_inds = guess_pairwise_constraints(coords)
+        # (with comm= the per-rank distance statistics are pooled exactly: every rank gets the same set)
+        constrained_inds = guess_pairwise_constraints(coords, comm=kwargs.get("comm"))
     with K.upload_cache():
         t = Trajectory(coords=coords, forces=forces)
         fused_ss = None  # sum of squares of the mapped forces when the apply kernel accumulated it

@@ -14,11 +14,14 @@ from ..util import distances
 from .hints import Constraints
 
 
-def guess_pairwise_constraints(xyz, cross_xyz: Union[None, np.ndarray] = None, threshold: float = 1e-3) -> Constraints:
+def guess_pairwise_constraints(xyz, cross_xyz: Union[None, np.ndarray] = None, threshold: float = 1e-3,
+                               comm=None) -> Constraints:
     """Pairs of sites whose distance fluctuates by less than ``threshold`` (standard deviation).
 
     Returns a set of frozensets {i, j}; with ``cross_xyz`` a set of ordered tuples (i, j) with i
-    indexing ``cross_xyz`` and j indexing ``xyz`` (as the reference).
+    indexing ``cross_xyz`` and j indexing ``xyz`` (as the reference).  ``comm`` (extra): ``xyz`` is this
+    rank's shard of a frame-sharded trajectory; the per-rank means and variances are combined exactly
+    (two all-reduces of (N, N)), so every rank gets the set the whole trajectory gives.
     """
     if cross_xyz is not None:
         x = xyz.detach().cpu().numpy() if hasattr(xyz, "detach") else np.asarray(xyz)
@@ -29,8 +32,23 @@ def guess_pairwise_constraints(xyz, cross_xyz: Union[None, np.ndarray] = None, t
     import torch
     from .. import _kernels as K
 
-    var = K.pair_dist_var(K.as_device(xyz))
-    close = torch.sqrt(var) < threshold
+    from ..distributed import all_reduce_sum_, world_size
+
+    x = K.as_device(xyz)
+    if world_size(comm) > 1:
+        # exact pooling of the per-rank (n_r, mean_r, var_r):  var = sum_r (n_r / n) (var_r + (mean_r - mean)^2)
+        mean_r, var_r = K.pair_dist_moments(x)
+        n = torch.full((1,), float(x.shape[0]), dtype=torch.float64, device=x.device)
+        all_reduce_sum_(n, comm)
+        weight = float(x.shape[0]) / float(n.item())
+        mean = K.axpby(weight, mean_r, 0.0, mean_r)
+        all_reduce_sum_(mean, comm)
+        var = K.pair_pool_term(var_r, mean_r, mean, weight)
+        all_reduce_sum_(var, comm)
+    else:
+        var = K.pair_dist_var(x)
+    close = var < float(threshold) * float(threshold)  # std < threshold
     close.fill_diagonal_(False)
     idx = torch.nonzero(torch.triu(close, diagonal=1)).cpu().numpy()
     return {frozenset((int(i), int(j))) for i, j in idx}
+

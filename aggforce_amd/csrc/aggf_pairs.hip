@@ -103,9 +103,12 @@ __global__ __launch_bounds__(256) void pair_stats_kernel(const TIn* __restrict__
 }
 
 // var[i,j] (N x N, symmetric, diagonal 0) from the slabs, fixed summation order
+// mean (optional): mean distance over the frames = d0 + shifted mean, d0 recomputed from frame 0 of X
+template <typename TIn>
 __global__ __launch_bounds__(256) void pair_var_kernel(const double* __restrict__ slabs, int32_t nt1,
                                                        int32_t ksplit, int32_t N, int64_t T,
-                                                       double* __restrict__ var) {
+                                                       double* __restrict__ var, const TIn* __restrict__ X,
+                                                       double* __restrict__ mean) {
   int tile = blockIdx.x;
   const int tile_lin = tile;
   int ti = 0;
@@ -133,6 +136,24 @@ __global__ __launch_bounds__(256) void pair_var_kernel(const double* __restrict_
     if (i == j) v = 0.0;
     var[(int64_t)i * N + j] = v;
     var[(int64_t)j * N + i] = v;
+    if (mean) {
+      const double dx = (double)X[(int64_t)j * 3 + 0] - (double)X[(int64_t)i * 3 + 0],
+                   dy = (double)X[(int64_t)j * 3 + 1] - (double)X[(int64_t)i * 3 + 1],
+                   dz = (double)X[(int64_t)j * 3 + 2] - (double)X[(int64_t)i * 3 + 2];
+      const double mu = i == j ? 0.0 : sqrt(dx * dx + dy * dy + dz * dz) + m;
+      mean[(int64_t)i * N + j] = mu;
+      mean[(int64_t)j * N + i] = mu;
+    }
+  }
+}
+
+// out = weight * (var_r + (mean_r - mean)^2): this rank's term of the pooled variance
+__global__ __launch_bounds__(256) void pair_pool_kernel(const double* __restrict__ var_r, const double* __restrict__ mean_r,
+                                                        const double* __restrict__ mean, double weight, int64_t n,
+                                                        double* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x) {
+    const double d = mean_r[e] - mean[e];
+    out[e] = weight * (var_r[e] + d * d);
   }
 }
 
@@ -161,26 +182,54 @@ extern "C" size_t aggf_pair_dist_var_workspace_bytes(int64_t T, int32_t N) {
   return (size_t)n_tiles * ksplit * 2 * PT * PT * sizeof(double) + 256;
 }
 
-extern "C" int aggf_pair_dist_var(const void* X, int64_t T, int32_t N, int dtype, double* var, void* ws,
-                                  size_t ws_bytes, void* stream_v) {
+static int pair_moments_impl(const void* X, int64_t T, int32_t N, int dtype, double* mean, double* var, void* ws,
+                             size_t ws_bytes, void* stream_v, const char* who) {
   hipStream_t stream = (hipStream_t)stream_v;
-  if (!X || !var || !ws) return fail(AGGF_ERR_ARG, "aggf_pair_dist_var: NULL pointer");
-  if (T <= 0 || N <= 0) return fail(AGGF_ERR_ARG, "aggf_pair_dist_var: empty problem");
+  if (!X || !var || !ws) return fail(AGGF_ERR_ARG, "%s: NULL pointer", who);
+  if (T <= 0 || N <= 0) return fail(AGGF_ERR_ARG, "%s: empty problem", who);
   int nt1, n_tiles, ksplit;
   int64_t fps;
   pair_plan(T, N, &nt1, &n_tiles, &ksplit, &fps);
   if (ws_bytes < (size_t)n_tiles * ksplit * 2 * PT * PT * sizeof(double))
-    return fail(AGGF_ERR_WORKSPACE, "aggf_pair_dist_var: workspace too small");
+    return fail(AGGF_ERR_WORKSPACE, "%s: workspace too small", who);
   double* slabs = reinterpret_cast<double*>(ws);
   const dim3 grid((unsigned)((int64_t)n_tiles * ksplit));
-  if (dtype == AGGF_F64)
+  if (dtype == AGGF_F64) {
     hipLaunchKernelGGL(pair_stats_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, T, N, nt1, n_tiles, fps, slabs);
-  else if (dtype == AGGF_F32)
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL(pair_var_kernel<double>, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var,
+                       (const double*)X, mean);
+  } else if (dtype == AGGF_F32) {
     hipLaunchKernelGGL(pair_stats_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, T, N, nt1, n_tiles, fps, slabs);
-  else
-    return fail(AGGF_ERR_ARG, "aggf_pair_dist_var: bad dtype");
+    AGGF_LAUNCH_OK();
+    hipLaunchKernelGGL(pair_var_kernel<float>, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var,
+                       (const float*)X, mean);
+  } else {
+    return fail(AGGF_ERR_ARG, "%s: bad dtype", who);
+  }
   AGGF_LAUNCH_OK();
-  hipLaunchKernelGGL(pair_var_kernel, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var);
+  return AGGF_OK;
+}
+
+extern "C" int aggf_pair_dist_var(const void* X, int64_t T, int32_t N, int dtype, double* var, void* ws,
+                                  size_t ws_bytes, void* stream_v) {
+  return pair_moments_impl(X, T, N, dtype, nullptr, var, ws, ws_bytes, stream_v, "aggf_pair_dist_var");
+}
+
+extern "C" int aggf_pair_dist_moments(const void* X, int64_t T, int32_t N, int dtype, double* mean, double* var,
+                                      void* ws, size_t ws_bytes, void* stream_v) {
+  if (!mean) return fail(AGGF_ERR_ARG, "aggf_pair_dist_moments: NULL pointer");
+  return pair_moments_impl(X, T, N, dtype, mean, var, ws, ws_bytes, stream_v, "aggf_pair_dist_moments");
+}
+
+extern "C" int aggf_pair_pool_term(const double* var_r, const double* mean_r, const double* mean, double weight,
+                                   int64_t n, double* out, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!var_r || !mean_r || !mean || !out) return fail(AGGF_ERR_ARG, "aggf_pair_pool_term: NULL pointer");
+  if (n <= 0) return AGGF_OK;
+  int64_t g = ceil_div(n, 256);
+  if (g > 4096) g = 4096;
+  hipLaunchKernelGGL(pair_pool_kernel, dim3((unsigned)g), dim3(256), 0, stream, var_r, mean_r, mean, weight, n, out);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

@@ -312,6 +312,17 @@ int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32_t N, int32
 size_t aggf_pair_dist_var_workspace_bytes(int64_t T, int32_t N);
 int aggf_pair_dist_var(const void* X, int64_t T, int32_t N, int dtype, double* var, void* ws,
                        size_t ws_bytes, void* stream);
+/* The same pass with the mean distance as a second output (mean, var: (N, N) float64): what a
+ * frame-sharded caller needs to combine the per-rank statistics exactly (Chan et al.):
+ *     n = sum n_r,  mean = sum n_r mean_r / n,  var = sum n_r (var_r + (mean_r - mean)^2) / n
+ * (aggforce_amd.guess_pairwise_constraints(..., comm=): two all-reduces of (N, N)).  Same workspace
+ * as aggf_pair_dist_var. */
+int aggf_pair_dist_moments(const void* X, int64_t T, int32_t N, int dtype, double* mean, double* var,
+                           void* ws, size_t ws_bytes, void* stream);
+/* out[e] = weight * (var_r[e] + (mean_r[e] - mean[e])^2) on n float64 elements: one rank's term of the
+ * pooled variance above (weight = n_r / n; out may alias var_r). */
+int aggf_pair_pool_term(const double* var_r, const double* mean_r, const double* mean, double weight,
+                        int64_t n, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Gram algebra for cross-validation.  Replaces, inside project_forces_grid_cv

@@ -261,3 +261,55 @@ def test_featurised_fit_is_replicated_across_two_ranks(tmp_path):
                              frame_indices=list(f0))
     assert rel(c0, np.stack(one.force_map.tags["coef_list"])) < 1e-6
     assert rel(g0, c0) < 2e-3
+
+
+# ------------------------------------------------------------------ constrained_inds="auto" with frames sharded over ranks
+def _auto_rank_worker(rank, world, port, out_dir):
+    import torch.distributed as dist
+    from aggforce_amd import LinearMap as LM, guess_pairwise_constraints as guess, project_forces as pf
+    from aggforce_amd.distributed import frame_shard
+
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    coords, forces = np.load(os.path.join(out_dir, "coords.npy")), np.load(os.path.join(out_dir, "forces.npy"))
+    b, e = frame_shard(coords.shape[0], rank, world)
+    cons = guess(coords[b:e], threshold=1e-3, comm=True)
+    np.save(os.path.join(out_dir, f"cons{rank}.npy"), np.array(sorted(sorted(c) for c in cons)))
+    res = pf(coords[b:e], forces[b:e], LM([[0], [40], [90]], n_fg_sites=coords.shape[1]), comm=True)  # "auto"
+    np.save(os.path.join(out_dir, f"W{rank}.npy"), res["tmap"].force_map.standard_matrix)
+    dist.destroy_process_group()
+
+
+def test_auto_constraints_with_sharded_frames(tmp_path):
+    """constrained_inds="auto" + comm=: the per-rank pair-distance statistics are pooled exactly (Chan), so every
+    rank guesses the set the whole trajectory gives -- including a pair that is rigid on each shard but sits at
+    DIFFERENT distances on the two shards (only the pooled variance sees that it moved)."""
+    import torch.multiprocessing as mp
+    from aggforce_amd import guess_pairwise_constraints, project_forces
+
+    rng = np.random.default_rng(9)
+    T, N = 301, 131
+    xyz = 10 * rng.random((1, N, 3)) + 0.3 * rng.standard_normal((T, N, 3))
+    for a, b_ in ((0, 1), (5, 70), (129, 130)):
+        xyz[:, b_, :] = xyz[:, a, :] + rng.standard_normal(3)          # rigid over the whole trajectory
+    half = T - T // 2                                                    # frame_shard(301, 0, 2) = [0, 151)
+    xyz[:half, 21, :] = xyz[:half, 20, :] + np.array([1.0, 0.0, 0.0])   # rigid on shard 0 at distance 1 ...
+    xyz[half:, 21, :] = xyz[half:, 20, :] + np.array([1.5, 0.0, 0.0])   # ... and on shard 1 at distance 1.5
+    forces = 20 * rng.standard_normal((T, N, 3))
+    np.save(tmp_path / "coords.npy", xyz)
+    np.save(tmp_path / "forces.npy", forces)
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_auto_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    whole = guess_pairwise_constraints(xyz, threshold=1e-3)
+    assert whole == {frozenset([0, 1]), frozenset([5, 70]), frozenset([129, 130])} == orc.guess_pairwise_constraints(xyz, threshold=1e-3)
+    want = np.array(sorted(sorted(c) for c in whole))
+    c0, c1 = np.load(tmp_path / "cons0.npy"), np.load(tmp_path / "cons1.npy")
+    assert np.array_equal(c0, want) and np.array_equal(c1, want)
+    # each shard alone WOULD have taken (20, 21) for a constraint
+    assert frozenset([20, 21]) in guess_pairwise_constraints(xyz[:half], threshold=1e-3)
+    one = project_forces(xyz, forces, LinearMap([[0], [40], [90]], n_fg_sites=N))
+    W0, W1 = np.load(tmp_path / "W0.npy"), np.load(tmp_path / "W1.npy")
+    assert np.array_equal(W0, W1) and rel(W0, one["tmap"].force_map.standard_matrix) < 1e-9
