@@ -279,7 +279,9 @@ __device__ unsigned long long aggf_gram_prof[4];
 #define AGGF_PROF_T(x)
 #endif
 
-template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false>
+// M32 (float, NW = 8 only): v_mfma_f32_32x32x2_f32 instead of 16x16x4 -- the same operand reads per flop (they
+// depend on the 64 x 32 wave tile only) in half as many MFMA instructions of twice the length.
+template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, bool M32 = false>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
@@ -403,6 +405,15 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   for (int m = 0; m < 4; ++m)
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[m][n] = acc_zero<T>();
+  typedef float __attribute__((ext_vector_type(16))) f32x16;
+  f32x16 acc32[2];
+#pragma unroll
+  for (int m = 0; m < 2; ++m)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc32[m][r] = 0.f;
+  // 32x32x2 operands: A[i = atom (lane & 31)][k = row (lane >> 5)], two K steps of two rows per row group
+  const int offA32 = (lane >> 5) * DmaCfg<T>::UNIT_STRIDE + 3 * (wm * 64 + (lane & 31));
+  const int offB32 = PANEL_ELEMS + (lane >> 5) * DmaCfg<T>::UNIT_STRIDE + 3 * (wn * WCOLS + (lane & 31));
 
   // MFMA operand of row group kk: rows kk*4 + (lane >> 4) -- f64: four consecutive rows; f32: member kk of
   // the four pairs
@@ -439,6 +450,25 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
+        if constexpr (M32) {
+          float a32[2][2], b32[2];  // [K step of two rows][32-atom tile]
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2) {
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a32[s2][m] = (float)pa[offA32 + kk * KKS + s2 * 2 * DmaCfg<T>::UNIT_STRIDE + 96 * m + d];
+            b32[s2] = (float)pa[offB32 + kk * KKS + s2 * 2 * DmaCfg<T>::UNIT_STRIDE + d];
+          }
+          if (SPREAD && issue_now) {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q)
+              if (q * GROUPS / PPW == kk * 3 + d) issue_piece(it + AHEAD, q);
+          }
+#pragma unroll
+          for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+              acc32[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a32[s2][m], b32[s2], acc32[m], 0, 0, 0);
+        } else {
         T a[4], bb[NACC];
 #pragma unroll
         for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * KKS + 48 * m + d];
@@ -455,6 +485,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
         for (int m = 0; m < 4; ++m)
 #pragma unroll
           for (int n = 0; n < NACC; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+        }
       }
     }
     AGGF_PROF_T(p2);
@@ -484,6 +515,18 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
 #endif
 
   T* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
+  if constexpr (M32) {
+    // D of v_mfma_f32_32x32x2_f32: lane holds column (lane & 31), rows 8 (r / 4) + 4 (lane >> 5) + r % 4
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 64 + m * 32 + 8 * (r / 4) + 4 * (lane >> 5) + (r % 4);
+        const int col = wn * WCOLS + (lane & 31);
+        slab[row * TILE + col] = (T)acc32[m][r];
+      }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -1386,6 +1429,25 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
     hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, p.first_tile);
     AGGF_LAUNCH_OK();
     const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
+    static const char* f32_mfma = getenv("AGGF_GRAM_F32_MFMA");  // "32": v_mfma_f32_32x32x2_f32 (measurement)
+    if constexpr (sizeof(T) == 4) {
+      if (f32_mfma && f32_mfma[0] == '3') {
+        static thread_local PerDeviceOnce once32;
+        bool& done32 = *once32.flag();
+        if (!done32) {
+          AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, true>,
+                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+          done32 = true;
+        }
+        hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, true>), dim3((unsigned)round_up(nblk, 512)),
+                           dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
+        AGGF_LAUNCH_OK();
+        hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
+                           slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
+        AGGF_LAUNCH_OK();
+        return AGGF_OK;
+      }
+    }
     hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
                        lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
     AGGF_LAUNCH_OK();
