@@ -539,7 +539,12 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
       (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) >= 16 && (((uintptr_t)P & 15) == 0) && T >= 64)
     return apply_small_launch<TIn, TC>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   // (32 frames x 128 sites with 8 waves -- two independent workgroups per CU -- measured the same 103 ms)
-  const int tile = force ? (force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
+  const int tile = force ? (force[0] == 'a' ? 3 : force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
+  // "all": one workgroup over 256 sites, so that P is read once for n_cg <= 256.  Measured at C3:
+  // see DESIGN section 8 -- 96 accumulator registers + staging at 4 waves per SIMD.
+  if (tile == 3)
+    return apply_launch<TIn, TC, 1024, 256>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
+                                            ws_bytes, stream);
   if (tile == 2)
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);
