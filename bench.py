@@ -67,7 +67,9 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     p.add_argument("--frames", type=int, default=None, help="override the total frame count")
-    p.add_argument("--cpu-frames", type=int, default=2000, help="frame sample of the CPU baseline")
+    p.add_argument("--cpu-frames", type=int, default=20000,
+                   help="frame sample of the CPU baseline (c3: ~20 s of host work: 2 GB of forces, two 2e12-flop matmuls, "
+                        "the single-threaded einsum apply)")
     p.add_argument("--no-cpu-baseline", action="store_true")
     p.add_argument("--dry-run", action="store_true",
                    help="launcher self-test on CPU (gloo, no GPU, no product compute): NOT a measurement")
