@@ -331,23 +331,37 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
     const int64_t t0 = stage_t0(s);
     const int64_t valid = (T - t0 < AS_KB ? T - t0 : AS_KB) * row_in * (int64_t)sizeof(TIn);
     const char* src = reinterpret_cast<const char*>(P + t0 * row_in);
+    if (valid >= (int64_t)n_vec * 16) {
+      // every frame of the stage exists (all stages but the last of the trajectory): straight-line loads.  With the
+      // ragged-end handling in the same loop the compiler put an s_waitcnt vmcnt(0) after EVERY load (the paths
+      // join in a phi): the loads of a stage went out one memory latency apart (tools/small_probe.hip: 6500 of
+      // 13600 cycles per stage were spent "issuing" five loads)
 #pragma unroll
-    for (int i = 0; i < AS_NV; ++i) {
-      const int v = tid + AS_THREADS * i;
-      v16_t x = {0.f, 0.f, 0.f, 0.f};
-      if (v < n_vec) {
-        const int64_t off = (int64_t)v * 16;
-        if (off + 16 <= valid) {
-          x = *reinterpret_cast<const v16_t*>(src + off);
-        } else if (off < valid) {
-          TIn tmp[16 / sizeof(TIn)];
-#pragma unroll
-          for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
-            tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
-          x = *reinterpret_cast<v16_t*>(tmp);
-        }
+      for (int i = 0; i < AS_NV; ++i) {
+        const int v = tid + AS_THREADS * i;
+        v16_t x = {0.f, 0.f, 0.f, 0.f};
+        if (v < n_vec) x = *reinterpret_cast<const v16_t*>(src + (int64_t)v * 16);
+        hold[i] = x;
       }
-      hold[i] = x;
+    } else {
+#pragma unroll
+      for (int i = 0; i < AS_NV; ++i) {
+        const int v = tid + AS_THREADS * i;
+        v16_t x = {0.f, 0.f, 0.f, 0.f};
+        if (v < n_vec) {
+          const int64_t off = (int64_t)v * 16;
+          if (off + 16 <= valid) {
+            x = *reinterpret_cast<const v16_t*>(src + off);
+          } else if (off < valid) {  // the ragged end of the trajectory: element by element
+            TIn tmp[16 / sizeof(TIn)];
+#pragma unroll
+            for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
+              tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
+            x = *reinterpret_cast<v16_t*>(tmp);
+          }
+        }
+        hold[i] = x;
+      }
     }
   };
   auto park = [&]() {

@@ -271,6 +271,14 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "unsupported vmcnt");
 }
 
+#ifdef AGGF_SMALL_PROF
+// tools/small_probe.hip: shader cycles per wave of the small-system kernel spent in park (incl. the wait for the
+// fetched frames) / group sums / MFMA / the three barriers, and the stage count
+__device__ unsigned long long aggf_small_prof[9];
+#define AGGF_SP_T(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define AGGF_SP_T(x)
+#endif
 #ifdef AGGF_GRAM_PROF
 // tools/clock_probe.hip: shader cycles per wave spent issuing DMAs / in ds_read+MFMA / in waitcnt+barrier
 __device__ unsigned long long aggf_gram_prof[4];
@@ -937,23 +945,37 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     const int64_t t0 = stage_t0(s);
     const int64_t valid = (t_end - t0 < KBS ? t_end - t0 : KBS) * row_in * (int64_t)sizeof(TIn);  // bytes
     const char* src = reinterpret_cast<const char*>(F + t0 * row_in);
+    if (valid >= (int64_t)n_vec * 16) {
+      // every frame of the stage exists (all stages but the last of the trajectory): straight-line loads.  With the
+      // ragged-end handling in the same loop the compiler put an s_waitcnt vmcnt(0) after EVERY load (the paths
+      // join in a phi): the loads of a stage went out one memory latency apart (tools/small_probe.hip: 6500 of
+      // 13600 cycles per stage were spent "issuing" five loads)
 #pragma unroll
-    for (int i = 0; i < NV; ++i) {
-      const int v = tid + SM_THREADS * i;
-      v16_t x = {0.f, 0.f, 0.f, 0.f};
-      if (v < n_vec) {
-        const int64_t off = (int64_t)v * 16;
-        if (off + 16 <= valid) {
-          x = *reinterpret_cast<const v16_t*>(src + off);
-        } else if (off < valid) {  // the ragged end of the trajectory: element by element
-          TIn tmp[16 / sizeof(TIn)];
-#pragma unroll
-          for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
-            tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
-          x = *reinterpret_cast<v16_t*>(tmp);
-        }
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + SM_THREADS * i;
+        v16_t x = {0.f, 0.f, 0.f, 0.f};
+        if (v < n_vec) x = *reinterpret_cast<const v16_t*>(src + (int64_t)v * 16);
+        hold[i] = x;
       }
-      hold[i] = x;
+    } else {
+#pragma unroll
+      for (int i = 0; i < NV; ++i) {
+        const int v = tid + SM_THREADS * i;
+        v16_t x = {0.f, 0.f, 0.f, 0.f};
+        if (v < n_vec) {
+          const int64_t off = (int64_t)v * 16;
+          if (off + 16 <= valid) {
+            x = *reinterpret_cast<const v16_t*>(src + off);
+          } else if (off < valid) {  // the ragged end of the trajectory: element by element
+            TIn tmp[16 / sizeof(TIn)];
+#pragma unroll
+            for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
+              tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
+            x = *reinterpret_cast<v16_t*>(tmp);
+          }
+        }
+        hold[i] = x;
+      }
     }
   };
   auto park = [&]() {
@@ -965,21 +987,38 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   };
   // raw frames -> MFMA panel: group sums in the compute dtype (frames past t_end were fetched as zeros)
   auto reduce_groups = [&]() {
+    // all entries' table reads first, then all raw reads, then the sums: six independent LDS chains in flight at
+    // once (with the rare-large-group loop inside the per-entry body the chains ran one after the other)
+    TC sum[SM_ENT];
+    uint2 mem[SM_ENT];
 #pragma unroll
     for (int i = 0; i < SM_ENT; ++i) {
       const int e = tid + SM_THREADS * i;  // (frame in stage, reduced column, xyz); padding columns sum nothing
-      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
-      const int base = r * (int)row_in;
-      const uint2 m = *reinterpret_cast<const uint2*>(memb_s + c * 4);
-      const int o0 = m.x & 0xFFFF, o1 = m.x >> 16, o2 = m.y & 0xFFFF, o3 = m.y >> 16;
+      mem[i] = *reinterpret_cast<const uint2*>(memb_s + (e % ROW_ELEMS) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < SM_ENT; ++i) {
+      const int e = tid + SM_THREADS * i;
+      const int base = (e / ROW_ELEMS) * (int)row_in;
+      const int o0 = mem[i].x & 0xFFFF, o1 = mem[i].x >> 16, o2 = mem[i].y & 0xFFFF, o3 = mem[i].y >> 16;
       const TC v0 = (TC)raw[o0 == 0xFFFF ? zero_idx : base + o0], v1 = (TC)raw[o1 == 0xFFFF ? zero_idx : base + o1],
                v2 = (TC)raw[o2 == 0xFFFF ? zero_idx : base + o2], v3 = (TC)raw[o3 == 0xFFFF ? zero_idx : base + o3];
-      TC acc = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
-      if (big_groups) {
+      sum[i] = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
+    }
+    if (big_groups) {
+#pragma unroll
+      for (int i = 0; i < SM_ENT; ++i) {
+        const int e = tid + SM_THREADS * i;
+        const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
         const int g = c / 3, d = c - 3 * g;
-        for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) acc += (TC)raw[base + 3 * atoms_s[j] + d];
+        for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) sum[i] += (TC)raw[r * (int)row_in + 3 * atoms_s[j] + d];
       }
-      panel[r * ROW_STRIDE + c] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < SM_ENT; ++i) {
+      const int e = tid + SM_THREADS * i;
+      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
+      panel[r * ROW_STRIDE + c] = sum[i];
     }
   };
 
@@ -1002,14 +1041,32 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   for (int k = 0; k < SM_MAXBLK; ++k) acc[k] = acc_zero<TC>();
   const int off = (lane >> 4) * ROW_STRIDE + 3 * (lane & 15);
 
+  // De-phase the workgroups that share a CU: they do identical work, so two that start together stay in lock-step
+  // and sit in the same phase (fetch wait / LDS group sums / MFMA) at the same time -- the three phases then add up
+  // instead of overlapping (measured: HBM 2.1 + LDS 2.2 + MFMA 2.2 ms against 6.2 ms total).  A pseudo-random start
+  // delay of up to ~one stage, as in the tile kernel.
+  {
+    const unsigned h = ((unsigned)blockIdx.x * 2654435761u) >> 25;  // 0..127
+    for (unsigned i = 0; i < h; ++i) __builtin_amdgcn_s_sleep(1);   // 64 clocks each
+  }
+#ifdef AGGF_SMALL_PROF
+  uint64_t pf[7] = {0, 0, 0, 0, 0, 0, 0};
+#endif
   if (n_it > 0) fetch(0);
   for (int s = 0; s < n_it; ++s) {
+    AGGF_SP_T(q0);
     __syncthreads();       // the MFMAs of stage s-1 are done with the panel, its group sums with `raw`
+    AGGF_SP_T(q1);
     park();
+    AGGF_SP_T(q2);
     __syncthreads();
+    AGGF_SP_T(q3);
     if (s + 1 < n_it) fetch(s + 1);
+    AGGF_SP_T(q3b);
     reduce_groups();
+    AGGF_SP_T(q4);
     __syncthreads();
+    AGGF_SP_T(q5);
 #pragma unroll
     for (int kk = 0; kk < KBS / 4; ++kk)
 #pragma unroll
@@ -1017,12 +1074,31 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 #pragma unroll
         for (int k = 0; k < SM_MAXBLK; ++k)
           if (b_i[k] >= 0) {
-            // (reading all operands of a group before its MFMAs needs 20 more VGPRs here: spills, 5.8 -> 9.0 ms)
+            // (one LDS round trip per MFMA.  Tried: all operands of a group read first -- 20 more VGPRs, spills,
+            // 5.8 -> 9.0 ms; one item ahead -- 10 spills, 6.5 ms; a compile-time block count with straight-line code --
+            // the scheduler hoists every read: 79-108 spilled VGPRs.  The staged frames take the registers.)
             const TC a = panel[off + kk * 4 * ROW_STRIDE + 48 * b_i[k] + d];
             const TC b = panel[off + kk * 4 * ROW_STRIDE + 48 * b_j[k] + d];
             acc[k] = M::mma(a, b, acc[k]);
           }
+#ifdef AGGF_SMALL_PROF
+    const uint64_t q6 = __builtin_readcyclecounter();
+    pf[0] += q1 - q0;  // barrier 1
+    pf[1] += q2 - q1;  // park (waits for the global loads)
+    pf[2] += q3 - q2;  // barrier 2
+    pf[3] += q4 - q3b;  // group sums
+    pf[6] += q3b - q3;  // fetch issue
+    pf[4] += q5 - q4;  // barrier 3
+    pf[5] += q6 - q5;  // MFMA phase
+#endif
   }
+#ifdef AGGF_SMALL_PROF
+  if (lane == 0) {
+    for (int i = 0; i < 7; ++i) atomicAdd(&aggf_small_prof[i], (unsigned long long)pf[i]);
+    atomicAdd(&aggf_small_prof[7], (unsigned long long)n_it);
+    atomicAdd(&aggf_small_prof[8], 1ull);
+  }
+#endif
   TC* slab = slabs + (int64_t)blockIdx.x * (TILE * TILE);
 #pragma unroll
   for (int k = 0; k < SM_MAXBLK; ++k)
@@ -1044,8 +1120,13 @@ constexpr int SD_ENT = SD_KB * ROW_ELEMS / SD_THREADS;  // 3
 constexpr int SD_MAXBLK = (36 + SD_NW - 1) / SD_NW;     // 5
 constexpr int SD_MAXPPW = 8;                            // DMA pieces per wave and stage (64 KB per stage)
 
-// ABL (ablation, AGGF_SMALL_ABL; measurements only): 1 = no MFMAs, 2 = no group sums, 3 = no DMAs
-template <typename TIn, typename TC, int ABL = 0>
+// ABL (ablation, AGGF_SMALL_ABL; measurements only): 1 = no MFMAs, 2 = no group sums, 3 = no DMAs.
+// NBW = 16x16 blocks per wave, a compile-time count: the upper-triangle blocks are dealt round-robin and a wave
+// that gets one block fewer multiplies a spare copy of block (0,0) that is never stored.  With a run-time count
+// every MFMA sat behind its own wave-uniform branch, its two operand reads and an s_waitcnt lgkmcnt(0) -- a chain
+// of LDS round trips (PMC: MFMA pipes busy 44 %); with straight-line code the reads of a group are in flight
+// together and the next group's are hoisted above the MFMAs.
+template <typename TIn, typename TC, int ABL = 0, int NBW = SD_MAXBLK>
 __global__ __launch_bounds__(SD_THREADS, 4) void gram_small_dma_kernel(
     const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
     const int32_t* __restrict__ grp_atoms, int32_t n_red, int64_t frames_per_split, int32_t raw_bytes,
@@ -1129,43 +1210,72 @@ __global__ __launch_bounds__(SD_THREADS, 4) void gram_small_dma_kernel(
     }
   };
   auto reduce_groups = [&](const TIn* raw) {
+    // table reads of all entries, then all raw reads, then the sums: independent LDS chains in flight together
+    TC sum[SD_ENT];
+    uint2 mem[SD_ENT];
+#pragma unroll
+    for (int i = 0; i < SD_ENT; ++i) mem[i] = *reinterpret_cast<const uint2*>(memb_s + ((tid + SD_THREADS * i) % ROW_ELEMS) * 4);
 #pragma unroll
     for (int i = 0; i < SD_ENT; ++i) {
       const int e = tid + SD_THREADS * i;  // (frame in stage, reduced column, xyz); padding columns sum nothing
-      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
-      const TIn* fr = raw + r * (int)row_in;
-      const uint2 m = *reinterpret_cast<const uint2*>(memb_s + c * 4);
-      const int o0 = m.x & 0xFFFF, o1 = m.x >> 16, o2 = m.y & 0xFFFF, o3 = m.y >> 16;
+      const TIn* fr = raw + (e / ROW_ELEMS) * (int)row_in;
+      const int o0 = mem[i].x & 0xFFFF, o1 = mem[i].x >> 16, o2 = mem[i].y & 0xFFFF, o3 = mem[i].y >> 16;
       const TC v0 = (TC) * (o0 == 0xFFFF ? zero_s : fr + o0), v1 = (TC) * (o1 == 0xFFFF ? zero_s : fr + o1),
                v2 = (TC) * (o2 == 0xFFFF ? zero_s : fr + o2), v3 = (TC) * (o3 == 0xFFFF ? zero_s : fr + o3);
-      TC acc = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
-      if (big_groups) {
+      sum[i] = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
+    }
+    if (big_groups) {
+#pragma unroll
+      for (int i = 0; i < SD_ENT; ++i) {
+        const int e = tid + SD_THREADS * i;
+        const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
         const int g = c / 3, d = c - 3 * g;
-        for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) acc += (TC)fr[3 * atoms_s[j] + d];
+        for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) sum[i] += (TC)raw[r * (int)row_in + 3 * atoms_s[j] + d];
       }
-      panel[r * ROW_STRIDE + c] = acc;
+    }
+#pragma unroll
+    for (int i = 0; i < SD_ENT; ++i) {
+      const int e = tid + SD_THREADS * i;
+      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
+      panel[r * ROW_STRIDE + c] = sum[i];
     }
   };
 
   const int nb = (n_red + 15) / 16;
-  int b_i[SD_MAXBLK], b_j[SD_MAXBLK];
+  int b_i[NBW], b_j[NBW];
+  bool b_live[NBW];
 #pragma unroll
-  for (int k = 0; k < SD_MAXBLK; ++k) {
+  for (int k = 0; k < NBW; ++k) {
     int q = wave + SD_NW * k, bi = 0, rowlen = nb;
     while (bi < nb && q >= rowlen) {
       q -= rowlen;
       --rowlen;
       ++bi;
     }
-    b_i[k] = bi < nb ? bi : -1;
-    b_j[k] = bi + q;
+    b_live[k] = bi < nb;
+    b_i[k] = b_live[k] ? bi : 0;
+    b_j[k] = b_live[k] ? bi + q : 0;
   }
-  acc_t acc[SD_MAXBLK];
+  acc_t acc[NBW];
 #pragma unroll
-  for (int k = 0; k < SD_MAXBLK; ++k) acc[k] = acc_zero<TC>();
+  for (int k = 0; k < NBW; ++k) acc[k] = acc_zero<TC>();
   const int off = (lane >> 4) * ROW_STRIDE + 3 * (lane & 15);
+  int addr_a[NBW], addr_b[NBW];
+#pragma unroll
+  for (int k = 0; k < NBW; ++k) {
+    addr_a[k] = off + 48 * b_i[k];
+    addr_b[k] = off + 48 * b_j[k];
+  }
 
   __syncthreads();  // tables complete
+  // De-phase the workgroups that share a CU: they do identical work, so two that start together stay in lock-step
+  // and sit in the same phase (fetch wait / LDS group sums / MFMA) at the same time -- the three phases then add up
+  // instead of overlapping (measured: HBM 2.1 + LDS 2.2 + MFMA 2.2 ms against 6.2 ms total).  A pseudo-random start
+  // delay of up to ~one stage, as in the tile kernel.
+  {
+    const unsigned h = ((unsigned)blockIdx.x * 2654435761u) >> 25;  // 0..127
+    for (unsigned i = 0; i < h; ++i) __builtin_amdgcn_s_sleep(1);   // 64 clocks each
+  }
   if (n_it > 0) issue_stage(0);
   if (n_it > 1) issue_stage(1);
   wait_older(n_it > 1 && !(ragged && n_it == 2));  // stage 0 has landed (this wave's pieces)
@@ -1176,18 +1286,18 @@ __global__ __launch_bounds__(SD_THREADS, 4) void gram_small_dma_kernel(
     __syncthreads();  // panel complete; slot (it + 2) % 3 was last read in iteration it - 1
     const bool more = it + 2 < n_it;
     if (more) issue_stage(it + 2);
+    if (ABL != 1) {
 #pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      TC av[SD_MAXBLK], bv[SD_MAXBLK];  // all operand reads of the group in flight together, then its MFMAs
+      for (int d = 0; d < 3; ++d) {
+        TC av[NBW], bv[NBW];
 #pragma unroll
-      for (int k = 0; k < SD_MAXBLK; ++k)
-        if (ABL != 1 && b_i[k] >= 0) {
-          av[k] = panel[off + 48 * b_i[k] + d];
-          bv[k] = panel[off + 48 * b_j[k] + d];
+        for (int k = 0; k < NBW; ++k) {
+          av[k] = panel[addr_a[k] + d];
+          bv[k] = panel[addr_b[k] + d];
         }
 #pragma unroll
-      for (int k = 0; k < SD_MAXBLK; ++k)
-        if (ABL != 1 && b_i[k] >= 0) acc[k] = M::mma(av[k], bv[k], acc[k]);
+        for (int k = 0; k < NBW; ++k) acc[k] = M::mma(av[k], bv[k], acc[k]);
+      }
     }
     // stage it + 1 must have landed; stage it + 2 may stay in flight (unless it is the ragged one: its DMA
     // count is not the usual one)
@@ -1197,8 +1307,8 @@ __global__ __launch_bounds__(SD_THREADS, 4) void gram_small_dma_kernel(
   }
   TC* slab = slabs + (int64_t)blockIdx.x * (TILE * TILE);
 #pragma unroll
-  for (int k = 0; k < SD_MAXBLK; ++k)
-    if (b_i[k] >= 0) {
+  for (int k = 0; k < NBW; ++k)
+    if (b_live[k]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) slab[(b_i[k] * 16 + M::row(lane, r)) * TILE + b_j[k] * 16 + (lane & 15)] = acc[k][r];
     }
@@ -1504,21 +1614,24 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     }
     static const char* abl_env = getenv("AGGF_SMALL_ABL");
     const int abl = abl_env ? atoi(abl_env) : 0;
-#define AGGF_SD(A)                                                                                                  \
+    const int nbk = (n_red + 15) / 16;
+    const int nbw = (nbk * (nbk + 1) / 2 + SD_NW - 1) / SD_NW;  // blocks per wave: 1 .. 5
+#define AGGF_SD(A, W)                                                                                               \
   do {                                                                                                               \
-    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_dma_kernel<TIn, TC, A>,                                  \
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_dma_kernel<TIn, TC, A, W>,                               \
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));                 \
-    hipLaunchKernelGGL((gram_small_dma_kernel<TIn, TC, A>), dim3((unsigned)p.ksplit), dim3(SD_THREADS), lds, stream, \
-                       reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red, p.frames_per_split,        \
-                       (int32_t)raw_bytes, slabs);                                                                   \
+    hipLaunchKernelGGL((gram_small_dma_kernel<TIn, TC, A, W>), dim3((unsigned)p.ksplit), dim3(SD_THREADS), lds,      \
+                       stream, reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red,                    \
+                       p.frames_per_split, (int32_t)raw_bytes, slabs);                                               \
   } while (0)
-    if (abl == 1) AGGF_SD(1);
-    else if (abl == 2) AGGF_SD(2);
-    else if (abl == 3) AGGF_SD(3);
-    else
-      hipLaunchKernelGGL((gram_small_dma_kernel<TIn, TC>), dim3((unsigned)p.ksplit), dim3(SD_THREADS), lds, stream,
-                         reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red, p.frames_per_split,
-                         (int32_t)raw_bytes, slabs);
+    if (abl == 1) AGGF_SD(1, 5);
+    else if (abl == 2) AGGF_SD(2, 5);
+    else if (abl == 3) AGGF_SD(3, 5);
+    else if (nbw <= 1) AGGF_SD(0, 1);
+    else if (nbw == 2) AGGF_SD(0, 2);
+    else if (nbw == 3) AGGF_SD(0, 3);
+    else if (nbw == 4) AGGF_SD(0, 4);
+    else AGGF_SD(0, 5);
 #undef AGGF_SD
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_reduce_small_kernel<TC>), dim3(TILE), dim3(256), 0, stream, slabs, p.ksplit, n_red,
