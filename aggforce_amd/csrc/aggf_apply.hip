@@ -80,6 +80,39 @@ __global__ __launch_bounds__(AP_THREADS, (AP_THREADS >= 1024 || AP_WF < 4) ? 4 :
   auto load_stage = [&](int s, auto set_c) {
     constexpr int SET = decltype(set_c)::value;
     const int a0 = s * AP_KA;
+    // Whole stage inside the rows and both operands 16-byte aligned (every stage but a ragged last one): straight-line
+    // vector loads.  With the element-wise tail handling inside the same loop body the compiler put an
+    // s_waitcnt vmcnt(0) after EVERY 16-byte load (the two paths join in a phi), so the loads that were meant to run
+    // two stages ahead each waited out a full memory latency right where they were issued.
+    if (p_vec_ok && m_vec_ok && a0 + AP_KA <= N) {
+#pragma unroll
+      for (int q = 0; q < P_PER_THREAD; ++q) {
+        const int c = tid + q * AP_THREADS;
+        const int r = c / P_CH_ROW, col = (c - r * P_CH_ROW) * VI;  // col in [0,48)
+        const int64_t t = t0 + r;
+        typedef TIn __attribute__((ext_vector_type(VI))) vin_t;
+        vin_t v;
+#pragma unroll
+        for (int e = 0; e < VI; ++e) v[e] = 0;
+        if (c < P_CH && t < T) v = *reinterpret_cast<const vin_t*>(P + t * rowP + (int64_t)a0 * 3 + col);
+#pragma unroll
+        for (int e = 0; e < VI; ++e) rp[SET][q][e] = v[e];
+      }
+#pragma unroll
+      for (int q = 0; q < M_PER_THREAD; ++q) {
+        const int c = tid + q * AP_THREADS;
+        const int r = c / M_CH_ROW, col = (c - r * M_CH_ROW) * VM;
+        const int cg = c0 + r;
+        typedef TC __attribute__((ext_vector_type(VM))) vm_t;
+        vm_t v;
+#pragma unroll
+        for (int e = 0; e < VM; ++e) v[e] = 0;
+        if (c < M_CH && cg < n_cg) v = *reinterpret_cast<const vm_t*>(Mx + (int64_t)cg * N + a0 + col);
+#pragma unroll
+        for (int e = 0; e < VM; ++e) rm[SET][q][e] = v[e];
+      }
+      return;
+    }
 #pragma unroll
     for (int q = 0; q < P_PER_THREAD; ++q) {
       const int c = tid + q * AP_THREADS;
