@@ -214,6 +214,151 @@ __global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ Akk
   }
 }
 
+// The same factorisation and inverse, blocked 16 x 16 inside the 64 x 64 block and spread over 4 waves (default;
+// AGGF_POTRF=wave selects the one-wave kernel above): 35.5 against 40.3 us per block (rocprofv3, n = 1024).  A 16 x 16
+// diagonal sub-block is factored AND inverted inside 16 lanes (v_readlane broadcasts), the panel below it is a
+// product with that inverse (independent entries; a row-wise triangular solve is a chain of 136 FMAs), the trailing
+// update is one (i, j) entry per thread, and the rest of the inverse comes from three levels of 16 x 16 block
+// products.  In-kernel cycle counts of one block: load 6.2 k, the four diagonal sub-blocks 45.7 k (the 16-lane serial
+// part: ~40 cycles per readlane + FMA pair), panels 5.7 k, trailing updates 14.5 k, inverse levels 12.7 k, stores
+// 4.5 k -- the next step would be the diagonal sub-blocks on all 64 lanes of the wave through an LDS column buffer.
+constexpr int PB = 16;
+constexpr int POTRF_LDS = 2 * NB * (NB + 1) * (int)sizeof(double);
+__global__ __launch_bounds__(256) void potrf_diag_blocked_kernel(double* __restrict__ Akk, int64_t lda,
+                                                                double* __restrict__ Linv,
+                                                                double* __restrict__ info, int pivot_base,
+                                                                int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
+  extern __shared__ __attribute__((aligned(16))) char potrf_smem[];
+  double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem);                       // A, then L (lower)
+  double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem) + NB;                  // L^-1
+  const int tid = threadIdx.x;
+  Akk += blockIdx.x * a_ps;  // blockIdx.x = problem of a batched solve
+  Linv += blockIdx.x * linv_ps;
+  info += blockIdx.x * info_ps;
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    a[r][c] = (c <= r) ? Akk[(int64_t)r * lda + c] : 0.0;
+    x[r][c] = 0.0;
+  }
+  __syncthreads();
+  for (int kb = 0; kb < NB / PB; ++kb) {
+    const int k0 = kb * PB;
+    // 1. diagonal sub-block and its inverse: lanes 0..15 of wave 0, the 16 columns in registers
+    if (tid < PB) {
+      double r[PB];  // row tid of the sub-block
+#pragma unroll
+      for (int c = 0; c < PB; ++c) r[c] = a[k0 + tid][k0 + c];
+      double rinv = 0.0;  // lane j keeps 1 / L[j][j]
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        double d = lane_bcast(r[j], j);
+        if (!(d > 0.0)) {
+          if (tid == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + k0 + j + 1);
+          d = 1.0;
+        }
+        // 1/sqrt(d): hardware estimate + two Newton steps
+        double rs = __builtin_amdgcn_rsq(d);
+        double e = fma(-d * rs, rs, 1.0);
+        rs = fma(rs * e, fma(e, 0.375, 0.5), rs);
+        e = fma(-d * rs, rs, 1.0);
+        rs = fma(rs * 0.5, e, rs);
+        r[j] = (tid == j) ? d * rs : r[j] * rs;  // column j of L (rows above the diagonal: unused values)
+        if (tid == j) rinv = rs;
+#pragma unroll
+        for (int k = j + 1; k < PB; ++k) r[k] = fma(-r[j], lane_bcast(r[j], k), r[k]);  // only rows i >= k are ever read
+      }
+#pragma unroll
+      for (int c = 0; c < PB; ++c) a[k0 + tid][k0 + c] = (c <= tid) ? r[c] : 0.0;
+      // inverse, lane = column c: right-looking forward substitution, L[i][k] broadcast from the lane that holds row i
+      double sv[PB];
+#pragma unroll
+      for (int i = 0; i < PB; ++i) sv[i] = (i == tid) ? 1.0 : 0.0;
+#pragma unroll
+      for (int k = 0; k < PB; ++k) {
+        const double xk = sv[k] * lane_bcast(rinv, k);
+        x[k0 + k][k0 + tid] = xk;
+#pragma unroll
+        for (int i = k + 1; i < PB; ++i) sv[i] = fma(-lane_bcast(r[k], i), xk, sv[i]);
+      }
+    }
+    __syncthreads();
+    const int nt = NB - k0 - PB;  // rows below the sub-block
+    // 2. panel below: P = A_panel inv(L_kk)', P[i][j] = sum_{m <= j} A[i][m] X[j][m]: independent entries (the
+    //    row-wise triangular solve is a chain of 136 FMAs with an LDS read in front of each)
+    {
+      double pv[3];
+      int np = 0;
+      for (int e = tid; e < nt * PB; e += 256) {
+        const int ii = e / PB, j = e - ii * PB, i = k0 + PB + ii;
+        double sacc = 0.0;
+#pragma unroll
+        for (int m = 0; m < PB; ++m) sacc = fma(a[i][k0 + m], x[k0 + j][k0 + m], sacc);  // X is lower: zeros for m > j
+        pv[np++] = sacc;
+      }
+      __syncthreads();
+      np = 0;
+      for (int e = tid; e < nt * PB; e += 256) {
+        const int ii = e / PB, j = e - ii * PB;
+        a[k0 + PB + ii][k0 + j] = pv[np++];
+      }
+    }
+    __syncthreads();
+    // 3. trailing block -= P P' (lower part), one entry per thread and pass
+    for (int e = tid; e < nt * nt; e += 256) {
+      const int ii = e / nt, jj = e - ii * nt;
+      if (jj <= ii) {
+        const int i = k0 + PB + ii, j = k0 + PB + jj;
+        double sacc = a[i][j];
+#pragma unroll
+        for (int m = 0; m < PB; ++m) sacc = fma(-a[i][k0 + m], a[j][k0 + m], sacc);
+        a[i][j] = sacc;
+      }
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    if (c <= r) Akk[(int64_t)r * lda + c] = a[r][c];
+  }
+  // sub-blocks of the inverse below the diagonal, by distance d from it:
+  //   X(bi,bj) = -X(bi,bi) * sum_{k = bj}^{bi-1} L(bi,k) X(k,bj)
+  for (int d = 1; d < NB / PB; ++d) {
+    const int nblk = NB / PB - d;
+    // (a) W = sum_k L(bi,k) X(k,bj), parked in X(bi,bj)
+    for (int e = tid; e < nblk * PB * PB; e += 256) {
+      const int bj = e / (PB * PB), rc = e - bj * PB * PB, r = rc / PB, c = rc - r * PB, bi = bj + d;
+      double w = 0.0;
+      for (int kb = bj; kb < bi; ++kb) {
+#pragma unroll
+        for (int m = 0; m < PB; ++m) w = fma(a[bi * PB + r][kb * PB + m], x[kb * PB + m][bj * PB + c], w);
+      }
+      x[bi * PB + r][bj * PB + c] = w;
+    }
+    __syncthreads();
+    // (b) X(bi,bj) = -X(bi,bi) W: read the column of W, barrier, write in place
+    double out[3];
+    int n_out = 0;
+    for (int e = tid; e < nblk * PB * PB; e += 256) {
+      const int bj = e / (PB * PB), rc = e - bj * PB * PB, r = rc / PB, c = rc - r * PB, bi = bj + d;
+      double w = 0.0;
+#pragma unroll
+      for (int m = 0; m < PB; ++m) w = fma(-x[bi * PB + r][bi * PB + m], x[bi * PB + m][bj * PB + c], w);  // X(bi,bi) lower
+      out[n_out++] = w;
+    }
+    __syncthreads();
+    n_out = 0;
+    for (int e = tid; e < nblk * PB * PB; e += 256) {
+      const int bj = e / (PB * PB), rc = e - bj * PB * PB, r = rc / PB, c = rc - r * PB, bi = bj + d;
+      x[bi * PB + r][bj * PB + c] = out[n_out++];
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    Linv[r * NB + c] = x[r][c];
+  }
+}
+
 // Helper kernels of the solve.  blockIdx.y = problem of a batched solve; every array argument comes
 // with its per-problem stride (`*_ps`, elements).
 
@@ -470,8 +615,22 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
     for (int k = k0; k < kend && !c.rc; ++k) {
       const Mat Akk = P.at((int64_t)k * NB, (int64_t)k * NB);
       const Mat Dk{Dinv.p + (int64_t)k * NB * NB, NB, Dinv.ps};
-      hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.nprob), dim3(64), 0, c.stream, Akk.p, (int64_t)npad, Dk.p,
-                         info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
+      static const char* potrf_env = getenv("AGGF_POTRF");
+      if (potrf_env && potrf_env[0] == 'w') {
+        hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.nprob), dim3(64), 0, c.stream, Akk.p, (int64_t)npad, Dk.p,
+                           info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
+      } else {
+        static thread_local PerDeviceOnce attr_once;
+        bool& attr_done = *attr_once.flag();
+        if (!attr_done) {
+          if (hipFuncSetAttribute((const void*)potrf_diag_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  POTRF_LDS) != hipSuccess)
+            c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
+          attr_done = true;
+        }
+        hipLaunchKernelGGL(potrf_diag_blocked_kernel, dim3(c.nprob), dim3(256), POTRF_LDS, c.stream, Akk.p,
+                           (int64_t)npad, Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
+      }
       if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
       const int rem = npad - (k + 1) * NB;
       if (rem <= 0) break;
