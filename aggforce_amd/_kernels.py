@@ -380,6 +380,28 @@ def sumsq(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def sym_pack_upper(G: torch.Tensor) -> torch.Tensor:
+    """Packed upper triangles (batch, n (n + 1) / 2) of symmetric float64 matrices G (..., n, n)."""
+    l = lib()
+    n = G.shape[-1]
+    assert G.dtype == torch.float64 and G.shape[-2] == n and G.is_contiguous()
+    batch = G.numel() // (n * n)
+    out = torch.empty((batch, n * (n + 1) // 2), dtype=torch.float64, device=G.device)
+    check(l.aggf_sym_pack_upper(ptr(G), n, batch, ptr(out), stream_ptr(G.device)), "aggf_sym_pack_upper")
+    return out
+
+
+def sym_unpack_upper(packed: torch.Tensor, G: torch.Tensor) -> torch.Tensor:
+    """Both triangles of G (..., n, n) from packed upper triangles; in place, returns G."""
+    l = lib()
+    n = G.shape[-1]
+    assert G.dtype == torch.float64 and packed.dtype == torch.float64 and G.is_contiguous() and packed.is_contiguous()
+    batch = G.numel() // (n * n)
+    assert packed.numel() == batch * (n * (n + 1) // 2)
+    check(l.aggf_sym_unpack_upper(ptr(packed), n, batch, ptr(G), stream_ptr(G.device)), "aggf_sym_unpack_upper")
+    return G
+
+
 def gram_quadform(G: torch.Tensor, X: torch.Tensor) -> torch.Tensor:
     """q[i] = x_i' G x_i for the rows of X (m, n); float64 on the device."""
     l = lib()

@@ -43,6 +43,8 @@ PROTOTYPES = {
     "aggf_not_close": (C.c_int, [_vp, _vp, _i64, C.c_int, _dbl, _dbl, _vp, _vp]),
     "aggf_sumsq_workspace_bytes": (_sz, []),
     "aggf_sumsq": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp, _sz, _vp]),
+    "aggf_sym_pack_upper": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
+    "aggf_sym_unpack_upper": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     "aggf_condnormal_augment": (C.c_int, [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _u64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "aggf_group_reduce": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _i32, C.c_int, C.c_int, _vp, _vp]),
     "aggf_gb_channels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),

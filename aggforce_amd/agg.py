@@ -13,7 +13,7 @@ import numpy as np
 
 from . import _kernels as K
 from .constraints import Constraints, guess_pairwise_constraints
-from .distributed import all_reduce_sum_
+from .distributed import all_reduce_sum_, all_reduce_sum_sym_
 from .map import LinearMap, SeperableTMap, TMap
 from .qp import qp_linear_map
 from .trajectory import Trajectory
@@ -162,7 +162,7 @@ def _grid_cv_gram_reuse(grid, forces, folds, kwargs) -> Dict[str, Dict[Any, Any]
     prob = LinearProblem(kwargs["coord_map"], kwargs.get("constrained_inds"), f_dev.device)
     fold_grams = torch.stack([prob.gram(_take_frames(f_dev, idx).contiguous(), kwargs.get("gram_dtype")) for idx in folds])
     counts = torch.tensor([float(len(idx)) for idx in folds], dtype=torch.float64, device=f_dev.device)
-    all_reduce_sum_(fold_grams, comm)
+    all_reduce_sum_sym_(fold_grams, comm)
     all_reduce_sum_(counts, comm)
     counts = counts.tolist()
     total = fold_grams[0].clone()

@@ -229,6 +229,67 @@ extern "C" int aggf_sumsq(const void* x, int64_t count, int dtype, double* out, 
   return AGGF_OK;
 }
 
+// ---- packed upper triangle of symmetric matrices (the payload of the Gram all-reduce) ----
+// packed[b][i * n - i (i - 1) / 2 + (j - i)] = G[b][i][j] for j >= i
+__device__ __forceinline__ int64_t sym_row_start(int64_t i, int64_t n) { return i * n - i * (i - 1) / 2; }
+
+__global__ __launch_bounds__(256) void sym_pack_kernel(const double* __restrict__ G, int32_t n, int64_t g_ps,
+                                                       double* __restrict__ packed, int64_t p_ps) {
+  const int64_t i = blockIdx.y, j = i + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (j < n) packed[blockIdx.z * p_ps + sym_row_start(i, n) + (j - i)] = G[blockIdx.z * g_ps + i * n + j];
+}
+
+// both triangles of G from the packed upper one; 32 x 32 tiles, the mirrored tile goes through LDS so that
+// both writes are row-contiguous
+__global__ __launch_bounds__(256) void sym_unpack_kernel(const double* __restrict__ packed, int32_t n, int64_t p_ps,
+                                                         double* __restrict__ G, int64_t g_ps) {
+  __shared__ double tile[32][33];
+  const int ti = blockIdx.y, tj = blockIdx.x;
+  if (tj < ti) return;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const double* P = packed + blockIdx.z * p_ps;
+  double* Gb = G + blockIdx.z * g_ps;
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = (int64_t)ti * 32 + r, j = (int64_t)tj * 32 + tx;
+    double v = 0.0;
+    if (i < n && j < n) {
+      const int64_t a = i < j ? i : j, b = i < j ? j : i;  // (only the diagonal tile has j < i)
+      v = P[sym_row_start(a, n) + (b - a)];
+      Gb[i * n + j] = v;
+    }
+    tile[r][tx] = v;
+  }
+  if (tj == ti) return;
+  __syncthreads();
+  for (int r = ty; r < 32; r += 8) {
+    const int64_t i = (int64_t)tj * 32 + r, j = (int64_t)ti * 32 + tx;  // element (i, j) of the mirrored tile
+    if (i < n && j < n) Gb[i * n + j] = tile[tx][r];
+  }
+}
+
+extern "C" int aggf_sym_pack_upper(const double* G, int32_t n, int32_t batch, double* packed, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!G || !packed) return fail(AGGF_ERR_ARG, "aggf_sym_pack_upper: NULL pointer");
+  if (n <= 0 || batch <= 0 || batch > 65535 || n > 65535) return fail(AGGF_ERR_ARG, "aggf_sym_pack_upper: bad size");
+  const int64_t per = (int64_t)n * (n + 1) / 2;
+  hipLaunchKernelGGL(sym_pack_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)batch), dim3(256), 0, stream,
+                     G, n, (int64_t)n * n, packed, per);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_sym_unpack_upper(const double* packed, int32_t n, int32_t batch, double* G, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!G || !packed) return fail(AGGF_ERR_ARG, "aggf_sym_unpack_upper: NULL pointer");
+  if (n <= 0 || batch <= 0 || batch > 65535 || n > 65535 * 32) return fail(AGGF_ERR_ARG, "aggf_sym_unpack_upper: bad size");
+  const int64_t per = (int64_t)n * (n + 1) / 2;
+  const unsigned nt = (unsigned)((n + 31) / 32);
+  hipLaunchKernelGGL(sym_unpack_kernel, dim3(nt, nt, (unsigned)batch), dim3(256), 0, stream, packed, n, per, G,
+                     (int64_t)n * n);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
 extern "C" int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
                                const int32_t* group_of_atom, int32_t N, double* W, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;

@@ -45,6 +45,32 @@ def all_reduce_sum_(t: torch.Tensor, comm) -> torch.Tensor:
     return t
 
 
+def all_reduce_sum_sym_(G: torch.Tensor, comm) -> torch.Tensor:
+    """In-place sum over the ranks of symmetric matrices G (..., n, n): only the upper triangles travel.
+
+    The Gram matrices are the one large payload of the data-parallel path (134 MB at n = 4096, 4.8 GB for the 64
+    sites of the featurised fit); packing halves the bytes on the xGMI links.  Device float64 matrices with
+    n >= 256 are packed (aggf_sym_pack_upper / aggf_sym_unpack_upper); anything else goes through
+    :func:`all_reduce_sum_` unchanged.  The result is exactly symmetric.
+    """
+    group = resolve_comm(comm)
+    if group is None:
+        return G
+    import torch.distributed as dist
+
+    if dist.get_world_size(group) == 1:
+        return G
+    n = G.shape[-1] if G.dim() >= 2 else 0
+    if not (G.is_cuda and G.dtype == torch.float64 and G.dim() >= 2 and G.shape[-2] == n and n >= 256
+            and G.is_contiguous() and G.numel() // (n * n) <= 65535):
+        return all_reduce_sum_(G, comm)
+    from . import _kernels as K
+
+    packed = K.sym_pack_upper(G)
+    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+    return K.sym_unpack_upper(packed, G)
+
+
 def all_reduce_minmax_(lo: torch.Tensor, hi: torch.Tensor, comm) -> None:
     """In place: elementwise minimum of ``lo`` and maximum of ``hi`` over the ranks of ``comm``."""
     group = resolve_comm(comm)

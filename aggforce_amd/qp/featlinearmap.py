@@ -21,7 +21,7 @@ from typing_extensions import TypedDict
 
 from .. import _kernels as K
 from ..constraints import Constraints, reduce_constraint_sets
-from ..distributed import agree_on_indices, all_reduce_sum_, shard_extent, take_global_frames
+from ..distributed import agree_on_indices, all_reduce_sum_sym_, shard_extent, take_global_frames
 from ..map import CLAFTMap, CLAMap, LinearMap
 from ..trajectory import Trajectory
 from .qplinear import DEFAULT_SOLVER_OPTIONS, SolverOptions
@@ -293,7 +293,7 @@ def qp_feat_linear_map(
         n_feat = feat_dev.shape[2]
         r3 = _site_regression(forces, feat_dev, div_dev, kbt, ld=-(-n_feat // 128) * 128)  # K1's in-place layout
         G = K.gram(r3, None, None, n_feat, torch.float64)  # exact Gram of R (see qp/gbfeat.py)
-        all_reduce_sum_(G, comm)
+        all_reduce_sum_sym_(G, comm)
         X, stats = K.eq_qp_solve(G, float(l2_regularization), None, A, b, schur_reg=1e-12, n_refine=3)
         st = stats.cpu().numpy()
         if st[0] != 0 or not np.isfinite(st[1]):

@@ -30,7 +30,7 @@ import numpy as np
 
 from .. import _kernels as K
 from ..constraints import Constraints
-from ..distributed import agree_on_indices, all_reduce_minmax_, all_reduce_sum_, shard_extent, take_global_frames
+from ..distributed import agree_on_indices, all_reduce_minmax_, all_reduce_sum_sym_, shard_extent, take_global_frames
 from ..map import CLAFTMap, CLAMap, LinearMap
 from .featlinearmap import KNAME_DIVS, KNAME_FEATS, KNAME_NAMES, constraint_group_labels, id_feat
 
@@ -297,7 +297,7 @@ def fit_id_gb(
                 gauss, _ = K.gb_channels(Pg_sel[lo_s:hi_s].contiguous(), cg_sel[lo_s:hi_s].contiguous(), site,
                                          geo.sizes, n_ch, centers, width, CLIP)
             K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j], cols=cols)  # K4b
-        all_reduce_sum_(Gs, comm)
+        all_reduce_sum_sym_(Gs, comm)
         X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3)
         st_all = stats.cpu().numpy()
         X_host = X[:, 0, :].cpu().numpy()

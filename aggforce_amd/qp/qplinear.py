@@ -14,7 +14,7 @@ from typing_extensions import TypedDict
 
 from .. import _kernels as K
 from ..constraints import Constraints, group_layout, groups_csr
-from ..distributed import all_reduce_sum_
+from ..distributed import all_reduce_sum_sym_
 from ..map import LinearMap, SeperableTMap
 from ..trajectory import ForcesTrajectory
 
@@ -170,5 +170,5 @@ def qp_linear_map(
     forces = K.as_device(traj.forces)
     prob = LinearProblem(coord_map, constraints, forces.device)
     G = prob.gram(forces, gram_dtype)
-    all_reduce_sum_(G, comm)
+    all_reduce_sum_sym_(G, comm)
     return prob.tmap(prob.solve(G, l2_regularization))

@@ -22,7 +22,7 @@ from .agg import (
     TMAP_KNAME,
 )
 from .constraints import Constraints
-from .distributed import all_reduce_sum_
+from .distributed import all_reduce_sum_, all_reduce_sum_sym_
 from .map import LinearMap
 from .qp.qplinear import LinearProblem
 
@@ -171,7 +171,7 @@ def project_forces_streamed(
             pending = up_f.stage(*spans[i + 1])
     if nan_seen:
         raise ValueError("NaN forces: the streamed path does not fit maps on trajectories with NaNs.")
-    all_reduce_sum_(G, comm)
+    all_reduce_sum_sym_(G, comm)
     tmap = prob.tmap(prob.solve(G, l2_regularization))
     del G
 

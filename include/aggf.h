@@ -125,6 +125,14 @@ int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, const double
                              double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
                              double* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* Packed upper triangle of `batch` symmetric n x n float64 matrices, row-major:
+ *   packed[b][i n - i (i - 1) / 2 + (j - i)] = G[b][i][j], j >= i   (n (n + 1) / 2 elements per matrix).
+ * The payload of the Gram all-reduce: the reference has no distributed code; the build sums the per-rank Gram
+ * matrices of reg_mat.T @ reg_mat (qplinear.py:71, featlinearmap.py:359) -- symmetric, so half the bytes travel.
+ * aggf_sym_unpack_upper writes both triangles (exactly symmetric). */
+int aggf_sym_pack_upper(const double* G, int32_t n, int32_t batch, double* packed, void* stream);
+int aggf_sym_unpack_upper(const double* packed, int32_t n, int32_t batch, double* G, void* stream);
+
 /* W[i, a] = X[i, group_of_atom[a]]  -- `con_mat @ gen_map`, qp/qplinear.py:86.
  * X: (n_rows, n_red) float64; group_of_atom: N int32; W: (n_rows, N) float64. */
 int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,

@@ -15,6 +15,29 @@ from aggforce_amd import _lib  # noqa: E402
 from conftest import ROOT  # noqa: E402
 
 
+def test_packed_upper_triangle_round_trip():
+    """aggf_sym_pack_upper / aggf_sym_unpack_upper (the Gram all-reduce payload): element order of the packed form,
+    both triangles restored exactly, batches, sizes that are not multiples of the 32 x 32 tile."""
+    from aggforce_amd import _kernels as K
+
+    rng = np.random.default_rng(5)
+    for batch, n in ((1, 1), (1, 31), (3, 97), (1, 256), (2, 1000)):
+        a = rng.standard_normal((batch, n, n))
+        sym = a + a.transpose(0, 2, 1)
+        G = torch.from_numpy(sym).cuda()
+        packed = K.sym_pack_upper(G)
+        iu = np.triu_indices(n)
+        assert np.array_equal(packed.cpu().numpy(), np.stack([m[iu] for m in sym]))  # row-major upper triangle
+        out = torch.full_like(G, float("nan"))
+        K.sym_unpack_upper(packed, out)
+        assert np.array_equal(out.cpu().numpy(), sym)
+        # the lower triangle of the input is never read: garbage there does not reach the result
+        dirty = G.clone()
+        il = np.tril_indices(n, -1)
+        dirty[:, il[0], il[1]] = 7.0
+        assert torch.equal(K.sym_pack_upper(dirty), packed)
+
+
 def test_allreduce_world_of_one_is_identity():
     l = _lib.lib()
     uid = (C.c_char * 128)()
