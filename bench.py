@@ -382,7 +382,7 @@ def main():
                     "flops_per_launch": flops, "mfma_tflops": flops / (gram_ms * 1e-3) / 1e12}
         else:
             achieved = flops / (gram_ms * 1e-3) / 1e12
-            kname = "gram_tile_dma_kernel<%s, 0, 3, 2, 8, true> (+ gram_reduce_kernel) = aggf_gram" % (
+            kname = "gram_tile_dma_kernel<%s, 0, 3, 2, 8, true, false> (+ gram_reduce_kernel) = aggf_gram" % (
                 "double" if gdt == "f64" else "float")
             roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS[gdt], "traffic": profiled_traffic(args.workload, world),
