@@ -66,3 +66,43 @@ def test_batched_solve_redundant_rows_and_identity_rhs():
     assert st3[0, 0] == 0 and st3[2, 0] == 0 and st3[1, 0] != 0
     with pytest.raises(ValueError):
         K.eq_qp_solve_batched(torch.from_numpy(G2).cuda(), 0.0, None, torch.from_numpy(A2[:2]).cuda(), None)
+
+
+_POTRF_SCRIPT = r"""
+import sys, numpy as np, torch
+sys.path.insert(0, sys.argv[1])
+from aggforce_amd import _kernels as K
+rng = np.random.default_rng(3)
+out = {}
+for n, m in ((64, 3), (200, 17), (1000, 64)):
+    R = rng.standard_normal((3 * n, n))
+    G = torch.from_numpy(R.T @ R).cuda()
+    A = torch.from_numpy(rng.standard_normal((m, n))).cuda()
+    b = torch.from_numpy(np.eye(m)).cuda()
+    X, stats = K.eq_qp_solve(G, 1e-3, None, A, b, schur_reg=1e-12, n_refine=3)
+    out[f"x{n}"] = X.cpu().numpy()
+np.savez(sys.argv[2], **out)
+"""
+
+
+def test_diagonal_block_kernels_agree(tmp_path):
+    """The 64 x 64 diagonal-block factorisation has two implementations (default: blocked 16 x 16 over four waves;
+    AGGF_POTRF=wave: one wave, the block in registers): the solves they feed agree to rounding."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = tmp_path / "potrf.py"
+    script.write_text(_POTRF_SCRIPT)
+    res = {}
+    for tag, env in (("blocked", dict(os.environ)), ("wave", dict(os.environ, AGGF_POTRF="wave"))):
+        env.pop("AGGF_POTRF", None) if tag == "blocked" else None
+        path = tmp_path / f"{tag}.npz"
+        run = subprocess.run([sys.executable, str(script), root, str(path)], env=env, capture_output=True, text=True,
+                             timeout=300)
+        assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-2000:]
+        res[tag] = np.load(path)
+    for key in res["blocked"].files:
+        a, b = res["blocked"][key], res["wave"][key]
+        assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b)), key
