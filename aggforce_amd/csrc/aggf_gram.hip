@@ -289,7 +289,8 @@ __device__ unsigned long long aggf_gram_prof[4];
 
 // M32 (float, NW = 8 only): v_mfma_f32_32x32x2_f32 instead of 16x16x4 -- the same operand reads per flop (they
 // depend on the 64 x 32 wave tile only) in half as many MFMA instructions of twice the length.
-template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, bool M32 = false>
+template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, bool M32 = false,
+          bool ES = false>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
@@ -313,6 +314,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   constexpr int PANEL_ELEMS = dma_panel_elems<T>();
   constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
   constexpr int AHEAD = NBUF - 1;  // stages in flight ahead of the one being computed
+  constexpr bool EARLY_SYNC = ES && SPREAD_DMA && !M32 && ABL == 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -489,6 +491,14 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           for (int q = 0; q < PPW; ++q)
             if (q * GROUPS / PPW == kk * 3 + d) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
         }
+        if (EARLY_SYNC && kk == KB / 4 - 1 && d == 2) {
+          // the stage's barrier BEFORE the MFMAs of its last group: their operands are in registers once the LDS
+          // reads have returned, so the slot is free for the next DMA, and the 8 MFMAs run while the waves meet
+          if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+        }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
 #pragma unroll
@@ -498,7 +508,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     }
     AGGF_PROF_T(p2);
     // stage it+1 must have landed (this wave's pieces), stage it+2 may stay in flight
-    if (ABL != 2) {
+    if (ABL != 2 && !EARLY_SYNC) {
       // (the ragged stage of the last split issues fewer DMAs: a counted wait would let pieces
       // of stage it+1 slip through)
       if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
@@ -1558,8 +1568,26 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
         return AGGF_OK;
       }
     }
-    hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
-                       lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
+    // The stage barrier in front of the last MFMA group instead of behind it (its operands are in registers by then,
+    // the 8 MFMAs run while the waves meet): float32 only.  Same box, back to back -- c5 60.2 -> 58.6 ms, c2 3.25 ->
+    // 3.16 ms; float64 at C3 757 -> 768 ms (the fp64 group is 512 cycles long: what the early barrier hides is less than
+    // what the earlier DMA wait costs).  AGGF_GRAM_EARLY_SYNC = 0 | 1 overrides (measurement).
+    static const char* es_env = getenv("AGGF_GRAM_EARLY_SYNC");
+    const bool early_sync = es_env ? es_env[0] == '1' : sizeof(T) == 4;
+    if (!early_sync) {
+      hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
+                         lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
+    } else {
+      static thread_local PerDeviceOnce once_es;
+      bool& done_es = *once_es.flag();
+      if (!done_es) {
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, true>,
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+        done_es = true;
+      }
+      hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, true>), dim3((unsigned)round_up(nblk, 512)),
+                         dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
+    }
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                        slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
