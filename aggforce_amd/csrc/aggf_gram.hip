@@ -289,8 +289,15 @@ __device__ unsigned long long aggf_gram_prof[4];
 
 // M32 (float, NW = 8 only): v_mfma_f32_32x32x2_f32 instead of 16x16x4 -- the same operand reads per flop (they
 // depend on the 64 x 32 wave tile only) in half as many MFMA instructions of twice the length.
+// pieces q of a stage (piece q goes with MFMA group q * groups / ppw) issued up to and including group g
+constexpr int dma_pieces_upto(int groups, int ppw, int g) {
+  int n = 0;
+  for (int q = 0; q < ppw; ++q) n += (q * groups / ppw <= g) ? 1 : 0;
+  return n;
+}
+
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, bool M32 = false,
-          bool ES = false>
+          int ES = 0>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
@@ -314,7 +321,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   constexpr int PANEL_ELEMS = dma_panel_elems<T>();
   constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
   constexpr int AHEAD = NBUF - 1;  // stages in flight ahead of the one being computed
-  constexpr bool EARLY_SYNC = ES && SPREAD_DMA && !M32 && ABL == 0;
+  constexpr bool EARLY_SYNC = ES > 0 && SPREAD_DMA && !M32 && ABL == 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   T* smem = reinterpret_cast<T*>(smem_raw);
@@ -456,6 +463,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     }
     const T* pa = smem + (((ABL == 1 || ABL == 2) ? it % 2 : it % NBUF)) * BUF_ELEMS;
     AGGF_PROF_T(p1);
+    T aL[ES > 0 ? ES : 1][4], bL[ES > 0 ? ES : 1][NACC];  // operands of the groups behind an early barrier
+    (void)aL;
+    (void)bL;
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
@@ -479,22 +489,45 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
             for (int m = 0; m < 2; ++m)
               acc32[m] = __builtin_amdgcn_mfma_f32_32x32x2f32(a32[s2][m], b32[s2], acc32[m], 0, 0, 0);
         } else {
+        constexpr int ESG = EARLY_SYNC ? ES : 0;  // MFMA groups that run behind the stage barrier
+        const int g = kk * 3 + d;
         T a[4], bb[NACC];
+        if (ESG > 0 && g == GROUPS - ESG) {
+          // operands of all remaining groups: once these reads have returned, nobody needs the slot any more
 #pragma unroll
-        for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * KKS + 48 * m + d];
+          for (int h = 0; h < (ESG > 0 ? ESG : 1); ++h) {
+            const int kh = (GROUPS - ESG + h) / 3, dh = (GROUPS - ESG + h) % 3;
 #pragma unroll
-        for (int n = 0; n < NACC; ++n) bb[n] = pa[offB + kk * KKS + 48 * n + d];
+            for (int m = 0; m < 4; ++m) aL[h][m] = pa[offA + kh * KKS + 48 * m + dh];
+#pragma unroll
+            for (int n = 0; n < NACC; ++n) bL[h][n] = pa[offB + kh * KKS + 48 * n + dh];
+          }
+        }
+        if (ESG > 0 && g >= GROUPS - ESG) {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a[m] = aL[g - (GROUPS - ESG)][m];
+#pragma unroll
+          for (int n = 0; n < NACC; ++n) bb[n] = bL[g - (GROUPS - ESG)][n];
+        } else {
+#pragma unroll
+          for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * KKS + 48 * m + d];
+#pragma unroll
+          for (int n = 0; n < NACC; ++n) bb[n] = pa[offB + kk * KKS + 48 * n + d];
+        }
         // between the operand reads and the MFMAs of the group: the reads are in flight while the DMA
         // waits to be accepted (before the reads: +3.5 %, after the MFMAs: +1 %, tools/clock_probe.hip)
         if (SPREAD && issue_now) {
 #pragma unroll
           for (int q = 0; q < PPW; ++q)
-            if (q * GROUPS / PPW == kk * 3 + d) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
+            if (q * GROUPS / PPW == g) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
         }
-        if (EARLY_SYNC && kk == KB / 4 - 1 && d == 2) {
-          // the stage's barrier BEFORE the MFMAs of its last group: their operands are in registers once the LDS
-          // reads have returned, so the slot is free for the next DMA, and the 8 MFMAs run while the waves meet
-          if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+        if (ESG > 0 && g == GROUPS - ESG) {
+          // the stage's barrier BEFORE the MFMAs of its last group(s): their operands are in registers once the LDS
+          // reads have returned, so the slot is free for the next DMA, and the MFMAs run while the waves meet.
+          // (Pieces of stage it+2 that go with later groups are not issued yet: the counted wait allows the rest.)
+          constexpr int ISSUED = dma_pieces_upto(GROUPS, PPW, GROUPS - ESG);
+          static_assert(ISSUED >= 1 && ISSUED <= PPW, "pieces issued by the barrier group");
+          if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<ISSUED>(); else wait_vmcnt<0>();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
@@ -1571,21 +1604,22 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
     // The stage barrier in front of the last MFMA group instead of behind it (its operands are in registers by then,
     // the 8 MFMAs run while the waves meet): float32 only.  Same box, back to back -- c5 60.2 -> 58.6 ms, c2 3.25 ->
     // 3.16 ms; float64 at C3 757 -> 768 ms (the fp64 group is 512 cycles long: what the early barrier hides is less than
-    // what the earlier DMA wait costs).  AGGF_GRAM_EARLY_SYNC = 0 | 1 overrides (measurement).
+    // what the earlier DMA wait costs; 743.0-747.6 against 747.9-749.8 ms on a second box).  Two groups behind the barrier
+    // (template ES = 2): c5 59.2 against 57.3 ms, worse again.  AGGF_GRAM_EARLY_SYNC = 0 | 1 overrides (measurement).
     static const char* es_env = getenv("AGGF_GRAM_EARLY_SYNC");
-    const bool early_sync = es_env ? es_env[0] == '1' : sizeof(T) == 4;
-    if (!early_sync) {
+    const int early_sync = es_env ? (es_env[0] == '1' ? 1 : 0) : (sizeof(T) == 4 ? 1 : 0);
+    if (early_sync <= 0) {
       hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
                          lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
     } else {
       static thread_local PerDeviceOnce once_es;
       bool& done_es = *once_es.flag();
       if (!done_es) {
-        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, true>,
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         done_es = true;
       }
-      hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, true>), dim3((unsigned)round_up(nblk, 512)),
+      hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1>), dim3((unsigned)round_up(nblk, 512)),
                          dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
     }
     AGGF_LAUNCH_OK();
