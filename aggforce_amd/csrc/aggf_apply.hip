@@ -220,17 +220,21 @@ __global__ __launch_bounds__(AP_THREADS, (AP_THREADS >= 1024 || AP_WF < 4) ? 4 :
       for (int d = 0; d < 3; ++d) a[d] = x[offX + 12 * kk + d];
 #pragma unroll
       for (int n = 0; n < NCT; ++n) b[n] = m[offM + 16 * n * AP_MS + 4 * kk];
+      if (kk == AP_KA / 4 - 1) {
+        // LDS refill and barrier IN FRONT of the stage's last MFMAs (their operands are in registers): the six MFMAs
+        // run while the 16 waves meet.  Same box, back to back, C3: 106.3 -> 104.4 ms; c5 14.2 -> 13.8 ms.
+#if !defined(AGGF_APPLY_ABL) || AGGF_APPLY_ABL < 2
+        if (s + 1 < n_stage) store_stage(cur ^ 1, other{});
+#endif
+        __syncthreads();
+      }
 #pragma unroll
       for (int n = 0; n < NCT; ++n)
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], b[n], acc[n][d]);
     }
     AP_T(q2);
-#if !defined(AGGF_APPLY_ABL) || AGGF_APPLY_ABL < 2
-    if (s + 1 < n_stage) store_stage(cur ^ 1, other{});
-#endif
     AP_T(q3);
-    __syncthreads();
 #ifdef AGGF_APPLY_PROF
     const uint64_t q4 = __builtin_readcyclecounter();
     pf[0] += q1 - q0;
