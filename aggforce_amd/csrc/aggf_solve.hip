@@ -119,13 +119,17 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
       for (int m = 0; m < 2; ++m) a[m] = sA[cur][offA + 16 * m * GS + 4 * kk];
 #pragma unroll
       for (int n = 0; n < 2; ++n) b[n] = sB[cur][offB + 16 * n * GS + 4 * kk];
+      if (kk == GK / 4 - 1) {
+        // LDS refill and barrier in front of the stage's last MFMAs (operands in registers): they run while the
+        // waves meet (as in K3).  Same box, back to back: c4 solve 81.2 -> 78.0 ms, C3 7.46 -> 7.07 ms, c2 1.64 -> 1.55 ms.
+        if (s + 1 < n_stage) store_stage(cur ^ 1);
+        __syncthreads();
+      }
 #pragma unroll
       for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) acc[m][n] = MF::mma(a[m], b[n], acc[m][n]);
     }
-    if (s + 1 < n_stage) store_stage(cur ^ 1);
-    __syncthreads();
   }
 #pragma unroll
   for (int m = 0; m < 2; ++m)
