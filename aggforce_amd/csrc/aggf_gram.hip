@@ -297,7 +297,7 @@ constexpr int dma_pieces_upto(int groups, int ppw, int g) {
 }
 
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, bool M32 = false,
-          int ES = 0>
+          int ES = 0, bool ES_DMA_AFTER = false>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
@@ -516,7 +516,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
         }
         // between the operand reads and the MFMAs of the group: the reads are in flight while the DMA
         // waits to be accepted (before the reads: +3.5 %, after the MFMAs: +1 %, tools/clock_probe.hip)
-        if (SPREAD && issue_now) {
+        constexpr bool DMA_AFTER = ES_DMA_AFTER && ESG > 0;  // the barrier group issues its DMA piece behind the barrier
+        if (SPREAD && issue_now && !(DMA_AFTER && g == GROUPS - ESG)) {
 #pragma unroll
           for (int q = 0; q < PPW; ++q)
             if (q * GROUPS / PPW == g) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
@@ -525,12 +526,17 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           // the stage's barrier BEFORE the MFMAs of its last group(s): their operands are in registers once the LDS
           // reads have returned, so the slot is free for the next DMA, and the MFMAs run while the waves meet.
           // (Pieces of stage it+2 that go with later groups are not issued yet: the counted wait allows the rest.)
-          constexpr int ISSUED = dma_pieces_upto(GROUPS, PPW, GROUPS - ESG);
-          static_assert(ISSUED >= 1 && ISSUED <= PPW, "pieces issued by the barrier group");
+          constexpr int ISSUED = dma_pieces_upto(GROUPS, PPW, GROUPS - ESG - (DMA_AFTER ? 1 : 0));
+          static_assert(ISSUED >= 0 && ISSUED <= PPW, "pieces issued by the barrier group");
           if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<ISSUED>(); else wait_vmcnt<0>();
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
+          if (DMA_AFTER && SPREAD && issue_now) {
+#pragma unroll
+            for (int q = 0; q < PPW; ++q)
+              if (q * GROUPS / PPW == g) issue_piece(it + AHEAD, q);
+          }
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -1602,24 +1608,25 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
       }
     }
     // The stage barrier in front of the last MFMA group instead of behind it (its operands are in registers by then,
-    // the 8 MFMAs run while the waves meet): float32 only.  Same box, back to back -- c5 60.2 -> 58.6 ms, c2 3.25 ->
-    // 3.16 ms; float64 at C3 757 -> 768 ms (the fp64 group is 512 cycles long: what the early barrier hides is less than
-    // what the earlier DMA wait costs; 743.0-747.6 against 747.9-749.8 ms on a second box).  Two groups behind the barrier
-    // (template ES = 2): c5 59.2 against 57.3 ms, worse again.  AGGF_GRAM_EARLY_SYNC = 0 | 1 overrides (measurement).
+    // the 8 MFMAs run while the waves meet), and the DMA piece that goes with that group issued BEHIND the barrier.
+    // Same box, back to back: float32 (no piece in the barrier group) c5 60.2 -> 58.6 ms, c2 3.25 -> 3.16 ms; float64
+    // C3 756.4 -> 747.9 ms, c4 297.0 -> 293.9 ms.  With the piece in front of the barrier float64 is SLOWER than the
+    // late barrier (757 -> 768 ms): the waves then meet right after the instruction that stalls longest, and nobody
+    // multiplies until the slowest DMA issue is through.  Two groups behind the barrier (template ES = 2): c5 59.2
+    // against 57.3 ms, worse again.  AGGF_GRAM_EARLY_SYNC=0: the late barrier (measurement).
     static const char* es_env = getenv("AGGF_GRAM_EARLY_SYNC");
-    const int early_sync = es_env ? (es_env[0] == '1' ? 1 : 0) : (sizeof(T) == 4 ? 1 : 0);
-    if (early_sync <= 0) {
+    if (es_env && es_env[0] == '0') {
       hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
                          lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
     } else {
       static thread_local PerDeviceOnce once_es;
       bool& done_es = *once_es.flag();
       if (!done_es) {
-        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1>,
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1, true>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
         done_es = true;
       }
-      hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1>), dim3((unsigned)round_up(nblk, 512)),
+      hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1, true>), dim3((unsigned)round_up(nblk, 512)),
                          dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
     }
     AGGF_LAUNCH_OK();

@@ -383,7 +383,7 @@ def main():
         else:
             achieved = flops / (gram_ms * 1e-3) / 1e12
             kname = "gram_tile_dma_kernel<%s> (+ gram_reduce_kernel) = aggf_gram" % (
-                "double, 0, 3, 2, 8, true, false, 0" if gdt == "f64" else "float, 0, 3, 2, 8, true, false, 1")
+                "double, 0, 3, 2, 8, true, false, 1, true" if gdt == "f64" else "float, 0, 3, 2, 8, true, false, 1, true")
             roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS[gdt], "traffic": profiled_traffic(args.workload, world),
                     "traffic_source": "profiles/r02_c3_rocprof_summary.json (separate rocprofv3 --pmc passes; not measured in this run)"
