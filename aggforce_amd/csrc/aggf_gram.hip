@@ -532,6 +532,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
+          // (right behind the barrier; behind the group's MFMAs instead: 744.5 against 737.9 ms at C3, same box)
           if (DMA_AFTER && SPREAD && issue_now) {
 #pragma unroll
             for (int q = 0; q < PPW; ++q)
@@ -1613,7 +1614,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
     // C3 756.4 -> 747.9 ms, c4 297.0 -> 293.9 ms.  With the piece in front of the barrier float64 is SLOWER than the
     // late barrier (757 -> 768 ms): the waves then meet right after the instruction that stalls longest, and nobody
     // multiplies until the slowest DMA issue is through.  Two groups behind the barrier (template ES = 2): c5 59.2
-    // against 57.3 ms, worse again.  AGGF_GRAM_EARLY_SYNC=0: the late barrier (measurement).
+    // against 57.3 ms, C3 789 against 746 ms: much worse.  AGGF_GRAM_EARLY_SYNC=0: the late barrier (measurement).
     static const char* es_env = getenv("AGGF_GRAM_EARLY_SYNC");
     if (es_env && es_env[0] == '0') {
       hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true>), dim3((unsigned)round_up(nblk, 512)), dim3(512),
