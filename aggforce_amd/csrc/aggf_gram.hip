@@ -290,9 +290,11 @@ __device__ unsigned long long aggf_gram_prof[4];
 // M32 (float, NW = 8 only): v_mfma_f32_32x32x2_f32 instead of 16x16x4 -- the same operand reads per flop (they
 // depend on the 64 x 32 wave tile only) in half as many MFMA instructions of twice the length.
 // pieces q of a stage (piece q goes with MFMA group q * groups / ppw) issued up to and including group g
+// (float32 has 6 groups for 3 pieces: groups 0, 2, 4; shifted to 1, 3, 5 -- the last one behind the barrier -- measured the same)
+constexpr int dma_piece_group(int groups, int ppw, int q) { return q * groups / ppw; }
 constexpr int dma_pieces_upto(int groups, int ppw, int g) {
   int n = 0;
-  for (int q = 0; q < ppw; ++q) n += (q * groups / ppw <= g) ? 1 : 0;
+  for (int q = 0; q < ppw; ++q) n += (dma_piece_group(groups, ppw, q) <= g) ? 1 : 0;
   return n;
 }
 
@@ -521,7 +523,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
         if (SPREAD && issue_now && !(DMA_AFTER && g == GROUPS - ESG)) {
 #pragma unroll
           for (int q = 0; q < PPW; ++q)
-            if (q * GROUPS / PPW == g) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
+            if (dma_piece_group(GROUPS, PPW, q) == g) issue_piece(it + AHEAD, q);  // piece q goes with group q*GROUPS/PPW
         }
         if (ESG > 0 && g == GROUPS - ESG) {
           // the stage's barrier BEFORE the MFMAs of its last group(s): their operands are in registers once the LDS
@@ -537,7 +539,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           if (DMA_AFTER && SPREAD && issue_now) {
 #pragma unroll
             for (int q = 0; q < PPW; ++q)
-              if (q * GROUPS / PPW == g) issue_piece(it + AHEAD, q);
+              if (dma_piece_group(GROUPS, PPW, q) == g) issue_piece(it + AHEAD, q);
           }
         }
 #pragma unroll
