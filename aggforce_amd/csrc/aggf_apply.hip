@@ -436,7 +436,8 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
 
   if (n_it > 0) fetch(0);
   for (int s = 0; s < n_it; ++s) {
-    __syncthreads();
+    // (no barrier in front of park(): the MFMAs of stage s-1 read `raw` in front of that stage's last barrier, and
+    // `part`, which waves 0 and 1 may still be reading, is not written before the next barrier)
     park();
     __syncthreads();
     if (s + 1 < n_it) fetch(s + 1);

@@ -1108,7 +1108,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   if (n_it > 0) fetch(0);
   for (int s = 0; s < n_it; ++s) {
     AGGF_SP_T(q0);
-    __syncthreads();       // the MFMAs of stage s-1 are done with the panel, its group sums with `raw`
+    // (no barrier here: `raw` was last read by the group sums of stage s-1, in front of that stage's third barrier;
+    // the panel, which the MFMAs of stage s-1 may still be reading, is not written before the next barrier)
     AGGF_SP_T(q1);
     park();
     AGGF_SP_T(q2);
