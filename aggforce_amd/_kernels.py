@@ -13,7 +13,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import check, dtype_code, lib, ptr, stream_ptr, workspace
+from ._lib import check, drop_workspace, dtype_code, lib, ptr, stream_ptr, workspace  # noqa: F401
 
 _TORCH_OF = {np.dtype(np.float32): torch.float32, np.dtype(np.float64): torch.float64}
 _NP_OF = {torch.float32: np.dtype(np.float32), torch.float64: np.dtype(np.float64)}
@@ -506,16 +506,24 @@ def group_reduce(x: torch.Tensor, grp_ptr: torch.Tensor, grp_atoms: torch.Tensor
     return out
 
 
+def _gb_dtype(Pg, cg, centers) -> int:
+    """Feature arithmetic type of the K4 calls: Pg, cg and centers must share it (float32 or float64)."""
+    if not (Pg.dtype == cg.dtype == centers.dtype):
+        raise TypeError(f"gb_feat operands differ in dtype: {Pg.dtype}, {cg.dtype}, {centers.dtype}")
+    return dtype_code(Pg.dtype)
+
+
 def gb_channels(Pg, cg, site: int, sizes, n_ch: int, centers, width: float, clip: float):
     l = lib()
     T, G, _ = Pg.shape
     nb = centers.numel()
-    gauss = torch.empty((T, n_ch, nb), dtype=torch.float32, device=Pg.device)
-    grad = torch.empty((T, n_ch, nb, 3), dtype=torch.float32, device=Pg.device)
+    gd = _gb_dtype(Pg, cg, centers)
+    gauss = torch.empty((T, n_ch, nb), dtype=Pg.dtype, device=Pg.device)
+    grad = torch.empty((T, n_ch, nb, 3), dtype=Pg.dtype, device=Pg.device)
     if T == 0 or n_ch == 0:
         return gauss, grad
     check(
-        l.aggf_gb_channels(ptr(Pg), ptr(cg), T, G, cg.shape[1], site, ptr(sizes), n_ch, ptr(centers), nb,
+        l.aggf_gb_channels(ptr(Pg), ptr(cg), gd, T, G, cg.shape[1], site, ptr(sizes), n_ch, ptr(centers), nb,
                            float(width), float(clip), ptr(gauss), ptr(grad), stream_ptr()),
         "aggf_gb_channels",
     )
@@ -529,7 +537,8 @@ def gb_regmat(Fg, Pg, cg, site: int, sizes, n_id: int, n_ch: int, centers, width
     T, G, _ = Fg.shape
     with _timed("gb_regmat"):
         check(
-            l.aggf_gb_regmat(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, cg.shape[1], site, ptr(sizes),
+            l.aggf_gb_regmat(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), _gb_dtype(Pg, cg, centers), T, G,
+                             cg.shape[1], site, ptr(sizes),
                              n_id, n_ch, ptr(centers), centers.numel(), float(width), float(clip), float(kbt),
                              out.shape[1], ptr(out), dtype_code(out.dtype), stream_ptr()),
             "aggf_gb_regmat",
@@ -546,7 +555,8 @@ def gb_apply(Fg, Pg, cg, sizes, n_id: int, n_ch: int, centers, width: float, cli
         return out
     with _timed("gb_apply"):
         check(
-            l.aggf_gb_apply(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, n_cg, ptr(sizes), n_id, n_ch,
+            l.aggf_gb_apply(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), _gb_dtype(Pg, cg, centers), T, G, n_cg,
+                            ptr(sizes), n_id, n_ch,
                             ptr(centers), centers.numel(), float(width), float(clip), ptr(coef), coef.shape[1],
                             ptr(out), stream_ptr()),
             "aggf_gb_apply",
@@ -634,13 +644,17 @@ def gb_constraint_rows(Mg: torch.Tensor, gauss: Optional[torch.Tensor], S: int, 
     A = out_A if out_A is not None else torch.empty((S * n_cg, n_feat), dtype=torch.float64, device=Mg.device)
     b = out_b if out_b is not None else torch.empty((S * n_cg, 1), dtype=torch.float64, device=Mg.device)
     ld = A.shape[-1]
-    check(lib().aggf_gb_constraint_rows(ptr(Mg), ptr(gauss), S, n_cg, G, n_id, n_ch, n_basis, ptr(cols), n_cols, ld,
+    gd = _lib.F32 if gauss is None else dtype_code(gauss.dtype)
+    check(lib().aggf_gb_constraint_rows(ptr(Mg), ptr(gauss), gd, S, n_cg, G, n_id, n_ch, n_basis, ptr(cols), n_cols, ld,
                                         int(site), ptr(A), ptr(b), stream_ptr()), "aggf_gb_constraint_rows")
     return A, b
 
 
 def gb_distance_range(Pg: torch.Tensor, cg: torch.Tensor, n_ch: int):
-    """(rmin, rmax) (n_cg, G) float32: range over frames of every channel's distance to every cg site."""
+    """(rmin, rmax) (n_cg, G) float32: range over frames of every channel's distance to every cg site
+    (evaluated in float32 whatever the feature dtype: the caller applies a safety margin)."""
+    if Pg.dtype != torch.float32:
+        Pg, cg = Pg.to(torch.float32), cg.to(torch.float32)
     T, G, _ = Pg.shape
     n_cg = cg.shape[1]
     rmin = torch.full((n_cg, G), float("inf"), dtype=torch.float32, device=Pg.device)
@@ -657,7 +671,8 @@ def gb_regmat_cols(Fg, Pg, cg, site: int, sizes, n_id: int, cols: torch.Tensor, 
     T, G, _ = Fg.shape
     with _timed("gb_regmat"):
         check(
-            lib().aggf_gb_regmat_cols(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), T, G, cg.shape[1], site,
+            lib().aggf_gb_regmat_cols(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), _gb_dtype(Pg, cg, centers), T, G,
+                                      cg.shape[1], site,
                                       ptr(sizes), n_id, ptr(cols), int(cols.numel()), ptr(centers), centers.numel(),
                                       float(width), float(clip), float(kbt), out.shape[1], ptr(out),
                                       dtype_code(out.dtype), stream_ptr()),

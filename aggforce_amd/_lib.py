@@ -47,15 +47,15 @@ PROTOTYPES = {
     "aggf_sym_unpack_upper": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     "aggf_condnormal_augment": (C.c_int, [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _u64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "aggf_group_reduce": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _i32, C.c_int, C.c_int, _vp, _vp]),
-    "aggf_gb_channels": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),
-    "aggf_gb_regmat": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
-    "aggf_gb_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp]),
+    "aggf_gb_channels": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),
+    "aggf_gb_regmat": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
+    "aggf_gb_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp]),
     "aggf_trjdot_frames": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp]),
     "aggf_feat_contract": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dbl, _i64, _i32, _i32, _i32, _vp, C.c_int, _vp]),
     "aggf_feat_constraint_rows": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
-    "aggf_gb_constraint_rows": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_gb_constraint_rows": (C.c_int, [_vp, _vp, C.c_int, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aggf_gb_distance_range": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
-    "aggf_gb_regmat_cols": (C.c_int, [_vp, C.c_int, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
+    "aggf_gb_regmat_cols": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
     "aggf_feat_weights": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),
     "aggf_pair_dist_var_workspace_bytes": (_sz, [_i64, _i32]),
     "aggf_pair_dist_var": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _sz, _vp]),
@@ -154,3 +154,9 @@ def workspace(nbytes: int, device, tag: str = "") -> torch.Tensor:
 
 def free_workspaces() -> None:
     _ws_cache.clear()
+
+
+def drop_workspace(tag: str, device=None) -> None:
+    """Forget the cached scratch buffers of one tag (on one device, or everywhere)."""
+    for key in [k for k in _ws_cache if k[1] == tag and (device is None or k[0] == str(device))]:
+        del _ws_cache[key]

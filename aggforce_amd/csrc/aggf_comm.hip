@@ -9,6 +9,8 @@
 #include <dlfcn.h>
 #include <string.h>
 
+#include <mutex>
+
 #include "aggf_common.h"
 
 namespace aggf {
@@ -21,7 +23,11 @@ typedef int (*fn_init_rank)(rccl_comm_t*, int, RcclId, int);
 typedef int (*fn_destroy)(rccl_comm_t);
 typedef int (*fn_allreduce)(const void*, void*, size_t, int, int, rccl_comm_t, hipStream_t);
 typedef const char* (*fn_errstr)(int);
-constexpr int RCCL_SUM = 0, RCCL_F32 = 7, RCCL_F64 = 8;  // ncclSum, ncclFloat32, ncclFloat64 (rccl.h)
+typedef int (*fn_version)(int*);
+// ncclSum, ncclFloat32, ncclFloat64 and the by-value 128-byte id of rccl.h, NCCL API 2.x (unchanged since 2.0); the
+// version of the library that was actually loaded is checked below, so a future ABI break is refused, not miscalled
+constexpr int RCCL_SUM = 0, RCCL_F32 = 7, RCCL_F64 = 8;
+constexpr int RCCL_MIN_VERSION = 20000, RCCL_MAX_VERSION = 29999;  // ncclGetVersion: major * 10000 + minor * 100 + patch (>= 2.9)
 
 struct Rccl {
   void* handle = nullptr;
@@ -30,13 +36,13 @@ struct Rccl {
   fn_destroy destroy = nullptr;
   fn_allreduce allreduce = nullptr;
   fn_errstr errstr = nullptr;
+  int version = 0;
 };
 
 static Rccl* rccl() {
   static Rccl r;
-  static bool tried = false;
-  if (!tried) {
-    tried = true;
+  static std::once_flag once;
+  std::call_once(once, [] {
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
       r.handle = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
       if (r.handle) break;
@@ -47,9 +53,15 @@ static Rccl* rccl() {
       r.destroy = (fn_destroy)dlsym(r.handle, "ncclCommDestroy");
       r.allreduce = (fn_allreduce)dlsym(r.handle, "ncclAllReduce");
       r.errstr = (fn_errstr)dlsym(r.handle, "ncclGetErrorString");
+      fn_version ver = (fn_version)dlsym(r.handle, "ncclGetVersion");
+      if (ver && ver(&r.version) != 0) r.version = 0;
+      // versions before 2.9 report major * 1000 + minor * 100 + patch
+      if (r.version > 0 && r.version < 10000) r.version = (r.version / 1000) * 10000 + r.version % 1000;
     }
-  }
-  return (r.handle && r.get_id && r.init_rank && r.destroy && r.allreduce) ? &r : nullptr;
+  });
+  if (!(r.handle && r.get_id && r.init_rank && r.destroy && r.allreduce)) return nullptr;
+  if (r.version < RCCL_MIN_VERSION || r.version > RCCL_MAX_VERSION) return nullptr;  // constants above are for API 2.x
+  return &r;
 }
 
 static int rccl_fail(Rccl* r, int rc, const char* what) {

@@ -207,7 +207,8 @@ __global__ __launch_bounds__(256) void feat_rows_kernel(const TX* __restrict__ f
 // A[(s,c), g] = Mg[c,g] (g < n_id);  A[(s,c), n_id + j] = Mg[c,ch] gauss[s,ch,k] with (ch,k) the j-th
 // Gaussian column (all n_ch*nb of them if cols == NULL, else cols[j] = ch*nb + k);  b one-hot on `site`.
 // A has row stride ld >= n_id + n_cols; columns beyond are written as zeros.
-__global__ __launch_bounds__(256) void gb_rows_kernel(const double* __restrict__ Mg, const float* __restrict__ gauss,
+template <typename TG>
+__global__ __launch_bounds__(256) void gb_rows_kernel(const double* __restrict__ Mg, const TG* __restrict__ gauss,
                                                       int32_t S, int32_t n_cg, int32_t G, int32_t n_id, int32_t n_ch,
                                                       int32_t nb, const int32_t* __restrict__ cols, int32_t n_cols,
                                                       int32_t ld, int32_t site, double* __restrict__ A,
@@ -342,7 +343,7 @@ extern "C" int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t 
   return AGGF_OK;
 }
 
-extern "C" int aggf_gb_constraint_rows(const double* Mg, const float* gauss, int32_t S, int32_t n_cg, int32_t G,
+extern "C" int aggf_gb_constraint_rows(const double* Mg, const void* gauss, int g_dtype, int32_t S, int32_t n_cg, int32_t G,
                                        int32_t n_id, int32_t n_ch, int32_t n_basis, const int32_t* cols,
                                        int32_t n_cols, int32_t ld, int32_t site, double* A, double* b,
                                        void* stream_v) {
@@ -353,8 +354,14 @@ extern "C" int aggf_gb_constraint_rows(const double* Mg, const float* gauss, int
       n_cols > n_ch * n_basis || n_id + n_cols <= 0 || ld < n_id + n_cols || site < 0 || site >= n_cg)
     return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: bad shape");
   const int64_t total = (int64_t)S * n_cg * ld;
-  hipLaunchKernelGGL(gb_rows_kernel, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg, gauss, S, n_cg, G,
-                     n_id, n_ch, n_basis, cols, n_cols, ld, site, A, b);
+  if (g_dtype == AGGF_F32)
+    hipLaunchKernelGGL(gb_rows_kernel<float>, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg,
+                       (const float*)gauss, S, n_cg, G, n_id, n_ch, n_basis, cols, n_cols, ld, site, A, b);
+  else if (g_dtype == AGGF_F64)
+    hipLaunchKernelGGL(gb_rows_kernel<double>, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg,
+                       (const double*)gauss, S, n_cg, G, n_id, n_ch, n_basis, cols, n_cols, ld, site, A, b);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: bad feature dtype");
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

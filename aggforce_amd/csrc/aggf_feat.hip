@@ -31,7 +31,8 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict
     for (int e = threadIdx.x; e < (int)row_out; e += blockDim.x) {
       const int g = e / 3, d = e - 3 * g;
       const int b = grp_ptr[g], en = grp_ptr[g + 1];
-      const TO w = mean ? (TO)1 / (TO)(en - b) : (TO)1;
+      // mean weights are the float32 entries of the reference's smear matrix (map/tools.py:94-101), whatever TO
+      const TO w = mean ? (TO)(1.0f / (float)(en - b)) : (TO)1;
       TO acc = 0;
       for (int j = b; j < en; ++j) acc += w * (TO)src[(int64_t)grp_atoms[j] * 3 + d];
       dst[e] = acc;
@@ -39,49 +40,68 @@ __global__ __launch_bounds__(256) void group_reduce_kernel(const TIn* __restrict
   }
 }
 
+// TG = arithmetic type of positions, distances and Gaussians: float (the reference's JAX default; the default
+// here) or double (opt-in `feature_dtype=np.float64` of gb_feat: product and float64 oracle then share arithmetic)
+template <typename TG>
 struct GbParams {
-  const float* centers;  // n_basis grid centres
+  const TG* centers;  // n_basis grid centres
   int32_t n_basis;
-  float width, clip;
+  TG width, clip;
 };
 
+__device__ __forceinline__ float gb_sqrt(float x) { return sqrtf(x); }
+__device__ __forceinline__ double gb_sqrt(double x) { return sqrt(x); }
+__device__ __forceinline__ float gb_exp(float x) { return expf(x); }
+__device__ __forceinline__ double gb_exp(double x) { return exp(x); }
+__device__ __forceinline__ float gb_max(float a, float b) { return fmaxf(a, b); }
+__device__ __forceinline__ double gb_max(double a, double b) { return fmax(a, b); }
+
+// arithmetic type of the products with the forces: NumPy promotion of (force dtype, feature dtype)
+template <typename TF, typename TG>
+struct GbProd { typedef double type; };
+template <>
+struct GbProd<float, float> { typedef float type; };
+
 // distance, unit vector and Gaussian row of channel ch at frame t
-__device__ __forceinline__ void gb_geometry(const float* __restrict__ Pg, const float* __restrict__ cg,
+template <typename TG>
+__device__ __forceinline__ void gb_geometry(const TG* __restrict__ Pg, const TG* __restrict__ cg,
                                             int64_t t, int32_t G, int32_t ch, int32_t n_cg, int32_t site,
-                                            float& r, float u[3]) {
-  const float* p = Pg + (t * G + ch) * 3;
-  const float* c = cg + (t * n_cg + site) * 3;
-  const float dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
-  r = sqrtf(dx * dx + dy * dy + dz * dz);
+                                            TG& r, TG u[3]) {
+  const TG* p = Pg + (t * G + ch) * 3;
+  const TG* c = cg + (t * n_cg + site) * 3;
+  const TG dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
+  r = gb_sqrt(dx * dx + dy * dy + dz * dz);
   u[0] = dx / r;  // NaN at r == 0, like the gradient of jnp.linalg.norm
   u[1] = dy / r;
   u[2] = dz / r;
 }
 
-__device__ __forceinline__ void gb_gauss(const GbParams& gp, float r, int k, float& g, float& dg) {
-  const float arg = (r - gp.centers[k]) / gp.width;
-  const float raw = expf(-(arg * arg));
-  g = fmaxf(raw, gp.clip) - gp.clip;
-  dg = raw > gp.clip ? -2.0f * arg / gp.width * raw : 0.0f;
+template <typename TG>
+__device__ __forceinline__ void gb_gauss(const GbParams<TG>& gp, TG r, int k, TG& g, TG& dg) {
+  const TG arg = (r - gp.centers[k]) / gp.width;
+  const TG raw = gb_exp(-(arg * arg));
+  g = gb_max(raw, gp.clip) - gp.clip;
+  dg = raw > gp.clip ? (TG)-2 * arg / gp.width * raw : (TG)0;
 }
 
 // compact per-channel features: gauss[t,ch,k], grad[t,ch,k,:] = |ch| g_k'(r) u
-__global__ __launch_bounds__(256) void gb_channels_kernel(const float* __restrict__ Pg,
-                                                          const float* __restrict__ cg, int64_t T, int32_t G,
+template <typename TG>
+__global__ __launch_bounds__(256) void gb_channels_kernel(const TG* __restrict__ Pg,
+                                                          const TG* __restrict__ cg, int64_t T, int32_t G,
                                                           int32_t n_cg, int32_t site,
                                                           const float* __restrict__ sizes, int32_t n_ch,
-                                                          GbParams gp, float* __restrict__ gauss,
-                                                          float* __restrict__ grad) {
+                                                          GbParams<TG> gp, TG* __restrict__ gauss,
+                                                          TG* __restrict__ grad) {
   const int64_t total = T * n_ch;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t t = i / n_ch;
     const int ch = (int)(i - t * n_ch);
-    float r, u[3];
+    TG r, u[3];
     gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
-    const float m = sizes[ch];
+    const TG m = (TG)sizes[ch];
     for (int k = 0; k < gp.n_basis; ++k) {
-      float g, dg;
+      TG g, dg;
       gb_gauss(gp, r, k, g, dg);
       const int64_t o = i * gp.n_basis + k;
       gauss[o] = g;
@@ -96,13 +116,15 @@ __global__ __launch_bounds__(256) void gb_channels_kernel(const float* __restric
 // n_ch * n_basis Gaussian columns; columns up to ld_feat are left untouched (ignored by K1).
 // TO = storage type of R3: the products are formed in TF (the reference's arithmetic) and only then widened,
 // so a float64 R3 -- K1's in-place operand for float64 products -- holds exactly the float32 matrix.
-template <typename TF, typename TO>
-__global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
-                                                        const float* __restrict__ cg, int64_t T, int32_t G,
+template <typename TF, typename TG, typename TO>
+__global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ Fg, const TG* __restrict__ Pg,
+                                                        const TG* __restrict__ cg, int64_t T, int32_t G,
                                                         int32_t n_cg, int32_t site,
                                                         const float* __restrict__ sizes, int32_t n_id,
-                                                        int32_t n_ch, GbParams gp, TF kbt, int32_t ld_feat,
+                                                        int32_t n_ch, GbParams<TG> gp, double kbt_d, int32_t ld_feat,
                                                         TO* __restrict__ R3) {
+  typedef typename GbProd<TF, TG>::type TP;
+  const TP kbt = (TP)kbt_d;
   const int per_frame = n_id + n_ch;  // work items per frame: id columns, then channels
   const int64_t total = T * per_frame;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -118,19 +140,19 @@ __global__ __launch_bounds__(256) void gb_regmat_kernel(const TF* __restrict__ F
       continue;
     }
     const int ch = j - n_id;
-    float r, u[3];
+    TG r, u[3];
     gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
     const TF* f = Fg + (t * G + ch) * 3;
-    const TF f0 = f[0], f1 = f[1], f2 = f[2];
-    const float m = sizes[ch];
+    const TP f0 = (TP)f[0], f1 = (TP)f[1], f2 = (TP)f[2];
+    const TG m = (TG)sizes[ch];
     TO* o = row + ((int64_t)n_id + (int64_t)ch * gp.n_basis) * 3;
     for (int k = 0; k < gp.n_basis; ++k) {
-      float g, dg;
+      TG g, dg;
       gb_gauss(gp, r, k, g, dg);
-      const float s = m * dg;
-      o[k * 3 + 0] = (TO)((TF)g * f0 + kbt * (TF)(s * u[0]));
-      o[k * 3 + 1] = (TO)((TF)g * f1 + kbt * (TF)(s * u[1]));
-      o[k * 3 + 2] = (TO)((TF)g * f2 + kbt * (TF)(s * u[2]));
+      const TG s = m * dg;
+      o[k * 3 + 0] = (TO)((TP)g * f0 + kbt * (TP)(s * u[0]));
+      o[k * 3 + 1] = (TO)((TP)g * f1 + kbt * (TP)(s * u[1]));
+      o[k * 3 + 2] = (TO)((TP)g * f2 + kbt * (TP)(s * u[2]));
     }
   }
 }
@@ -174,14 +196,16 @@ __global__ __launch_bounds__(256) void gb_range_kernel(const float* __restrict__
 // Compact regression matrix: column j < n_id = group force sums; column n_id + j = the Gaussian column
 // cols[j] = ch * n_basis + k (only the listed ones).  One thread per (frame, compact column): consecutive
 // threads write consecutive 3-vectors (coalesced), the distance of a channel is recomputed per listed k.
-template <typename TF, typename TO>
-__global__ __launch_bounds__(256) void gb_regmat_cols_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
-                                                             const float* __restrict__ cg, int64_t T, int32_t G,
+template <typename TF, typename TG, typename TO>
+__global__ __launch_bounds__(256) void gb_regmat_cols_kernel(const TF* __restrict__ Fg, const TG* __restrict__ Pg,
+                                                             const TG* __restrict__ cg, int64_t T, int32_t G,
                                                              int32_t n_cg, int32_t site,
                                                              const float* __restrict__ sizes, int32_t n_id,
                                                              const int32_t* __restrict__ cols, int32_t n_cols,
-                                                             GbParams gp, TF kbt, int32_t ld_feat,
+                                                             GbParams<TG> gp, double kbt_d, int32_t ld_feat,
                                                              TO* __restrict__ R3) {
+  typedef typename GbProd<TF, TG>::type TP;
+  const TP kbt = (TP)kbt_d;
   const int per_frame = n_id + n_cols;
   const int64_t total = T * per_frame;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
@@ -198,27 +222,28 @@ __global__ __launch_bounds__(256) void gb_regmat_cols_kernel(const TF* __restric
     }
     const int full = cols[j - n_id];
     const int ch = full / gp.n_basis, k = full - ch * gp.n_basis;
-    float r, u[3], g, dg;
+    TG r, u[3], g, dg;
     gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
     gb_gauss(gp, r, k, g, dg);
     const TF* f = Fg + (t * G + ch) * 3;
-    const float s = sizes[ch] * dg;
-    o[0] = (TO)((TF)g * f[0] + kbt * (TF)(s * u[0]));
-    o[1] = (TO)((TF)g * f[1] + kbt * (TF)(s * u[1]));
-    o[2] = (TO)((TF)g * f[2] + kbt * (TF)(s * u[2]));
+    const TG s = (TG)sizes[ch] * dg;
+    o[0] = (TO)((TP)g * (TP)f[0] + kbt * (TP)(s * u[0]));
+    o[1] = (TO)((TP)g * (TP)f[1] + kbt * (TP)(s * u[1]));
+    o[2] = (TO)((TP)g * (TP)f[2] + kbt * (TP)(s * u[2]));
   }
 }
 
 // CLAMap application of the [id | gb] feature-linear map (featlinearmap.py:512-520,
 // map/core.py:428-430): out[t,c,:] = sum_f coef[c,f] * (feat_c[t]' F[t] + div_c[t])[f,:]
 // -- the divergence enters WITHOUT kbt, exactly as in the reference's trans_f.
-template <typename TF>
-__global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg, const float* __restrict__ Pg,
-                                                       const float* __restrict__ cg, int64_t T, int32_t G,
+template <typename TF, typename TG>
+__global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg, const TG* __restrict__ Pg,
+                                                       const TG* __restrict__ cg, int64_t T, int32_t G,
                                                        int32_t n_cg, const float* __restrict__ sizes,
-                                                       int32_t n_id, int32_t n_ch, GbParams gp,
+                                                       int32_t n_id, int32_t n_ch, GbParams<TG> gp,
                                                        const double* __restrict__ coef, int32_t n_feat,
                                                        double* __restrict__ out) {
+  typedef typename GbProd<TF, TG>::type TP;
   // one wave per (frame, site); lanes stride over id columns and channels
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
@@ -236,19 +261,19 @@ __global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg
       a2 += c * (double)f[2];
     }
     for (int ch = lane; ch < n_ch; ch += 64) {
-      float r, u[3];
+      TG r, u[3];
       gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
       const TF* f = Fg + (t * G + ch) * 3;
-      const float m = sizes[ch];
+      const TG m = (TG)sizes[ch];
       for (int k = 0; k < gp.n_basis; ++k) {
         const double c = cf[n_id + ch * gp.n_basis + k];
         if (c == 0.0) continue;  // columns the fit left out (identically zero over the training frames): no expf
-        float g, dg;
+        TG g, dg;
         gb_gauss(gp, r, k, g, dg);
-        const float s = m * dg;
-        a0 += c * ((double)((TF)g * f[0]) + (double)(s * u[0]));
-        a1 += c * ((double)((TF)g * f[1]) + (double)(s * u[1]));
-        a2 += c * ((double)((TF)g * f[2]) + (double)(s * u[2]));
+        const TG s = m * dg;
+        a0 += c * ((double)((TP)g * (TP)f[0]) + (double)(s * u[0]));
+        a1 += c * ((double)((TP)g * (TP)f[1]) + (double)(s * u[1]));
+        a2 += c * ((double)((TP)g * (TP)f[2]) + (double)(s * u[2]));
       }
     }
 #pragma unroll
@@ -303,9 +328,9 @@ extern "C" int aggf_group_reduce(const void* X, int64_t T, int32_t N, int in_dty
   return AGGF_OK;
 }
 
-extern "C" int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
-                                int32_t site, const float* sizes, int32_t n_ch, const float* centers,
-                                int32_t n_basis, double width, double clip, float* gauss, float* grad,
+extern "C" int aggf_gb_channels(const void* Pg, const void* cg, int g_dtype, int64_t T, int32_t G, int32_t n_cg,
+                                int32_t site, const float* sizes, int32_t n_ch, const void* centers,
+                                int32_t n_basis, double width, double clip, void* gauss, void* grad,
                                 void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!Pg || !cg || !sizes || !gauss || !grad) return fail(AGGF_ERR_ARG, "aggf_gb_channels: NULL pointer");
@@ -313,15 +338,43 @@ extern "C" int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int
     return fail(AGGF_ERR_ARG, "aggf_gb_channels: bad shape");
   int rc = check_gb(centers, n_basis, width);
   if (rc) return rc;
-  GbParams gp{centers, n_basis, (float)width, (float)clip};
-  hipLaunchKernelGGL(gb_channels_kernel, feat_grid(T * n_ch), dim3(256), 0, stream, Pg, cg, T, G, n_cg, site, sizes, n_ch, gp, gauss, grad);
+  if (g_dtype == AGGF_F32) {
+    GbParams<float> gp{(const float*)centers, n_basis, (float)width, (float)clip};
+    hipLaunchKernelGGL(gb_channels_kernel<float>, feat_grid(T * n_ch), dim3(256), 0, stream, (const float*)Pg, (const float*)cg, T, G, n_cg, site, sizes, n_ch, gp, (float*)gauss, (float*)grad);
+  } else if (g_dtype == AGGF_F64) {
+    GbParams<double> gp{(const double*)centers, n_basis, width, clip};
+    hipLaunchKernelGGL(gb_channels_kernel<double>, feat_grid(T * n_ch), dim3(256), 0, stream, (const double*)Pg, (const double*)cg, T, G, n_cg, site, sizes, n_ch, gp, (double*)gauss, (double*)grad);
+  } else {
+    return fail(AGGF_ERR_ARG, "aggf_gb_channels: bad feature dtype");
+  }
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
 
-extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+// dispatch over (force dtype, feature dtype, output dtype): out must be the promoted product dtype or float64
+#define AGGF_GB_DISPATCH(WHO, LAUNCH)                                                                          \
+  do {                                                                                                         \
+    if (g_dtype == AGGF_F32) {                                                                                 \
+      GbParams<float> gp{(const float*)centers, n_basis, (float)width, (float)clip};                           \
+      typedef float TG;                                                                                        \
+      if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32) { typedef float TF; typedef float TO; LAUNCH; }        \
+      else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64) { typedef float TF; typedef double TO; LAUNCH; }  \
+      else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64) { typedef double TF; typedef double TO; LAUNCH; } \
+      else return fail(AGGF_ERR_ARG, WHO ": bad dtype (out must be the product dtype or float64)");            \
+    } else if (g_dtype == AGGF_F64) {                                                                          \
+      GbParams<double> gp{(const double*)centers, n_basis, width, clip};                                       \
+      typedef double TG;                                                                                       \
+      if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64) { typedef float TF; typedef double TO; LAUNCH; }       \
+      else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64) { typedef double TF; typedef double TO; LAUNCH; } \
+      else return fail(AGGF_ERR_ARG, WHO ": bad dtype (float64 features give float64 products)");              \
+    } else {                                                                                                   \
+      return fail(AGGF_ERR_ARG, WHO ": bad feature dtype");                                                    \
+    }                                                                                                          \
+  } while (0)
+
+extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
                               int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
-                              int32_t n_ch, const float* centers, int32_t n_basis, double width,
+                              int32_t n_ch, const void* centers, int32_t n_basis, double width,
                               double clip, double kbt, int32_t ld_feat, void* R3, int out_dtype, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!Fg || !Pg || !cg || !sizes || !R3) return fail(AGGF_ERR_ARG, "aggf_gb_regmat: NULL pointer");
@@ -330,23 +383,18 @@ extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, cons
     return fail(AGGF_ERR_ARG, "aggf_gb_regmat: bad shape");
   int rc = check_gb(centers, n_basis, width);
   if (rc) return rc;
-  GbParams gp{centers, n_basis, (float)width, (float)clip};
   const dim3 grid = feat_grid(T * (n_id + n_ch));
-  if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((gb_regmat_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (float)kbt, ld_feat, (float*)R3);
-  else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((gb_regmat_kernel<float, double>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (float)kbt, ld_feat, (double*)R3);
-  else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((gb_regmat_kernel<double, double>), grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, (double)kbt, ld_feat, (double*)R3);
-  else
-    return fail(AGGF_ERR_ARG, "aggf_gb_regmat: bad dtype (out must be the force dtype or float64)");
+  AGGF_GB_DISPATCH("aggf_gb_regmat",
+                   hipLaunchKernelGGL((gb_regmat_kernel<TF, TG, TO>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                                      (const TG*)Pg, (const TG*)cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, kbt,
+                                      ld_feat, (TO*)R3));
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
 
-extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
                              int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, int32_t n_ch,
-                             const float* centers, int32_t n_basis, double width, double clip,
+                             const void* centers, int32_t n_basis, double width, double clip,
                              const double* coef, int32_t n_feat, double* out, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!Fg || !Pg || !cg || !sizes || !coef || !out) return fail(AGGF_ERR_ARG, "aggf_gb_apply: NULL pointer");
@@ -355,14 +403,12 @@ extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const
     return fail(AGGF_ERR_ARG, "aggf_gb_apply: bad shape");
   int rc = check_gb(centers, n_basis, width);
   if (rc) return rc;
-  GbParams gp{centers, n_basis, (float)width, (float)clip};
   const dim3 grid = feat_grid(T * n_cg * 64);
-  if (f_dtype == AGGF_F32)
-    hipLaunchKernelGGL(gb_apply_kernel<float>, grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat, out);
-  else if (f_dtype == AGGF_F64)
-    hipLaunchKernelGGL(gb_apply_kernel<double>, grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat, out);
-  else
-    return fail(AGGF_ERR_ARG, "aggf_gb_apply: bad dtype");
+  const int out_dtype = AGGF_F64;
+  AGGF_GB_DISPATCH("aggf_gb_apply",
+                   hipLaunchKernelGGL((gb_apply_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                                      (const TG*)Pg, (const TG*)cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat,
+                                      out));
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -381,9 +427,9 @@ extern "C" int aggf_gb_distance_range(const float* Pg, const float* cg, int64_t 
   return AGGF_OK;
 }
 
-extern "C" int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+extern "C" int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
                                    int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
-                                   const int32_t* cols, int32_t n_cols, const float* centers, int32_t n_basis,
+                                   const int32_t* cols, int32_t n_cols, const void* centers, int32_t n_basis,
                                    double width, double clip, double kbt, int32_t ld_feat, void* R3,
                                    int out_dtype, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
@@ -394,16 +440,11 @@ extern "C" int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const float* Pg,
     return fail(AGGF_ERR_ARG, "aggf_gb_regmat_cols: bad shape");
   int rc = check_gb(centers, n_basis, width);
   if (rc) return rc;
-  GbParams gp{centers, n_basis, (float)width, (float)clip};
   const dim3 grid = feat_grid(T * (n_id + n_cols));
-  if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((gb_regmat_cols_kernel<float, float>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, (float)kbt, ld_feat, (float*)R3);
-  else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((gb_regmat_cols_kernel<float, double>), grid, dim3(256), 0, stream, (const float*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, (float)kbt, ld_feat, (double*)R3);
-  else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((gb_regmat_cols_kernel<double, double>), grid, dim3(256), 0, stream, (const double*)Fg, Pg, cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, (double)kbt, ld_feat, (double*)R3);
-  else
-    return fail(AGGF_ERR_ARG, "aggf_gb_regmat_cols: bad dtype (out must be the force dtype or float64)");
+  AGGF_GB_DISPATCH("aggf_gb_regmat_cols",
+                   hipLaunchKernelGGL((gb_regmat_cols_kernel<TF, TG, TO>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                                      (const TG*)Pg, (const TG*)cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, kbt,
+                                      ld_feat, (TO*)R3));
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

@@ -1803,6 +1803,9 @@ static int gram_impl(const void* F, int64_t T, int32_t N, int in_dtype, int comp
     return fail(AGGF_ERR_ARG, "aggf_gram: grp_ptr and grp_atoms must be given together");
   if (n_red > N) return fail(AGGF_ERR_ARG, "aggf_gram: n_red > N");
   if (first_col < 0 || first_col % TILE != 0) return fail(AGGF_ERR_ARG, "aggf_gram_from_column: first_col must be a multiple of 128");
+  // the leading block is skipped only by the in-place LDS-DMA plan; every other plan computes (and with `accumulate`
+  // would ADD) it, so the result of accumulate + first_col would depend on pointer alignment: refused
+  if (first_col > 0 && accumulate) return fail(AGGF_ERR_ARG, "aggf_gram_from_column: accumulate != 0 needs first_col == 0");
   if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram: workspace not 256-byte aligned");
   const bool aligned = ((uintptr_t)F & 15) == 0;
   GramPlan p;

@@ -83,6 +83,21 @@ def all_reduce_minmax_(lo: torch.Tensor, hi: torch.Tensor, comm) -> None:
         dist.all_reduce(hi, op=dist.ReduceOp.MAX, group=group)
 
 
+def agree_on_min(value: int, comm, device) -> int:
+    """The smallest ``value`` over the ranks of ``comm``: for quantities every rank derives from its own
+    state (free memory, shard length) but that decide the SHAPE or NUMBER of later collectives."""
+    group = resolve_comm(comm)
+    if group is None:
+        return int(value)
+    import torch.distributed as dist
+
+    if dist.get_world_size(group) == 1:
+        return int(value)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=group)
+    return int(t.item())
+
+
 def frame_shard(n_frames: int, rank: int, world: int) -> Tuple[int, int]:
     """Contiguous [begin, end) frame range of ``rank``; sizes differ by at most one frame."""
     if not 0 <= rank < world:

@@ -335,6 +335,19 @@ class CLAMap(_Taggable):
             return self._apply(points, copoints)
         from .. import _kernels as K
 
-        # trjdot(points, scale) + trans (reference map/core.py:428-430) in one pass of kernel K3c
-        out = K.trjdot_frames(K.as_device(points), K.as_device(self.scale(copoints)), K.as_device(self.trans(copoints)))
-        return K.like_input(out, points)
+        # trjdot(points, scale) + trans (reference map/core.py:428-430).  A per-frame (3-D) scale with a full
+        # (n_steps, n_cg, 3) trans is ONE pass of kernel K3c; anything else the reference's expression accepts -- a
+        # frame-independent 2-D scale (K3), a scalar or broadcastable trans -- takes that expression literally.
+        scale, trans = self.scale(copoints), self.trans(copoints)
+        n_steps = points.shape[0]
+        if (getattr(scale, "ndim", 0) == 3 and tuple(getattr(trans, "shape", ())) == (n_steps, scale.shape[1], self.n_dim)):
+            out = K.trjdot_frames(K.as_device(points), K.as_device(scale), K.as_device(trans))
+            return K.like_input(out, points)
+        mapped = trjdot(points, scale)
+        if K.is_torch(mapped):
+            import torch
+
+            if not K.is_torch(trans):
+                trans = torch.as_tensor(np.asarray(trans), device=mapped.device)
+            return mapped + trans.to(mapped.device)
+        return mapped + (trans.cpu().numpy() if K.is_torch(trans) else trans)

@@ -30,7 +30,8 @@ import numpy as np
 
 from .. import _kernels as K
 from ..constraints import Constraints
-from ..distributed import agree_on_indices, all_reduce_minmax_, all_reduce_sum_sym_, shard_extent, take_global_frames
+from ..distributed import (agree_on_indices, agree_on_min, all_reduce_minmax_, all_reduce_sum_sym_, shard_extent,
+                           take_global_frames)
 from ..map import CLAFTMap, CLAMap, LinearMap
 from .featlinearmap import KNAME_DIVS, KNAME_FEATS, KNAME_NAMES, constraint_group_labels, id_feat
 
@@ -39,18 +40,28 @@ DIVMETHOD_BASIC = "basic"
 CLIP = 1e-3  # clipped_gauss default (jaxfeat.py:243-276)
 
 
-def gb_centers(outer: float, inner: float, n_basis: int, dist_power: float) -> np.ndarray:
-    """Gaussian grid centres, uniform in r**dist_power (jaxfeat.py:235-236), float32."""
-    grid = np.linspace(inner**dist_power, outer**dist_power, n_basis).astype(np.float32)
-    return (grid ** np.float32(1 / dist_power)).astype(np.float32)
+def gb_centers(outer: float, inner: float, n_basis: int, dist_power: float, dtype=np.float32) -> np.ndarray:
+    """Gaussian grid centres, uniform in r**dist_power (jaxfeat.py:235-236), in the feature dtype."""
+    dt = np.dtype(dtype).type
+    grid = np.linspace(inner**dist_power, outer**dist_power, n_basis).astype(dt)
+    return (grid ** dt(1 / dist_power)).astype(dt)
+
+
+def _feature_dtype(feature_dtype) -> np.dtype:
+    dt = np.dtype(np.float32 if feature_dtype is None else feature_dtype)
+    if dt not in (np.dtype(np.float32), np.dtype(np.float64)):
+        raise TypeError(f"feature_dtype must be float32 or float64, not {dt}")
+    return dt
 
 
 class _Geometry:
     """Device-side per-trajectory quantities shared by all cg sites."""
 
-    def __init__(self, coords, cmap: LinearMap, constraints: Constraints, drop_last_channel: bool):
+    def __init__(self, coords, cmap: LinearMap, constraints: Constraints, drop_last_channel: bool,
+                 feature_dtype=np.float32):
         import torch
 
+        self.fdt = K.torch_dtype(_feature_dtype(feature_dtype))
         self.ids = constraint_group_labels(cmap.n_fg_sites, constraints)
         self.G = int(self.ids.max()) + 1
         order = np.argsort(self.ids, kind="stable").astype(np.int32)
@@ -64,9 +75,10 @@ class _Geometry:
         self.grp_atoms = torch.from_numpy(order).to(self.dev)
         self.sizes = torch.from_numpy(counts.astype(np.float32)).to(self.dev)
         self.n_ch = self.G - 1 if drop_last_channel else self.G
-        # group-mean ("smeared") positions and mapped sites, float32 like the reference's JAX arrays
-        self.Pg = K.group_reduce(c, self.grp_ptr, self.grp_atoms, self.G, True, torch.float32)
-        self.cg = K.as_device(cmap(c)).to(torch.float32).contiguous()
+        # group-mean ("smeared") positions and mapped sites in the feature dtype: float32 like the reference's
+        # JAX arrays unless feature_dtype=np.float64 was asked for
+        self.Pg = K.group_reduce(c, self.grp_ptr, self.grp_atoms, self.G, True, self.fdt)
+        self.cg = K.as_device(cmap(c)).to(self.fdt).contiguous()
         # group-summed coordinate map: sum_a M[c,a] [label(a) == g]
         M = np.asarray(cmap.standard_matrix, dtype=np.float64)
         self.Mg = np.add.reduceat(M[:, order], ptr[:-1], axis=1) if self.G < M.shape[1] else M[:, order]
@@ -89,26 +101,31 @@ def gb_feat(
     lazy: bool = True,
     div_method: str = DIVMETHOD_REORDER,
     drop_last_channel: bool = True,
+    feature_dtype=np.float32,
 ):
     """Featurise each site by its distance to every mapped site (reference jaxfeat.py:20-184).
 
     Same arguments as the reference (``batch_size`` is accepted and unused; both ``div_method``
     values give the same closed-form divergence).  Returns the featuriser dictionary with
-    per-site dense float32 arrays: feats (n_frames, n_fg, n_basis*n_channels) and divs
-    (n_frames, n_basis*n_channels, 3); generators if ``lazy``.
+    per-site dense arrays: feats (n_frames, n_fg, n_basis*n_channels) and divs
+    (n_frames, n_basis*n_channels, 3); generators if ``lazy``.  ``feature_dtype`` (no reference
+    counterpart) is the arithmetic type of positions, distances and Gaussians: float32 is the
+    reference's (JAX default) and the default; float64 evaluates the same expressions in double
+    precision (the featurised fit amplifies float32 rounding of the features).
     """
     import torch
 
     if div_method not in (DIVMETHOD_REORDER, DIVMETHOD_BASIC):
         raise ValueError("Unknown method for jacobian calculation.")
-    geo = _Geometry(points, cmap, constraints, drop_last_channel)
-    centers = torch.from_numpy(gb_centers(outer, inner, n_basis, dist_power)).to(geo.dev)
+    fdt = _feature_dtype(feature_dtype)
+    geo = _Geometry(points, cmap, constraints, drop_last_channel, fdt)
+    centers = torch.from_numpy(gb_centers(outer, inner, n_basis, dist_power, fdt)).to(geo.dev)
     ids_dev = torch.from_numpy(geo.ids.astype(np.int64)).to(geo.dev)
     keep = torch.nonzero(ids_dev < geo.n_ch).flatten()
 
     def site_arrays(site: int):
         gauss, grad = K.gb_channels(geo.Pg, geo.cg, site, geo.sizes, geo.n_ch, centers, width, CLIP)
-        feats = torch.zeros((geo.T, cmap.n_fg_sites, geo.n_ch, n_basis), dtype=torch.float32, device=geo.dev)
+        feats = torch.zeros((geo.T, cmap.n_fg_sites, geo.n_ch, n_basis), dtype=geo.fdt, device=geo.dev)
         if keep.numel():
             feats[:, keep, ids_dev[keep], :] = gauss[:, ids_dev[keep], :]
         return feats.reshape(geo.T, cmap.n_fg_sites, geo.n_ch * n_basis), grad.reshape(geo.T, geo.n_ch * n_basis, 3)
@@ -142,7 +159,7 @@ def _bound_gb_kwargs(f) -> Optional[dict]:
         return None
     kw = dict(getattr(f, "kwargs", None) or getattr(f, "keywords", None) or {})
     allowed = {"outer", "inner", "n_basis", "width", "dist_power", "batch_size", "lazy", "div_method",
-               "drop_last_channel"}
+               "drop_last_channel", "feature_dtype"}
     if "outer" not in kw or not set(kw) <= allowed:
         return None
     return kw
@@ -165,19 +182,22 @@ def recognise(featurizers) -> Optional[Tuple[bool, Optional[dict]]]:
 # Leave Gaussian columns that are identically zero over the trajectory out of the Gram matrix and the solve
 # (their coefficients are exactly zero in the minimiser); tests switch it off to compare with the full system.
 COMPACT_ZERO_COLUMNS = True
-_SOLVE_MEMORY_FRACTION = 0.6  # share of the free HBM the batched solve of a chunk of sites may take
+_SOLVE_MEMORY_FRACTION = 0.6  # share of the HBM not held by live tensors that a batch of sites may take
 
 
 def _sites_per_batch(n_cg: int, n_feat: int, m: int, device) -> int:
     """How many cg sites are fitted side by side: each needs its Gram matrix, its constraint rows and one
     problem's share of the batched solver workspace.  288 GB of HBM hold all 64 sites of BASELINE config 4
-    (n_feat 6139: 0.3 GB of Gram + 0.5 GB of workspace per site)."""
+    (n_feat 6139: 0.3 GB of Gram + 0.5 GB of workspace per site).  Derived from the device's TOTAL memory minus
+    what live tensors hold (cached allocator blocks and the momentary free figure do not enter), so the value is
+    the same from step to step; under ``comm=`` the ranks still agree on the minimum (``fit_id_gb``), because
+    the batch size fixes the shape and the number of the all-reduces."""
     import torch
 
     per_site = 8 * (n_feat * n_feat + m * n_feat + m) + K.eq_qp_batched_bytes(n_feat, m, 1, 1)
-    free, _ = torch.cuda.mem_get_info(device)
-    free += torch.cuda.memory_reserved(device) - torch.cuda.memory_allocated(device)  # reusable cached blocks
-    return int(max(1, min(n_cg, (_SOLVE_MEMORY_FRACTION * free) // per_site)))
+    _, total = torch.cuda.mem_get_info(device)
+    usable = total - torch.cuda.memory_allocated(device)
+    return int(max(1, min(n_cg, (_SOLVE_MEMORY_FRACTION * usable) // per_site)))
 
 
 def fit_id_gb(
@@ -199,11 +219,12 @@ def fit_id_gb(
 
     kw = dict(gb_kwargs or {})
     drop_last = kw.pop("drop_last_channel", True)
-    geo = _Geometry(traj.coords, coord_map, constraints, drop_last)
+    fdt = _feature_dtype(kw.pop("feature_dtype", np.float32))
+    geo = _Geometry(traj.coords, coord_map, constraints, drop_last, fdt)
     n_basis = int(kw.get("n_basis", 10)) if gb_kwargs is not None else 1
     width = float(kw.get("width", 1.0))
-    centers_h = (gb_centers(kw["outer"], kw.get("inner", 0), n_basis, kw.get("dist_power", 0.5))
-                 if gb_kwargs is not None else np.zeros(1, dtype=np.float32))
+    centers_h = (gb_centers(kw["outer"], kw.get("inner", 0), n_basis, kw.get("dist_power", 0.5), fdt)
+                 if gb_kwargs is not None else np.zeros(1, dtype=fdt))
     centers = torch.from_numpy(centers_h).to(geo.dev)
     n_id = geo.G if use_id else 0
     n_ch = geo.n_ch if gb_kwargs is not None else 0
@@ -261,6 +282,7 @@ def fit_id_gb(
     # columns: those variables come out as exact zeros.
     m_rows = max(n_sel) * n_cg if n_sel else 0
     per_batch = _sites_per_batch(n_cg, n_max, m_rows, geo.dev) if len(n_sel) == 1 else 1
+    per_batch = agree_on_min(per_batch, comm, geo.dev)  # shapes and count of the collectives below depend on it
     shared_lead = None  # leading (id x id) Gram block, identical for all sites
     for c0 in range(0, n_cg, per_batch):
         sites = list(range(c0, min(n_cg, c0 + per_batch)))
@@ -313,11 +335,15 @@ def fit_id_gb(
             full[n_id + cols_of[site]] = X_host[j, n_id:n_act[site]]
             coefs[site] = full
         del Gs, As, bs, X, stats
-    fit_info = {"kept_columns": n_act, "n_feat": n_feat, "sites_per_batch": per_batch}
+    # the batched solve's scratch (up to _SOLVE_MEMORY_FRACTION of the HBM) is not kept for the life of the
+    # process: the next Gram / apply / streamed fit would find the memory gone
+    K.drop_workspace("solve", geo.dev)
+    fit_info = {"kept_columns": n_act, "n_feat": n_feat, "sites_per_batch": per_batch,
+                "kept_gauss_columns": cols_of, "feature_dtype": str(fdt)}
     coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
 
     def apply_f(points, copoints):
-        g2 = _Geometry(copoints, coord_map, constraints, drop_last)
+        g2 = _Geometry(copoints, coord_map, constraints, drop_last, fdt)
         out = K.gb_apply(g2.group_forces(points), g2.Pg, g2.cg, g2.sizes, n_id, n_ch, centers, width, CLIP,
                          coef_dev.to(g2.dev))
         return K.like_input(out, points)

@@ -56,8 +56,15 @@ METHOD_LABEL = {
     "c5": "noised joptgauss_map (var 0.01), no constraints",
     "c1": "linear qp_linear_map, CLN025 topology: 59 constraint groups (n_red 97), l2_regularization 1",
 }
+VARIANT_LABEL = {
+    "pairs": "linear qp_linear_map, bond-pair constraints {3i, 3i+1} (n_red = N - N//3)",
+    "zeronet": "linear qp_linear_map, no constraints, zero net force per frame (singular P)",
+    "dense": "linear qp_linear_map, no constraints, dense centre-of-mass coordinate map",
+}
 PEAK_TFLOPS = {"f64": 78.6, "f32": 157.3}  # dense MFMA peaks (MI355X_MICROARCH.md / SURVEY 8(d))
 SEED = 42100
+KBT_BENCH = 0.6955215
+VARIANT = "none"  # set by main(): the committed PMC profiles describe the plain c3 workload only
 
 
 def parse(argv=None):
@@ -67,6 +74,12 @@ def parse(argv=None):
     p.add_argument("--warmup", type=int, default=2)
     p.add_argument("--workload", default="c3", choices=sorted(WORKLOADS))
     p.add_argument("--frames", type=int, default=None, help="override the total frame count")
+    p.add_argument("--variant", default="none", choices=["none", "pairs", "zeronet", "dense"],
+                   help="SURVEY 8(d) synthetic-input variants of the linear workloads (c2/c3/tiny): pairs = bond-pair "
+                        "constraints {3i, 3i+1} (n_red = N - N//3: the `@ con_mat` group sums of qplinear.py:69-70); "
+                        "zeronet = every frame's forces sum to zero (isolated molecule: P singular along the all-ones "
+                        "vector, qplinear.py:71-86); dense = centre-of-mass coordinate map over contiguous blocks "
+                        "(map/core.py:219-240: a second full K3 pass instead of the slice gather)")
     p.add_argument("--cpu-frames", type=int, default=20000,
                    help="frame sample of the CPU baseline (c3: ~20 s of host work: 2 GB of forces, two 2e12-flop matmuls, "
                         "the single-threaded einsum apply)")
@@ -161,7 +174,7 @@ def profiled_traffic(workload, world):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
     (profiles/r02_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
     and counts 128-byte requests as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM): x 2."""
-    if workload != "c3" or world != 1:
+    if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_rocprof_summary.json")))
@@ -172,10 +185,25 @@ def profiled_traffic(workload, world):
         return None
 
 
+def profile_label():
+    """Where `traffic` / `mfma_busy_frac_pmc` come from: PMC passes are separate rocprofv3 runs by construction, so
+    the line quotes the committed profile and says which one (file, commit and date that last touched it)."""
+    rel = "profiles/r02_c3_rocprof_summary.json"
+    label = f"{rel} (separate rocprofv3 --pmc passes; NOT measured in this run)"
+    try:
+        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cI", "--", rel], stdout=subprocess.PIPE,
+                             stderr=subprocess.DEVNULL, timeout=10).stdout.decode().strip()
+        if out:
+            label += f"; profile committed {out}"
+    except Exception:
+        pass
+    return label
+
+
 def profiled_mfma_busy(workload, world):
     """Fraction of the Gram kernel's cycles in which the MFMA pipes were busy, from the committed PMC pass
     (profiles/r02_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
-    if workload != "c3" or world != 1:
+    if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
         d = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_mfma_counters.json")))
@@ -194,26 +222,45 @@ def blas_threads():
         return 1
 
 
-def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores):
+def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores, cmat=None, constraints=None, l2=0.0, zeronet=False,
+                 noised=None):
     """Reference operation sequence (qplinear.py:66-88, util.py:119-125, agg.py:120-136) in NumPy
-    on a frame sample; T-linear stages are scaled to T_total, the solve is counted once."""
+    on a frame sample; T-linear stages are scaled to T_total, the solve is counted once.
+    ``noised`` = (var, kbt): the joptgauss_map sequence (jgauss.py:114-131: augment, linear fit on N + n_cg sites,
+    re-augment and apply as AugmentedTMap.__call__ does, tmap.py:240-243) with NumPy's generator for the noise."""
     from oracle import aggforce_oracle as orc
 
     rng = np.random.default_rng(SEED)
     forces = (30 * rng.standard_normal((T_cpu, N, 3))).astype(np_dtype)
     coords = rng.random((T_cpu, N, 3)).astype(np_dtype)
-    cmat = orc.list_mapping_matrix([[i * (N // n_cg)] for i in range(n_cg)], N)
+    if zeronet:
+        forces -= forces.mean(axis=1, keepdims=True)
+    if cmat is None:
+        cmat = orc.list_mapping_matrix([[i * (N // n_cg)] for i in range(n_cg)], N)
+    cons = set() if constraints is None else constraints
+    t_aug = 0.0
+    fit_cmat, fit_coords, fit_forces = cmat, coords, forces
+    if noised is not None:
+        var, kbt = noised
+        ta = time.perf_counter()
+        noise = rng.standard_normal((T_cpu, n_cg, 3)).astype(np_dtype)
+        fit_coords, fit_forces = orc.augment(coords, forces, cmat, var, kbt, noise, dtype=np_dtype)
+        fit_cmat = orc.list_mapping_matrix([[x] for x in range(N, N + n_cg)], N + n_cg)
+        t_aug = time.perf_counter() - ta
     t0 = time.perf_counter()
-    pr = orc.linear_problem(forces, cmat, set(), 0.0)           # qp_form, @con_mat, Gram
+    pr = orc.linear_problem(fit_forces, fit_cmat, cons, l2)     # qp_form, @con_mat, Gram
     t1 = time.perf_counter()
     X = orc.eq_qp_solve(pr["qp_mat"], None, pr["A"], np.eye(n_cg))  # exact solve in place of OSQP
     W = (pr["con_mat"] @ X).T
     t2 = time.perf_counter()
-    mc = orc.linearmap_apply(coords, cmat)
-    mf = orc.linearmap_apply(forces, W)
+    if noised is not None:  # the returned map re-augments with fresh noise when it is applied
+        noise = rng.standard_normal((T_cpu, n_cg, 3)).astype(np_dtype)
+        fit_coords, fit_forces = orc.augment(coords, forces, cmat, noised[0], noised[1], noise, dtype=np_dtype)
+    mc = orc.linearmap_apply(fit_coords, fit_cmat)
+    mf = orc.linearmap_apply(fit_forces, W)
     res = orc.force_smoothness(mf)
     t3 = time.perf_counter()
-    lin = (t1 - t0) + (t3 - t2)
+    lin = t_aug + (t1 - t0) + (t3 - t2)
     full = lin * (T_total / T_cpu) + (t2 - t1)
     return {
         "value": T_total / full,
@@ -221,11 +268,64 @@ def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores):
         "cores": cores,
         "kind": "port",
         "sample": (f"{T_cpu} of {T_total} frames x {N} atoms on the host ({os.cpu_count()} logical cores, BLAS threads "
-                   f"= cores field; the einsum apply is single-threaded as in the reference): gram {t1 - t0:.2f}s, "
+                   f"= cores field; the einsum apply is single-threaded as in the reference): "
+                   + (f"augment {t_aug:.2f}s, " if noised is not None else "")
+                   + f"gram {t1 - t0:.2f}s (n_red {pr['qp_mat'].shape[0]}), "
                    f"solve {t2 - t1:.2f}s (exact direct solve instead of {n_cg} OSQP runs), "
-                   f"apply+residual {t3 - t2:.2f}s; T-linear stages scaled to {T_total} frames, "
+                   + ("re-augment + " if noised is not None else "")
+                   + f"apply+residual {t3 - t2:.2f}s; T-linear stages scaled to {T_total} frames, "
                    f"solve counted once"),
         "_check": float(res + mc.sum() * 0),
+    }
+
+
+def cpu_baseline_featurised(cores, n_basis=8, outer=8.0, T_cpu=500):
+    """The featurised fit in the reference's formulation cannot run at BASELINE config 4's size at all (the dense
+    one-hot feature tensor is 2e4 x 1024 x 6139 float32 = 503 GB per cg site), so the port is timed at
+    CLN025-like size -- 175 atoms, 10 CA beads, the 59 constraint groups of tests/golden/g4_cln025.npz, T_cpu
+    frames -- and the figure says so: it is NOT the same workload as `value`."""
+    from oracle import aggforce_oracle as orc
+
+    topo = np.load(os.path.join(ROOT, "tests", "golden", "g4_cln025.npz"))
+    cons = {frozenset(int(x) for x in row if x >= 0) for row in topo["pairs"]}
+    N, ca = 175, [int(i) for i in topo["ca"]]
+    cmat = orc.list_mapping_matrix([[i] for i in ca], N)
+    rng = np.random.default_rng(SEED)
+    side = 6
+    base = np.stack(np.meshgrid(*[np.arange(side)] * 3, indexing="ij"), -1).reshape(-1, 3)[:N] * 1.5
+    coords = (base[None] + 0.3 * rng.standard_normal((T_cpu, N, 3))).astype(np.float32)
+    forces = (30 * rng.standard_normal((T_cpu, N, 3))).astype(np.float32)
+    t0 = time.perf_counter()
+    ids = orc.id_feat_ids(N, cons)
+    G = int(ids.max()) + 1
+    smear = orc.smear_matrix(orc.reduce_constraint_sets(cons), N)
+    cg = orc.linearmap_apply(coords, cmat)
+    onehot = np.zeros((T_cpu, N, G), dtype=np.float32)
+    onehot[:, np.arange(N), ids] = 1
+    frames = [rng.choice(T_cpu, size=20, replace=False) for _ in ca]
+    feats, divs, coefs = [], [], []
+    for c in range(len(ca)):  # featlinearmap.py:349-384, site by site like the reference's lazy generators
+        gf, gd = orc.gb_feat_site(coords, cg[:, c, :], ids, smear, outer=outer, n_basis=n_basis, n_channels=G - 1)
+        feat = np.concatenate([onehot, gf], axis=2)
+        div = np.concatenate([np.zeros((T_cpu, G, 3), np.float32), gd], axis=1)
+        A, b = orc.feat_constraint_arrays(feat, c, cmat, frames[c])
+        _, qp_mat = orc.feat_site_problem(forces, feat, div, KBT_BENCH, 10.0)
+        coefs.append(orc.eq_qp_solve(qp_mat, None, A, b))
+        feats.append(feat)
+        divs.append(div)
+    t1 = time.perf_counter()
+    mf = orc.cla_apply(forces, feats, divs, coefs)  # the reference re-runs the featuriser here (featlinearmap.py:513,518)
+    t2 = time.perf_counter()
+    return {
+        "value": T_cpu / (t2 - t0),
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": (f"NOT this workload: the reference's dense formulation at CLN025-like size ({T_cpu} frames x {N} atoms x "
+                   f"{len(ca)} beads, 59 constraint groups, n_feat {feats[0].shape[2]}, n_basis {n_basis}, 20 constraint frames); "
+                   f"fit {t1 - t0:.2f}s, apply {t2 - t1:.2f}s (features reused, the reference recomputes them twice). At "
+                   f"config-4 size its feature tensor alone is 503 GB per site"),
+        "_check": float(np.sum(mf) * 0),
     }
 
 
@@ -266,6 +366,8 @@ def main():
     from aggforce_amd import _kernels as K
     from aggforce_amd.distributed import frame_shard
 
+    global VARIANT
+    VARIANT = args.variant
     T_total, N, n_cg, dt = WORKLOADS[args.workload]
     if args.frames:
         T_total = args.frames
@@ -278,7 +380,23 @@ def main():
     cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
     kwargs = {"comm": comm} if comm is not None else {}
     constraints = set()
-    KBT = 0.6955215
+    KBT = KBT_BENCH
+    if args.variant != "none" and args.workload not in ("c2", "c3", "tiny"):
+        raise SystemExit("--variant applies to the linear workloads c2 / c3 / tiny")
+    n_red = N
+    if args.variant == "pairs":
+        constraints = {frozenset([3 * i, 3 * i + 1]) for i in range(N // 3)}
+        n_red = N - N // 3
+    elif args.variant == "zeronet":
+        # data preparation (outside the timed region): every frame's net force removed, in place, by frame blocks
+        blk = max(1, (1 << 28) // (3 * N))
+        for t0_ in range(0, T_local, blk):
+            chunk = forces[t0_:t0_ + blk]
+            chunk -= chunk.mean(dim=1, keepdim=True)
+        del chunk
+    elif args.variant == "dense":
+        w = N // n_cg
+        cmap = LinearMap([list(range(i * w, (i + 1) * w)) for i in range(n_cg)], n_fg_sites=N)
     if args.workload == "c4":
         # bond-pair constraints {3i, 3i+1}; every cg site is a constrained atom (its smeared position
         # differs from the site, r > 0 -- as for CLN025's CA/HA; with r == 0 the reference is NaN)
@@ -355,7 +473,7 @@ def main():
         gram_ms = gram["ms"] / max(1, gram["calls"])
         gdt = "f64" if args.workload == "c4" else dt  # arithmetic type of the Gram products
         s_bytes = 8 if dt == "f64" else 4
-        n_gram = N
+        n_gram = n_red
         if args.workload == "c5":
             n_gram = N + n_cg
         elif args.workload == "c1":
@@ -384,10 +502,11 @@ def main():
             achieved = flops / (gram_ms * 1e-3) / 1e12
             kname = "gram_tile_dma_kernel<%s> (+ gram_reduce_kernel) = aggf_gram" % (
                 "double, 0, 3, 2, 8, true, false, 1, true" if gdt == "f64" else "float, 0, 3, 2, 8, true, false, 1, true")
+            if args.variant == "pairs":
+                kname = "pack_groups_kernel (constraint-group sums) + " + kname
             roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS[gdt], "traffic": profiled_traffic(args.workload, world),
-                    "traffic_source": "profiles/r02_c3_rocprof_summary.json (separate rocprofv3 --pmc passes; not measured in this run)"
-                    if profiled_traffic(args.workload, world) is not None else None,
+                    "traffic_source": profile_label() if profiled_traffic(args.workload, world) is not None else None,
                     "mfma_busy_frac_pmc": profiled_mfma_busy(args.workload, world), "ms_per_launch": gram_ms,
                     "flops_per_launch": flops}
             if gram_note:
@@ -406,8 +525,12 @@ def main():
             "dtype": dt,
             "data": "synthetic",
             "config": {
-                "workload": (f"{args.workload}: {T_total} frames x {N} atoms x {n_cg} CG beads, {METHOD_LABEL[args.workload]}, "
-                             f"{dt} trajectory, slice coord map, frames sharded over {world} GPU(s)"),
+                "workload": (f"{args.workload}{'' if args.variant == 'none' else '+' + args.variant}: {T_total} frames x {N} atoms x "
+                             f"{n_cg} CG beads, {VARIANT_LABEL.get(args.variant) or METHOD_LABEL[args.workload]}, "
+                             f"{dt} trajectory, {'dense block-average' if args.variant == 'dense' else 'slice'} coord map, "
+                             f"frames sharded over {world} GPU(s)"),
+                "variant": args.variant,
+                "n_red": n_gram,
                 "frames_per_gpu": T_local,
                 "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
                 "constraint_residual": cons_resid,
@@ -415,19 +538,29 @@ def main():
                 "collective": ("REHEARSAL: gloo, all ranks on cuda:0 -- not a measurement" if args.rehearse_on_one_gpu
                                else "RCCL all-reduce of the Gram matrix (torch.distributed backend nccl)" if comm is not None
                                else "none (single process)"),
-                "rccl_world_size_seen": world_seen if comm is not None else None,
+                "backend": (None if comm is None else "gloo" if args.rehearse_on_one_gpu else "nccl (RCCL)"),
+                "world_size_seen": world_seen if comm is not None else None,
                 "replicated_solve_max_abs_diff_across_ranks": w_spread,
             },
             "roofline": roof,
         }
-        if world == 1 and not args.no_cpu_baseline and args.workload in ("c3", "c2", "tiny"):
+        if world == 1 and not args.no_cpu_baseline:
             del out
-            cb = cpu_baseline(N, n_cg, np.float64 if dt == "f64" else np.float32, T_total,
-                              min(args.cpu_frames, T_total), blas_threads())
+            npdt = np.float64 if dt == "f64" else np.float32
+            cm_host = np.asarray(cmap.standard_matrix, dtype=np.float64)
+            if args.workload == "c4":
+                cb = cpu_baseline_featurised(blas_threads())
+            elif args.workload == "c5":
+                cb = cpu_baseline(N, n_cg, npdt, T_total, min(args.cpu_frames // 2, T_total), blas_threads(), cmat=cm_host,
+                                  noised=(0.01, KBT))
+            elif args.workload == "c1":
+                cb = cpu_baseline(N, n_cg, npdt, T_total, min(20 * args.cpu_frames, T_total), blas_threads(), cmat=cm_host,
+                                  constraints=constraints, l2=1.0)
+            else:
+                cb = cpu_baseline(N, n_cg, npdt, T_total, min(args.cpu_frames, T_total), blas_threads(), cmat=cm_host,
+                                  constraints=constraints, zeronet=args.variant == "zeronet")
             cb.pop("_check")
             line["cpu_baseline"] = cb
-        elif world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = None  # the NumPy port times the linear unconstrained path only (c2/c3)
         sys.stdout.flush()
         os.write(result_fd, (json.dumps(line) + "\n").encode())
     if comm is not None:

@@ -77,9 +77,12 @@ int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dty
  * are computed and written (both triangles); G[0:first_col, 0:first_col] is left untouched.
  * Used by the featurised fit (featlinearmap.py:361-372 per cg site): the id_feat block of the
  * regression matrix -- the group force sums -- is the same for every site, so its Gram block is
- * formed once and pasted.  No constraint groups here (F is a regression matrix).  Layouts that
- * do not take the in-place tile kernel compute everything (still correct: G is overwritten with
- * the same values). */
+ * formed once and pasted.  No constraint groups here (F is a regression matrix).  Guarantee:
+ * with accumulate == 0 every entry outside the leading block is written; the leading block is
+ * either left untouched (in-place tile kernel: N % 128 == 0, in_dtype == compute_dtype, F
+ * 16-byte aligned) or overwritten with its own correct values (any other layout computes the
+ * whole matrix), so the caller may paste its copy afterwards either way.  accumulate != 0 with
+ * first_col > 0 is refused (AGGF_ERR_ARG): the two cases would differ there. */
 int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
                           int32_t n_red, int32_t first_col, double* G, int accumulate, void* ws,
                           size_t ws_bytes, void* stream);
@@ -209,7 +212,12 @@ int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, i
  * id_feat label order (featlinearmap.py:598-609): group g = feature channel g.
  * All atoms of a group share the group-mean position, hence one distance
  * r[t,ch] = |Pg[t,ch] - cg[t,site]| and one Gaussian row
- * g_k(r) = max(exp(-((r - centers[k])/width)^2), clip) - clip  (float32, as JAX).
+ * g_k(r) = max(exp(-((r - centers[k])/width)^2), clip) - clip.
+ * g_dtype = arithmetic type of positions, distances and Gaussians (Pg, cg, centers, gauss,
+ * grad are arrays of that type): AGGF_F32 is the reference's (JAX default float32) and the
+ * default of the Python layer; AGGF_F64 (gb_feat(feature_dtype=np.float64)) evaluates the
+ * same expressions in float64.  Products with the forces are formed in the NumPy-promoted
+ * type of (f_dtype, g_dtype).  `sizes` (group sizes) is float32 either way.
  * ------------------------------------------------------------------------- */
 /* out[t,g,:] = sum (mean != 0: mean) over the atoms of group g of X[t,a,:];
  * X: (T, N, 3) in in_dtype; out: (T, n_groups, 3) in out_dtype; CSR groups. */
@@ -219,44 +227,45 @@ int aggf_group_reduce(const void* X, int64_t T, int32_t N, int in_dtype, const i
 /* compact features of cg site `site`: gauss (T, n_ch, n_basis) and
  * grad (T, n_ch, n_basis, 3) = |ch| g_k'(r) (Pg - cg)/r  (the per-channel divergence,
  * jaxfeat.py:544-565).  Pg: (T, G, 3) group means, cg: (T, n_cg, 3), sizes: G. */
-int aggf_gb_channels(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
-                     int32_t site, const float* sizes, int32_t n_ch, const float* centers,
-                     int32_t n_basis, double width, double clip, float* gauss, float* grad,
+int aggf_gb_channels(const void* Pg, const void* cg, int g_dtype, int64_t T, int32_t G, int32_t n_cg,
+                     int32_t site, const float* sizes, int32_t n_ch, const void* centers,
+                     int32_t n_basis, double width, double clip, void* gauss, void* grad,
                      void* stream);
-/* R3 (T, ld_feat, 3) in out_dtype (f_dtype, or AGGF_F64 for float32 forces: the float32
- * products widened on store, which with ld_feat % 128 == 0 is aggf_gram's in-place operand for
- * float64 products), the regression matrix of featlinearmap.py:361-369 in the
+/* R3 (T, ld_feat, 3) in out_dtype (the product type, or AGGF_F64: float32 products widened on
+ * store, which with ld_feat % 128 == 0 is aggf_gram's in-place operand for float64 products;
+ * float64 features always give AGGF_F64), the regression matrix of featlinearmap.py:361-369 in the
  * layout aggf_gram consumes: columns [0, n_id) = Fg (id_feat block, n_id = 0 or G), then
  * R3[t, n_id + ch*n_basis + k, d] = g_k(r) Fg[t,ch,d] + kbt |ch| g_k'(r) u_d for ch < n_ch.
  * Fg: (T, G, 3) group force sums in f_dtype.  Columns beyond n_id + n_ch*n_basis are not
  * written (pass n_red = that count to aggf_gram, which ignores the rest). */
-int aggf_gb_regmat(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+int aggf_gb_regmat(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
                    int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
-                   int32_t n_ch, const float* centers, int32_t n_basis, double width, double clip,
+                   int32_t n_ch, const void* centers, int32_t n_basis, double width, double clip,
                    double kbt, int32_t ld_feat, void* R3, int out_dtype, void* stream);
 /* Column compaction of the fused fit (no reference counterpart: the reference multiplies the
  * zeros).  A clipped Gaussian column (ch, k) of gb_feat (jaxfeat.py:272-276) is identically
  * zero over the trajectory if channel ch never comes within width*sqrt(ln(1/clip)) of centre
  * c_k; it then contributes nothing to P = R'R nor to the constraint rows, its coefficient in
  * the minimiser of featlinearmap.py:370-381 is exactly 0 (l2 > 0), and it can be dropped.
- * aggf_gb_distance_range: rmin/rmax (n_cg, G) float32, caller-initialised to +inf / 0, receive
+ * aggf_gb_distance_range (always float32 positions: a superset test with a safety margin):
+ *   rmin/rmax (n_cg, G) float32, caller-initialised to +inf / 0, receive
  *   the min / max over frames of |Pg[t,ch] - cg[t,site]| for ch < n_ch (atomic min/max, so
  *   several calls -- frame chunks, ranks -- accumulate).
  * aggf_gb_regmat_cols: aggf_gb_regmat restricted to the Gaussian columns cols[j] = ch*n_basis+k
  *   (j < n_cols), stored compactly: R3[t, n_id + j, :]. */
 int aggf_gb_distance_range(const float* Pg, const float* cg, int64_t T, int32_t G, int32_t n_cg,
                            int32_t n_ch, float* rmin, float* rmax, void* stream);
-int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
                         int32_t G, int32_t n_cg, int32_t site, const float* sizes, int32_t n_id,
-                        const int32_t* cols, int32_t n_cols, const float* centers, int32_t n_basis,
+                        const int32_t* cols, int32_t n_cols, const void* centers, int32_t n_basis,
                         double width, double clip, double kbt, int32_t ld_feat, void* R3,
                         int out_dtype, void* stream);
 /* out (T, n_cg, 3) float64: application of the feature-linear force map
  * (featlinearmap.py:512-520 + map/core.py:428-430) for all sites;
  * coef: (n_cg, n_feat) float64, n_feat = n_id + n_ch*n_basis. */
-int aggf_gb_apply(const void* Fg, int f_dtype, const float* Pg, const float* cg, int64_t T,
+int aggf_gb_apply(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
                   int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, int32_t n_ch,
-                  const float* centers, int32_t n_basis, double width, double clip,
+                  const void* centers, int32_t n_basis, double width, double clip,
                   const double* coef, int32_t n_feat, double* out, void* stream);
 
 /* ---------------------------------------------------------------------------
@@ -290,7 +299,7 @@ int aggf_trjdot_frames(const void* points, int p_dtype, const void* factor, int 
  *     A[(s,c), g]        = Mg[c,g]                        g < n_id
  *     A[(s,c), n_id+j]   = Mg[c,ch] * gauss[s,ch,k]       j-th Gaussian column = (ch, k)
  *   Mg (n_cg, G) float64 = coordinate map summed over each constraint group, gauss
- *   (S, n_ch, nb) float32 from aggf_gb_channels on the sampled frames.  cols == NULL: all
+ *   (S, n_ch, nb) in g_dtype from aggf_gb_channels on the sampled frames.  cols == NULL: all
  *   n_ch*nb Gaussian columns in (ch, k) order; else cols[j] = ch*nb + k for the n_cols
  *   columns kept by the compacted fit (see aggf_gb_distance_range).  A has row stride
  *   ld >= n_id + n_cols; columns beyond are zero.
@@ -303,7 +312,7 @@ int aggf_feat_contract(const void* forces, int f_dtype, const void* feat, const 
 int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t T, int32_t N, int32_t n_feat,
                               const int64_t* frame_idx, int32_t S, const double* M, int32_t n_cg,
                               int32_t site, double* A, double* b, void* stream);
-int aggf_gb_constraint_rows(const double* Mg, const float* gauss, int32_t S, int32_t n_cg, int32_t G,
+int aggf_gb_constraint_rows(const double* Mg, const void* gauss, int g_dtype, int32_t S, int32_t n_cg, int32_t G,
                             int32_t n_id, int32_t n_ch, int32_t n_basis, const int32_t* cols,
                             int32_t n_cols, int32_t ld, int32_t site, double* A, double* b, void* stream);
 int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32_t N, int32_t n_feat,

@@ -1,0 +1,60 @@
+"""GPU: bench.py itself as the driver runs it -- launcher -> torch.distributed.run -> ranks -> ONE line.
+
+The pool gives one GPU per box and RCCL refuses two ranks on one device, so the N = 2 case runs as a REHEARSAL
+(`--rehearse-on-one-gpu`: both ranks on cuda:0, gloo between them): everything of the multi-rank path except the
+transport -- frame shards, the packed all-reduce of G, the replicated solve, max-over-ranks timing, the single
+result line -- is exercised exactly as at N = 8."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_bench(*flags, timeout=600):
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    proc = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), *flags], stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, env=env, timeout=timeout, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip()]
+    assert len(lines) == 1, lines
+    return json.loads(lines[0])
+
+
+def test_bench_two_ranks_rehearsal_on_one_gpu():
+    line = run_bench("--gpus", "2", "--rehearse-on-one-gpu", "--workload", "tiny", "--steps", "2", "--warmup", "1")
+    cfg = line["config"]
+    assert line["n_gpus"] == 2 and line["value"] > 0 and line["ms_per_step"] > 0 and line["scaling"] == "strong"
+    assert cfg["replicated_solve_max_abs_diff_across_ranks"] == 0.0
+    assert cfg["world_size_seen"] == 2 and cfg["backend"] == "gloo"
+    assert not any("rccl" in k.lower() for k in cfg)              # nothing is called RCCL under gloo
+    assert "REHEARSAL" in cfg["collective"] and cfg["frames_per_gpu"] == 2048
+    assert cfg["constraint_residual"] < 1e-8
+    assert "cpu_baseline" not in line                               # rank 0 at N = 1 only
+    # the same workload in one process: same residual (the Gram matrix is summed over the shards)
+    one = run_bench("--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
+    assert one["n_gpus"] == 1 and one["config"]["backend"] is None
+    assert abs(one["config"]["residual"] / cfg["residual"] - 1.0) < 1e-9
+
+
+@pytest.mark.parametrize("variant", ["pairs", "zeronet", "dense"])
+def test_bench_variants_of_the_linear_workload(variant):
+    """SURVEY 8(d)'s synthetic-input variants, small: the line is well formed, the map is feasible, and the
+    CPU port beside it ran the same variant."""
+    line = run_bench("--workload", "tiny", "--variant", variant, "--steps", "1", "--warmup", "1", "--cpu-frames", "512")
+    cfg = line["config"]
+    assert cfg["variant"] == variant and ("+" + variant) in cfg["workload"]
+    assert cfg["constraint_residual"] < 1e-8 and line["value"] > 0
+    assert cfg["n_red"] == (256 - 256 // 3 if variant == "pairs" else 256)
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["traffic"] is None
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
+    if variant == "pairs":
+        assert "n_red 171" in line["cpu_baseline"]["sample"] and "pack_groups_kernel" in line["roofline"]["kernel"]

@@ -72,6 +72,16 @@ def test_clamap_call_with_user_scale_and_trans_matches_reference_formula():
     assert out.shape == (T, n_cg, 3) and rel(out, ref) < 1e-13
     out32 = cla(points.astype(np.float32), copoints)  # float32 points, float64 map: promoted like NumPy
     assert out32.dtype == np.float64 and rel(out32, orc.trjdot(points.astype(np.float32), scale(copoints)) + trans(copoints)) < 1e-12
+    # the reference's expression also takes a frame-independent (2-D) scale and a broadcastable trans
+    # (a map that passes the constructor's zero test must not fail when called)
+    for tr in (lambda y: 0.0, lambda y: np.full((n_cg, 3), 0.5), lambda y: np.asarray(y)[:, :n_cg, :] * 0.25):
+        flat = CLAMap(scale=lambda y: mix, trans=tr, n_fg_sites=N)
+        assert flat.n_cg_sites == n_cg
+        want = orc.trjdot(points, mix) + tr(copoints)
+        got = flat(points, copoints)
+        assert got.shape == (T, n_cg, 3) and rel(got, want) < 1e-13
+    per_frame_bcast = CLAMap(scale=scale, trans=lambda y: np.full((1, n_cg, 3), -1.5), n_fg_sites=N)
+    assert rel(per_frame_bcast(points, copoints), orc.trjdot(points, scale(copoints)) - 1.5) < 1e-13
 
 
 def _dense_featuriser(points, cmap, constraints):
@@ -232,6 +242,19 @@ def _feat_rank_worker(rank, world, port, out_dir):
     tg = fit(Tr(coords=coords, forces=forces), cmap, feat, 0.6955215, constraints=cons, n_constraint_frames=6,
              rng=np.random.default_rng(100 + rank), comm=True, fused=False)
     np.save(os.path.join(out_dir, f"gcoef{rank}.npy"), np.stack(tg.force_map.tags["coef_list"]))
+    # the ranks estimate the batch size (sites fitted side by side) from their own memory state; the
+    # estimates may differ, the batch size in use may not (it fixes the shapes and the count of the all-reduces)
+    from aggforce_amd.qp import gbfeat as gbmod
+
+    real = gbmod._sites_per_batch
+    gbmod._sites_per_batch = lambda n_cg, n_feat, m, device: (1 if rank == 0 else 3)
+    try:
+        tb = fit(Tr(coords=coords, forces=forces), cmap, feat, 0.6955215, constraints=cons, n_constraint_frames=6,
+                 rng=np.random.default_rng(100 + rank), comm=True)
+    finally:
+        gbmod._sites_per_batch = real
+    np.save(os.path.join(out_dir, f"bcoef{rank}.npy"), np.stack(tb.force_map.tags["coef_list"]))
+    np.save(os.path.join(out_dir, f"bbatch{rank}.npy"), np.array([tb.force_map.tags["fit_info"]["sites_per_batch"]]))
     dist.destroy_process_group()
 
 
@@ -250,6 +273,10 @@ def test_featurised_fit_is_replicated_across_two_ranks(tmp_path):
     assert np.array_equal(c0, c1)
     g0, g1 = np.load(tmp_path / "gcoef0.npy"), np.load(tmp_path / "gcoef1.npy")
     assert np.array_equal(g0, g1)
+    # per-rank batch-size estimates 1 and 3: both ranks used the minimum and got the same coefficients as before
+    assert np.load(tmp_path / "bbatch0.npy")[0] == np.load(tmp_path / "bbatch1.npy")[0] == 1
+    b0, b1 = np.load(tmp_path / "bcoef0.npy"), np.load(tmp_path / "bcoef1.npy")
+    assert np.array_equal(b0, b1) and rel(b0, c0) < 1e-9
     # single process on the whole trajectory with the same constraint frames
     T, N, n_cg = 400, 48, 4
     forces = K.synth_normal(T, N, torch.float32, 17, sigma=30.0)

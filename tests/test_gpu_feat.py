@@ -80,10 +80,11 @@ def test_fused_feat_fit_matches_dense_path_and_oracle(dtype):
     assert rel(cf, cd) < 2e-4
     mf, md = fused(traj), dense(traj)
     assert rel(mf.forces, md.forces) < 2e-4 and rel(mf.coords, md.coords) < 1e-6
-    # oracle: dense features in the reference's label order, exact solve.  With several sampled frames the constraint
-    # rows are nearly dependent (smallest singular value ~1e-3 of the largest) and the optimum moves with
-    # float32-level feature differences, so the end-to-end comparison uses ONE constraint frame per site
-    # (well conditioned); K4's regression matrix, the Gram and the solve are compared piecewise below.
+    # oracle: dense float32 features in the reference's label order, exact solve, with the SAME six sampled frames
+    # per site.  The Gram matrix of the oracle is formed in float64 here (forces widened): a float32 Gram, which is
+    # what featlinearmap.py:361-370 produces for float32 arrays, carries rounding noise of the order of l2 and moves
+    # the optimum by 1e-3 with the summation order alone (profiles/r03_feat_conditioning.txt); the product forms
+    # the exact Gram of its float32 regression matrix.  20 frames per site: tests/test_gpu_feat20.py.
     ids = orc.id_feat_ids(coords.shape[1], cons)  # the reference's labels: decides the dropped channel
     G = int(ids.max()) + 1
     onehot = np.zeros((60, coords.shape[1], G), dtype=np.float32)
@@ -91,12 +92,9 @@ def test_fused_feat_fit_matches_dense_path_and_oracle(dtype):
     gf, gd = oracle_feats(coords.astype(np.float32), cmat, cons, ids, G - 1, dist_power=0.5, **kw)
     feats = [np.concatenate([onehot, g], axis=2) for g in gf]
     divs = [np.concatenate([np.zeros((60, G, 3), np.float32), d], axis=1) for d in gd]
-    one = [f[:1] for f in frames]
-    fused1 = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=one, l2_regularization=10.0)
-    ocoef = orc.qp_feat_linear_map(forces, cmat, feats, divs, KBT, one, 10.0)
-    cf1 = np.stack(fused1.force_map.tags["coef_list"])
-    assert rel(cf1, np.stack(ocoef)) < 1e-3
-    assert rel(fused1(traj).forces, orc.cla_apply(forces, feats, divs, ocoef)) < 1e-3
+    ocoef = orc.qp_feat_linear_map(forces.astype(np.float64), cmat, feats, divs, KBT, frames, 10.0)
+    assert rel(cf, np.stack(ocoef)) < 1e-3
+    assert rel(mf.forces, orc.cla_apply(forces.astype(np.float64), feats, divs, ocoef)) < 1e-3
     # piecewise: regression matrix and Gram of site 1 against the oracle's
     from aggforce_amd import _kernels as K
     from aggforce_amd.qp.gbfeat import CLIP, _Geometry, gb_centers
@@ -250,7 +248,8 @@ def test_zero_column_compaction_is_exact():
     onehot[:, np.arange(N), ids] = 1
     feats = [np.concatenate([onehot, g], axis=2) for g in gf]
     divs = [np.concatenate([np.zeros((T, G, 3), np.float32), d], axis=1) for d in gd]
-    ocoef = orc.qp_feat_linear_map(forces, cmat, feats, divs, KBT, frames, 10.0)
-    # (float32 features: K4 and NumPy differ in the last bits of the Gaussians, which the fit amplifies)
-    assert rel(cs, np.stack(ocoef)) < 1e-2
-    assert rel(small(traj).forces, orc.cla_apply(forces, feats, divs, ocoef)) < 2e-3
+    # (Gram in float64, like the product's: the float32 Gram of featlinearmap.py:361-370 is only reproducible to
+    # ~1e-3 -- round 2 compared with it and had to loosen this to 1e-2 / 2e-3; profiles/r03_feat_conditioning.txt)
+    ocoef = orc.qp_feat_linear_map(forces.astype(np.float64), cmat, feats, divs, KBT, frames, 10.0)
+    assert rel(cs, np.stack(ocoef)) < 1e-3
+    assert rel(small(traj).forces, orc.cla_apply(forces.astype(np.float64), feats, divs, ocoef)) < 1e-3

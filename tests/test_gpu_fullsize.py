@@ -142,12 +142,34 @@ def test_full_size_c4_properties():
             w = coefs[c, lab] + (gauss[:, lab, :] @ coefs[c, G_lab + 8 * lab: G_lab + 8 * lab + 8] if lab < G_lab - 1 else 0.0)
             worst = max(worst, float(np.max(np.abs(w - (1.0 if cp == c else 0.0)))))
     assert worst < 1e-6, worst
-    # KKT of one site on its kept columns: P x + A' lam = 0  =>  P x lies in the row space of A
+    # KKT of one site on its kept columns: P x + A' lam = 0  =>  P x lies in the row space of A.  P = R'R + l2 I
+    # from K4 + K1 on exactly the columns the fit kept, A = the site's 20 x 64 constraint rows (K4b); the
+    # projection on the row space is a host least-squares on the (1280 x n_kept) rows.
     c = 17
     from aggforce_amd.qp import gbfeat
 
     keep_cols = np.nonzero(coefs[c, G_lab:] != 0)[0]
-    assert len(keep_cols) + G_lab <= info["kept_columns"][c]
+    kept = np.asarray(info["kept_gauss_columns"][c])
+    assert len(keep_cols) + G_lab <= info["kept_columns"][c] == G_lab + len(kept)
+    assert np.all(np.isin(keep_cols, kept))             # coefficients outside the kept set are exact zeros
+    n_act = G_lab + len(kept)
+    ld = -(-n_act // 128) * 128
+    R3 = torch.zeros((T, ld, 3), dtype=torch.float64, device="cuda")
+    cols_d = torch.from_numpy(kept.astype(np.int32)).cuda()
+    K.gb_regmat_cols(geo.group_forces(forces), geo.Pg, geo.cg, c, geo.sizes, G_lab, cols_d, centers, 1.0, CLIP, KBT, R3)
+    P = K.gram(R3, None, None, n_act, torch.float64).cpu().numpy() + 10.0 * np.eye(n_act)
+    del R3
+    fr = torch.from_numpy(np.asarray(tags["constraint_frames"][c])).cuda()
+    gauss_c, _ = K.gb_channels(geo.Pg[fr].contiguous(), geo.cg[fr].contiguous(), c, geo.sizes, G_lab - 1, centers, 1.0, CLIP)
+    Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).cuda()
+    A_c, b_c = K.gb_constraint_rows(Mg, gauss_c, len(fr), G_lab, G_lab - 1, 8, c, cols=cols_d)
+    A_c, b_c = A_c.cpu().numpy(), b_c.cpu().numpy().ravel()
+    x = np.concatenate([coefs[c, :G_lab], coefs[c, G_lab + kept]])
+    assert A_c.shape == (20 * n_cg, n_act) and np.max(np.abs(A_c @ x - b_c)) < 1e-8   # feasible
+    grad = P @ x
+    lam = np.linalg.lstsq(A_c.T, -grad, rcond=None)[0]
+    stat = np.linalg.norm(grad + A_c.T @ lam) / np.linalg.norm(grad)
+    assert stat < 1e-6, stat                            # stationary on the feasible set: x is THE minimiser (P > 0)
     mapped = tm(traj)
     assert tuple(mapped.forces.shape) == (T, n_cg, 3) and bool(torch.isfinite(K.as_device(mapped.forces)).all())
     # determinism: the same fit twice gives the same coefficients, bit for bit

@@ -325,8 +325,8 @@ def _helpers_worker(rank, world, port, out_dir):
     import torch.distributed as dist
 
     sys.path.insert(0, ROOT)
-    from aggforce_amd.distributed import (agree_on_indices, all_reduce_minmax_, frame_shard, shard_extent,
-                                          take_global_frames, world_size)
+    from aggforce_amd.distributed import (agree_on_indices, agree_on_min, all_reduce_minmax_, frame_shard,
+                                          shard_extent, take_global_frames, world_size)
 
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
     T = 23
@@ -345,6 +345,8 @@ def _helpers_worker(rank, world, port, out_dir):
     np.save(os.path.join(out_dir, f"idx{rank}.npy"), idx)
     np.save(os.path.join(out_dir, f"got{rank}.npy"), got.numpy())
     np.save(os.path.join(out_dir, f"mm{rank}.npy"), torch.stack([lo, hi]).numpy())
+    # a per-rank estimate that fixes the shape of later collectives (sites per batch of the featurised fit)
+    assert agree_on_min(7 - 3 * rank, True, local.device) == 4 and agree_on_min(5, None, local.device) == 5
     try:
         take_global_frames(local, np.array([T]), True)
         raise SystemExit("expected IndexError")

@@ -195,3 +195,31 @@ def test_gb_feat_oracle_matches_autodiff_fixture(golden):
         assert np.all(f[:, 3, nb * ids[3]] == 0) and np.all(g["clip_edge__divs"][0][:, nb * ids[3], :] == 0)
         checked += 1
     assert checked >= 1
+
+
+def test_exact_featurised_problem_is_ill_posed_when_float32_flips_the_rank():
+    """Why the featurised fit at 20 constraint frames is compared in float64 features, and in float32 only where
+    the rank is stable (tests/test_gpu_feat20.py): when a cg site is the midpoint of two unconstrained atoms, both
+    are exactly equidistant from it, their Gaussian rows coincide and the 20 n_cg constraint rows lose rank in exact
+    arithmetic.  float32 rounding makes the rows independent again at the 1e-7 level; the EXACT equality-constrained
+    optimum then enforces those rounding-level rows and moves by O(0.1) -- for the oracle itself, float32 against
+    float64 features, with everything else in float64.  No implementation can be within 1e-3 of both."""
+    from oracle.feat_cases import KBT, L2, dense_features, geometry, numerical_rank
+
+    coords, forces, cons, cmat, kw, frames = geometry("box14_degenerate")
+    f64, d64 = dense_features(coords, cmat, cons, kw, np.float64)
+    f32, d32 = dense_features(coords.astype(np.float32), cmat, cons, kw, np.float32)
+    x64 = orc.qp_feat_linear_map(forces, cmat, f64, d64, KBT, frames, L2)
+    wide = [f.astype(np.float64) for f in f32], [d.astype(np.float64) for d in d32]
+    x32 = orc.qp_feat_linear_map(forces, cmat, wide[0], wide[1], KBT, frames, L2)   # float32 FEATURES, float64 arithmetic
+    shift = []
+    for c in range(cmat.shape[0]):
+        r64, _ = orc.feat_site_problem(forces, f64[c], d64[c], KBT, 0.0)
+        r32, _ = orc.feat_site_problem(forces, wide[0][c], wide[1][c], KBT, 0.0)
+        a, b = r32 @ x32[c], r64 @ x64[c]
+        A64, _ = orc.feat_constraint_arrays(f64[c], c, cmat, frames[c])
+        A32, _ = orc.feat_constraint_arrays(f32[c], c, cmat, frames[c])
+        shift.append((numerical_rank(A32) - numerical_rank(A64), float(np.max(np.abs(a - b)) / np.max(np.abs(b)))))
+    assert [s[0] for s in shift] == [0, 0, shift[2][0], 0] and shift[2][0] > 0      # only the midpoint site flips
+    assert shift[2][1] > 1e-2                                                         # ... and its optimum moves
+    assert max(shift[0][1], shift[1][1], shift[3][1]) < 1e-5                          # the others do not
