@@ -37,28 +37,63 @@ struct GramCfg<float> {
 };
 
 // ---------------------------------------------------------------------------
+// One workgroup = 768 consecutive elements (256 reduced columns x xyz) of the packed row, for a strided set of
+// frames: a thread owns three fixed output elements, so the member atoms of their constraint groups -- the chain
+// grp_ptr -> grp_atoms -> element offset, three dependent loads per element and frame in the first version of this
+// kernel -- are looked up ONCE, outside the frame loop, and held in registers (up to PK_FAST members; larger groups
+// finish through the CSR arrays).  Inside the loop every load is independent and neighbouring threads read
+// neighbouring addresses (xyz of one atom, then the next group's atoms); workgroups with the same blockIdx.y walk
+// the same frames, so a frame row is fetched from HBM once.  Sums run in CSR order like the column sum of `@ con_mat`.
+constexpr int PK_FAST = 4;
+constexpr int PK_ELEMS = 3;  // output elements per thread
+
 template <typename TIn, typename TC>
 __global__ __launch_bounds__(256) void pack_groups_kernel(
     const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
     const int32_t* __restrict__ grp_atoms, int32_t n_red, int32_t n_pad, TC* __restrict__ out) {
   const int64_t row_in = (int64_t)N * 3;
   const int64_t row_out = (int64_t)n_pad * 3;
-  for (int64_t t = blockIdx.x; t < T; t += gridDim.x) {
+  int off[PK_ELEMS][PK_FAST], cnt[PK_ELEMS], first[PK_ELEMS], eo[PK_ELEMS];
+  int max_cnt = 0;
+#pragma unroll
+  for (int q = 0; q < PK_ELEMS; ++q) {
+    const int e = blockIdx.x * (256 * PK_ELEMS) + q * 256 + threadIdx.x;
+    eo[q] = e < (int)row_out ? e : -1;
+    const int g = e / 3, d = e - 3 * g;
+    int b = 0, n = 0;
+    if (e < (int)row_out && g < n_red) {
+      b = grp_ptr ? grp_ptr[g] : g;
+      n = grp_ptr ? grp_ptr[g + 1] - b : 1;
+    }
+    cnt[q] = n;
+    first[q] = b;
+    max_cnt = n > max_cnt ? n : max_cnt;
+#pragma unroll
+    for (int j = 0; j < PK_FAST; ++j) off[q][j] = j < n ? 3 * (grp_atoms ? grp_atoms[b + j] : b + j) + d : -1;
+  }
+  const bool big = __syncthreads_or(max_cnt > PK_FAST);
+  for (int64_t t = blockIdx.y; t < T; t += gridDim.y) {
     const TIn* src = F + t * row_in;
     TC* dst = out + t * row_out;
-    for (int e = threadIdx.x; e < (int)row_out; e += blockDim.x) {
-      const int g = e / 3, d = e - 3 * g;
-      TC acc = 0;
-      if (g < n_red) {
-        if (grp_ptr) {
-          const int b = grp_ptr[g], en = grp_ptr[g + 1];
-          for (int j = b; j < en; ++j) acc += (TC)src[(int64_t)grp_atoms[j] * 3 + d];
-        } else {
-          acc = (TC)src[e];
-        }
-      }
-      dst[e] = acc;
+    TC acc[PK_ELEMS];
+#pragma unroll
+    for (int q = 0; q < PK_ELEMS; ++q) {
+      TC a = 0;
+#pragma unroll
+      for (int j = 0; j < PK_FAST; ++j)
+        if (off[q][j] >= 0) a += (TC)src[off[q][j]];
+      acc[q] = a;
     }
+    if (big) {
+#pragma unroll
+      for (int q = 0; q < PK_ELEMS; ++q) {
+        const int d = off[q][0] % 3;
+        for (int j = PK_FAST; j < cnt[q]; ++j) acc[q] += (TC)src[(int64_t)grp_atoms[first[q] + j] * 3 + d];
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < PK_ELEMS; ++q)
+      if (eo[q] >= 0) dst[eo[q]] = acc[q];
   }
 }
 
@@ -1512,10 +1547,16 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   const size_t slab1 = (size_t)p->n_tiles * TILE * TILE * cs;  // one split
   const size_t row_bytes = (size_t)p->n_pad * 3 * cs;
   if (query) {
-    // recommended: slabs for the preferred split count + a pack chunk of <= 1 GiB
+    // recommended: slabs for the preferred split count + a pack chunk of up to 16 GiB (and at most a quarter of the
+    // HBM that is free right now).  Round 2 capped the chunk at 1 GiB: 119 pack + table + tile + reduce launches at C3
+    // with the pair constraints, 13 ms of slab sums and 2.5 ms of tile tables per step for nothing.
     p->chunk_frames = T;
     if (!p->direct) {
-      int64_t cf = (int64_t)((size_t)1 << 30) / (int64_t)row_bytes;
+      size_t free_b = 0, total_b = 0;
+      size_t cap_b = (size_t)16 << 30;
+      if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && free_b / 4 < cap_b) cap_b = free_b / 4;
+      if (cap_b < ((size_t)1 << 28)) cap_b = (size_t)1 << 28;
+      int64_t cf = (int64_t)(cap_b / row_bytes);
       if (cf < 256) cf = 256;
       if (cf > T) cf = T;
       p->chunk_frames = cf > 0 ? cf : 1;
@@ -1525,19 +1566,19 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->pack_bytes = p->direct ? 0 : round_up((int64_t)(p->chunk_frames * row_bytes), 256);
     return AGGF_OK;
   }
-  // fit into the given workspace: pack chunk gets at most half of it
+  // fit into the given workspace: the slabs of the split count the whole trajectory would like come first (at most
+  // half of the space), the pack chunk takes what is left
   p->pack_bytes = 0;
   p->chunk_frames = T;
   if (ws_bytes < table_bytes(*p) + 1024) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
   ws_bytes -= table_bytes(*p);
   size_t avail = ws_bytes;
   if (!p->direct) {
-    int64_t cf = (int64_t)(ws_bytes / 2 / row_bytes);
+    size_t slab_budget = slab1 * (size_t)choose_ksplit(p->n_entries, T, kb, slots, 1 << 20, upw) + 1024;
+    if (slab_budget > ws_bytes / 2) slab_budget = ws_bytes / 2;
+    int64_t cf = (int64_t)((ws_bytes - slab_budget) / row_bytes);
     if (cf > T) cf = T;
     if (cf < 1) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small for one packed frame");
-    int64_t cap = (int64_t)((size_t)1 << 30) / (int64_t)row_bytes;
-    if (cap < 256) cap = 256;
-    if (cf > cap) cf = cap;
     p->chunk_frames = cf;
     p->pack_bytes = (size_t)round_up((int64_t)(cf * row_bytes), 256);
     avail = ws_bytes - p->pack_bytes;
@@ -1763,8 +1804,10 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   int acc = accumulate;
   for (int64_t t0 = 0; t0 < T; t0 += p.chunk_frames) {
     const int64_t rows = (T - t0 < p.chunk_frames) ? T - t0 : p.chunk_frames;
-    int grid = (int)(rows < 4096 ? rows : 4096);
-    hipLaunchKernelGGL((pack_groups_kernel<TIn, TC>), dim3(grid), dim3(256), 0, stream,
+    const unsigned gx = (unsigned)ceil_div((int64_t)p.n_pad * 3, 256 * PK_ELEMS);
+    int64_t gy = ceil_div((int64_t)16 * device_cu_count(), gx);  // ~16 workgroups per CU in all
+    if (gy > rows) gy = rows;
+    hipLaunchKernelGGL((pack_groups_kernel<TIn, TC>), dim3(gx, (unsigned)gy), dim3(256), 0, stream,
                        F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad,
                        pack);
     AGGF_LAUNCH_OK();

@@ -484,7 +484,10 @@ __global__ __launch_bounds__(256) void crop_transpose_kernel(const double* __res
   }
 }
 
-// S[i,i] += reg * trace(S[:m,:m]) / m  for i < m  (Tikhonov shift for redundant constraint rows)
+// S[i,i] += reg * trace(S[:m,:m])  for i < m  (Tikhonov shift for redundant constraint rows).  Relative to the TRACE,
+// an upper bound of the largest eigenvalue -- not to the mean diagonal entry: with 20 n_cg sampled rows of rank ~30
+// the trace sits in a few eigenvalues, reg * trace / m fell to 1e-14 of the largest one, the level of the blocked
+// factorisation's own rounding, and an exactly redundant row produced a non-positive pivot (round 3, 100 rows).
 __global__ __launch_bounds__(256) void schur_reg_kernel(double* __restrict__ S, int m, int mpad, int64_t s_ps,
                                                         double reg) {
   __shared__ double sh[256];
@@ -497,7 +500,7 @@ __global__ __launch_bounds__(256) void schur_reg_kernel(double* __restrict__ S, 
     if ((int)threadIdx.x < w) sh[threadIdx.x] += sh[threadIdx.x + w];
     __syncthreads();
   }
-  const double shift = reg * sh[0] / m;
+  const double shift = reg * sh[0];
   for (int i = threadIdx.x; i < m; i += 256) S[(int64_t)i * mpad + i] += shift;
 }
 

@@ -100,7 +100,7 @@ int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int
  * G: (n, n) float64 (not modified).  l2_diag: n float64 or NULL (= ones).
  * A: (m, n) float64.  B: (m, nrhs) float64 or NULL (= identity, nrhs must equal m).
  * X: (nrhs, n) float64, row i = x_i.
- * schur_reg: 0 for full-row-rank A; > 0 adds schur_reg * mean(diag) to the Schur
+ * schur_reg: 0 for full-row-rank A; > 0 adds schur_reg * trace (>= the largest eigenvalue) to the Schur
  * complement so that redundant (consistent) constraint rows -- the sampled rows of
  * featlinearmap._constr_arrays -- can be factorised; the n_refine refinement steps
  * x -= P~^-1 A' S^-1 (A x - b) then remove the bias of that shift.

@@ -27,7 +27,7 @@ def system(T=40, N=14, seed=0, dtype=np.float32):
     cons = {frozenset([1, 2]), frozenset([4, 5]), frozenset([5, 6]), frozenset([10, 13])}
     # two-atom sites: no cg site coincides with a (smeared) atom, so r > 0 everywhere (at r == 0 the
     # reference's norm gradient is NaN and poisons the whole site)
-    cmat = orc.list_mapping_matrix([[0, 1], [4, 7], [8, 9], [12, 13]], N)
+    cmat = orc.list_mapping_matrix([[0, 1], [4, 7], [8, 10], [12, 13]], N)
     return coords, forces, cons, cmat
 
 
