@@ -471,6 +471,68 @@ def condnormal_augment(
     return oc, of
 
 
+def condnormal_sites(mean: torch.Tensor, var: float, kbt: float, noise: Optional[torch.Tensor], seed: int,
+                     frame_offset: int, out_dtype: torch.dtype):
+    """(y, Fa): generated-site coordinates and forces (T, n_cg, 3), the non-copy part of the extended trajectory;
+    same arithmetic and Philox stream as :func:`condnormal_augment` (aggf_condnormal_sites)."""
+    T, n_cg, _ = mean.shape
+    y = torch.empty((T, n_cg, 3), dtype=out_dtype, device=mean.device)
+    fa = torch.empty((T, n_cg, 3), dtype=out_dtype, device=mean.device)
+    if T == 0:
+        return y, fa
+    with _timed("augment"):
+        check(lib().aggf_condnormal_sites(ptr(mean), ptr(noise), int(seed) & (2**64 - 1), int(frame_offset), T, n_cg,
+                                          dtype_code(mean.dtype), float(var), float(kbt), ptr(y), ptr(fa),
+                                          dtype_code(out_dtype), stream_ptr()), "aggf_condnormal_sites")
+    return y, fa
+
+
+def gram_pair_ok(a: torch.Tensor, b: torch.Tensor) -> bool:
+    """Can aggf_gram_pair read [a | b] in place?  (same dtype, 128-multiples of sites, 16-byte aligned)"""
+    return (a.dtype == b.dtype and a.dtype in (torch.float32, torch.float64) and a.shape[0] == b.shape[0] and a.shape[0] > 0
+            and a.shape[1] % 128 == 0 and b.shape[1] % 128 == 0 and a.is_contiguous() and b.is_contiguous()
+            and a.data_ptr() % 16 == 0 and b.data_ptr() % 16 == 0)
+
+
+def gram_pair(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """Gram matrix ((Na + Nb)^2 float64) of the column-concatenation [a | b] of two (T, ., 3) arrays, read where
+    they lie (aggf_gram_pair); products in the arrays' dtype."""
+    l = lib()
+    T, N, _ = a.shape
+    N2 = b.shape[1]
+    out = torch.empty((N + N2, N + N2), dtype=torch.float64, device=a.device)
+    need = l.aggf_gram_pair_workspace_bytes(T, N, N2, dtype_code(a.dtype))
+    ws = workspace(need, a.device, "gram")
+    with _timed("gram"):
+        check(l.aggf_gram_pair(ptr(a), N, ptr(b), N2, T, dtype_code(a.dtype), ptr(out), 0, ptr(ws), need, stream_ptr()),
+              "aggf_gram_pair")
+    return out
+
+
+def augmented_gram(Gx: torch.Tensor, N: int, columns) -> torch.Tensor:
+    """Tm' Gx Tm, Tm = [[I, 0], [-C, I]]: Gram matrix of [F - Fa C | Fa] from that of [F | Fa] (aggf_augmented_gram);
+    ``columns`` = premap_columns(C, float64)."""
+    l = lib()
+    n = Gx.shape[0]
+    n2 = n - N
+    cp, ci, cv = columns
+    assert Gx.dtype == torch.float64 and cv.dtype == torch.float64 and Gx.is_contiguous()
+    out = torch.empty_like(Gx)
+    need = l.aggf_augmented_gram_workspace_bytes(N, n2)
+    ws = workspace(need, Gx.device, "auggram")
+    check(l.aggf_augmented_gram(ptr(Gx), N, n2, ptr(cp), ptr(ci), ptr(cv), ptr(out), ptr(ws), need, stream_ptr()),
+          "aggf_augmented_gram")
+    return out
+
+
+def sym_group_reduce(G: torch.Tensor, grp_ptr: torch.Tensor, grp_atoms: torch.Tensor, n_red: int) -> torch.Tensor:
+    """C' G C for the 0/1 constraint matrix given as CSR groups (aggf_sym_group_reduce)."""
+    out = torch.empty((n_red, n_red), dtype=torch.float64, device=G.device)
+    check(lib().aggf_sym_group_reduce(ptr(G.contiguous()), G.shape[0], ptr(grp_ptr), ptr(grp_atoms), n_red, ptr(out),
+                                      stream_ptr()), "aggf_sym_group_reduce")
+    return out
+
+
 # ------------------------------------------------------------------ synthetic data
 
 

@@ -79,6 +79,100 @@ __global__ __launch_bounds__(256) void augment_kernel(
   }
 }
 
+// The generated sites alone -- y and their forces -kbt r, (T, n_cg, 3) each -- by the SAME expressions as
+// augment_kernel's first loop (same Philox stream): the pieces of the extended trajectory that are not copies.
+// With them the noised maps never materialise the (T, N + n_cg, 3) arrays (aggf_gram_pair, aggf_augmented_gram).
+template <typename TA, typename TOut>
+__global__ __launch_bounds__(256) void noise_sites_kernel(const TA* __restrict__ mean, const TA* __restrict__ noise,
+                                                          uint64_t seed, int64_t frame_offset, int64_t T, int32_t n_cg,
+                                                          TA var, TA kbt, TOut* __restrict__ out_y,
+                                                          TOut* __restrict__ out_f) {
+  const int row_aug = n_cg * 3;
+  const int64_t total = T * row_aug;
+  const TA sd = (TA)sqrt((double)var);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const TA mu = mean[i];
+    TA eps;
+    if (noise) {
+      eps = noise[i];
+    } else {
+      const int64_t g = frame_offset * row_aug + i;  // (frame_offset + t) * row_aug + cd
+      double z[4];
+      normal_quad(seed, 1, g >> 2, z);
+      eps = (TA)z[g & 3];
+    }
+    const TA y = mu + sd * eps;
+    const TA r = (y - mu) / var;
+    out_y[i] = (TOut)y;
+    out_f[i] = (TOut)(kbt * (-r));
+  }
+}
+
+// G_aug = Tm' Gx Tm with Tm = [[I, 0], [-C, I]]: the Gram matrix of the extended trajectory
+// [F - Fa C | Fa] from the Gram matrix Gx of [F | Fa] (n = N + n2 columns).  C (n2 x N) arrives as compressed columns
+// (premap_columns: for atom a the entries (c, C[c,a])).  Two kernels: H = Gyy C (n2 x N), then the upper triangle of
+// G_aug, mirrored on store so that the result is exactly symmetric.
+__global__ __launch_bounds__(256) void auggram_h_kernel(const double* __restrict__ Gx, int32_t N, int32_t n2,
+                                                        const int32_t* __restrict__ cp, const int32_t* __restrict__ ci,
+                                                        const double* __restrict__ cv, double* __restrict__ H) {
+  const int64_t n = (int64_t)N + n2;
+  const int64_t total = (int64_t)n2 * N;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e / N), j = (int)(e - (int64_t)c * N);
+    double h = 0.0;
+    for (int k = cp[j]; k < cp[j + 1]; ++k) h += Gx[(N + c) * n + N + ci[k]] * cv[k];
+    H[e] = h;
+  }
+}
+
+__global__ __launch_bounds__(256) void auggram_kernel(const double* __restrict__ Gx, int32_t N, int32_t n2,
+                                                      const int32_t* __restrict__ cp, const int32_t* __restrict__ ci,
+                                                      const double* __restrict__ cv, const double* __restrict__ H,
+                                                      double* __restrict__ out) {
+  const int64_t n = (int64_t)N + n2;
+  const int64_t total = n * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t i = e / n, j = e - i * n;
+    if (j < i) continue;  // upper triangle; mirrored below
+    double v;
+    if (i >= N) {
+      v = Gx[e];  // Gyy
+    } else if (j >= N) {
+      // Gxy[i,c] - sum_{c' in col(i)} C[c',i] Gyy[c',c]
+      const int c = (int)(j - N);
+      v = Gx[e];
+      for (int k = cp[i]; k < cp[i + 1]; ++k) v -= cv[k] * Gx[(N + ci[k]) * n + N + c];
+    } else {
+      // Gxx[i,j] - sum_{col(i)} C[c,i] (Gyx[c,j] - H[c,j]) - sum_{col(j)} Gxy[i,c] C[c,j]
+      v = Gx[e];
+      for (int k = cp[i]; k < cp[i + 1]; ++k) v -= cv[k] * (Gx[(N + ci[k]) * n + j] - H[(int64_t)ci[k] * N + j]);
+      for (int k = cp[j]; k < cp[j + 1]; ++k) v -= Gx[i * n + N + ci[k]] * cv[k];
+    }
+    out[e] = v;
+    if (j > i) out[j * n + i] = v;
+  }
+}
+
+// G_red[gi, gj] = sum_{a in gi} sum_{b in gj} G[a, b]  (C' G C for the 0/1 constraint matrix C of qplinear.py:147-164),
+// upper triangle computed and mirrored
+__global__ __launch_bounds__(256) void sym_group_reduce_kernel(const double* __restrict__ G, int32_t n,
+                                                               const int32_t* __restrict__ gp,
+                                                               const int32_t* __restrict__ ga, int32_t n_red,
+                                                               double* __restrict__ out) {
+  const int64_t total = (int64_t)n_red * n_red;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int gi = (int)(e / n_red), gj = (int)(e - (int64_t)gi * n_red);
+    if (gj < gi) continue;
+    double v = 0.0;
+    for (int a = gp[gi]; a < gp[gi + 1]; ++a) {
+      const double* row = G + (int64_t)ga[a] * n;
+      for (int b = gp[gj]; b < gp[gj + 1]; ++b) v += row[ga[b]];
+    }
+    out[e] = v;
+    if (gj > gi) out[(int64_t)gj * n_red + gi] = v;
+  }
+}
+
 template <typename TIn, typename TA, typename TOut>
 static int augment_typed(const void* coords, const void* forces, int64_t T, int32_t N,
                          const int32_t* mt_ptr, const int32_t* mt_idx, const void* mt_val,
@@ -123,4 +217,61 @@ extern "C" int aggf_condnormal_augment(const void* coords, const void* forces, i
   if (traj_dtype == AGGF_F32 && aug_dtype == AGGF_F64)
     return augment_typed<float, double, double>(coords, forces, T, N, mt_ptr, mt_idx, mt_val, n_cg, mean, noise, seed, frame_offset, var, kbt, out_coords, out_forces, stream);
   return fail(AGGF_ERR_ARG, "aggf_condnormal_augment: bad dtype");
+}
+
+extern "C" int aggf_condnormal_sites(const void* mean, const void* noise, uint64_t seed, int64_t frame_offset,
+                                     int64_t T, int32_t n_cg, int aug_dtype, double var, double kbt, void* out_y,
+                                     void* out_f, int out_dtype, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!mean || !out_y || !out_f) return fail(AGGF_ERR_ARG, "aggf_condnormal_sites: NULL pointer");
+  if (T <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_condnormal_sites: empty problem");
+  if (!(var > 0.0)) return fail(AGGF_ERR_ARG, "aggf_condnormal_sites: var must be positive");
+  int64_t g = ceil_div(T * n_cg * 3, 256);
+  if (g > 16384) g = 16384;
+  const dim3 grid((unsigned)g), block(256);
+  if (aug_dtype == AGGF_F32 && out_dtype == AGGF_F32)
+    hipLaunchKernelGGL((noise_sites_kernel<float, float>), grid, block, 0, stream, (const float*)mean, (const float*)noise, seed, frame_offset, T, n_cg, (float)var, (float)kbt, (float*)out_y, (float*)out_f);
+  else if (aug_dtype == AGGF_F32 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((noise_sites_kernel<float, double>), grid, block, 0, stream, (const float*)mean, (const float*)noise, seed, frame_offset, T, n_cg, (float)var, (float)kbt, (double*)out_y, (double*)out_f);
+  else if (aug_dtype == AGGF_F64 && out_dtype == AGGF_F64)
+    hipLaunchKernelGGL((noise_sites_kernel<double, double>), grid, block, 0, stream, (const double*)mean, (const double*)noise, seed, frame_offset, T, n_cg, var, kbt, (double*)out_y, (double*)out_f);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_condnormal_sites: bad dtype (out must be the augmenter's dtype or float64)");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" size_t aggf_augmented_gram_workspace_bytes(int32_t N, int32_t n2) {
+  return (N > 0 && n2 > 0) ? (size_t)round_up((int64_t)N * n2 * 8, 256) : 0;
+}
+
+extern "C" int aggf_augmented_gram(const double* Gx, int32_t N, int32_t n2, const int32_t* c_ptr, const int32_t* c_idx,
+                                   const double* c_val, double* G_aug, void* ws, size_t ws_bytes, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Gx || !c_ptr || !c_idx || !c_val || !G_aug || !ws) return fail(AGGF_ERR_ARG, "aggf_augmented_gram: NULL pointer");
+  if (N <= 0 || n2 <= 0) return fail(AGGF_ERR_ARG, "aggf_augmented_gram: empty problem");
+  if (Gx == G_aug) return fail(AGGF_ERR_ARG, "aggf_augmented_gram: in-place transform is not supported");
+  if (ws_bytes < aggf_augmented_gram_workspace_bytes(N, n2)) return fail(AGGF_ERR_WORKSPACE, "aggf_augmented_gram: workspace too small");
+  double* H = reinterpret_cast<double*>(ws);
+  int64_t g1 = ceil_div((int64_t)N * n2, 256), g2 = ceil_div(((int64_t)N + n2) * ((int64_t)N + n2), 256);
+  if (g1 > 65535) g1 = 65535;
+  if (g2 > 65535) g2 = 65535;
+  hipLaunchKernelGGL(auggram_h_kernel, dim3((unsigned)g1), dim3(256), 0, stream, Gx, N, n2, c_ptr, c_idx, c_val, H);
+  AGGF_LAUNCH_OK();
+  hipLaunchKernelGGL(auggram_kernel, dim3((unsigned)g2), dim3(256), 0, stream, Gx, N, n2, c_ptr, c_idx, c_val, H, G_aug);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_sym_group_reduce(const double* G, int32_t n, const int32_t* grp_ptr, const int32_t* grp_atoms,
+                                     int32_t n_red, double* G_red, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!G || !grp_ptr || !grp_atoms || !G_red) return fail(AGGF_ERR_ARG, "aggf_sym_group_reduce: NULL pointer");
+  if (n <= 0 || n_red <= 0 || n_red > n) return fail(AGGF_ERR_ARG, "aggf_sym_group_reduce: bad shape");
+  if (G == G_red) return fail(AGGF_ERR_ARG, "aggf_sym_group_reduce: in-place reduction is not supported");
+  int64_t g = ceil_div((int64_t)n_red * n_red, 256);
+  if (g > 65535) g = 65535;
+  hipLaunchKernelGGL(sym_group_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, G, n, grp_ptr, grp_atoms, n_red, G_red);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
 }

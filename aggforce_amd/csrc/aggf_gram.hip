@@ -333,11 +333,15 @@ constexpr int dma_pieces_upto(int groups, int ppw, int g) {
   return n;
 }
 
+// TWO: the operand is the column-concatenation [X | X2] of two arrays that lie apart in HBM (panels 0..np1-1 from X,
+// row stride ld; the rest from X2, row stride ld2) -- the noised maps' [forces | generated-site forces], which round 2
+// materialised as one (T, N + n_cg, 3) array twice per step (aggf_gram_pair).
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, bool M32 = false,
-          int ES = 0, bool ES_DMA_AFTER = false>
+          int ES = 0, bool ES_DMA_AFTER = false, bool TWO = false>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
-    const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs) {
+    const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs,
+    const T* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   constexpr int KB = GramCfg<T>::KB;
@@ -390,6 +394,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   // reads (for the ragged last stage) and the LDS element offset of the piece
   int64_t g_off[PPW];
   int l_off[PPW], p_row[PPW];
+  const T* g_base[TWO ? PPW : 1];
+  int64_t g_ld[TWO ? PPW : 1];
+  (void)g_base;
+  (void)g_ld;
 #pragma unroll
   for (int q = 0; q < PPW; ++q) {
     const int p = wave + NW * q;
@@ -408,8 +416,16 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
       elem = cp * PE + lane * 2;
     }
     p_row[q] = r;
-    const int64_t col = (int64_t)(panel ? tj : ti) * ROW_ELEMS;
-    g_off[q] = (int64_t)r * ld + col + elem;
+    if constexpr (TWO) {
+      const int pj = panel ? tj : ti;
+      const bool second = pj >= np1;
+      g_base[q] = second ? X2 : X;
+      g_ld[q] = second ? ld2 : ld;
+      g_off[q] = (int64_t)r * g_ld[q] + (int64_t)(second ? pj - np1 : pj) * ROW_ELEMS + elem;
+    } else {
+      const int64_t col = (int64_t)(panel ? tj : ti) * ROW_ELEMS;
+      g_off[q] = (int64_t)r * ld + col + elem;
+    }
     l_off[q] = panel * PANEL_ELEMS + unit * DmaCfg<T>::UNIT_STRIDE + cp * PE;
   }
 
@@ -443,8 +459,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const int64_t t0 = t_begin + (ABL == 3 ? 0 : ABL == 4 ? (int64_t)(stage_of(s) & 7) * KB : (int64_t)stage_of(s) * KB);
     const bool row_ok = t0 + p_row[q] < t_end;
     if (row_ok) {
+      const T* src = TWO ? g_base[TWO ? q : 0] + t0 * g_ld[TWO ? q : 0] + g_off[q] : X + t0 * ld + g_off[q];
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(X + t0 * ld + g_off[q]),
+          (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(smem + (s % NBUF) * BUF_ELEMS + l_off[q]), 16, 0, 0);
     }
   };
@@ -1868,6 +1885,68 @@ extern "C" int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int 
                          const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red,
                          double* G, int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
   return gram_impl(F, T, N, in_dtype, compute_dtype, grp_ptr, grp_atoms, n_red, 0, G, accumulate, ws, ws_bytes, stream_v);
+}
+
+// Gram matrix of the column-concatenation [F | F2] without materialising it: both (T, ., 3) arrays of the same dtype
+// (which is also the arithmetic type of the products), N and N2 multiples of 128, 16-byte aligned.
+template <typename T>
+static int gram_pair_typed(const T* F, const T* F2, int64_t rows, int32_t N, int32_t N2, const GramPlan& p, char* ws,
+                           double* G, int accumulate, hipStream_t stream) {
+  constexpr int KB = GramCfg<T>::KB;
+  int32_t* tile_table = reinterpret_cast<int32_t*>(ws);
+  T* slabs = reinterpret_cast<T*>(ws + table_bytes(p));
+  const int ksplit = p.ksplit;
+  int64_t fps = round_up(ceil_div(rows, ksplit), KB);
+  if (fps < KB) fps = KB;
+  const size_t lds3 = (size_t)3 * 2 * dma_panel_elems<T>() * sizeof(T);
+  static thread_local PerDeviceOnce attr_once;
+  bool& attr_done = *attr_once.flag();
+  if (!attr_done) {
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1, true, true>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, 0);
+  AGGF_LAUNCH_OK();
+  const int64_t nblk = (int64_t)ksplit * p.n_tiles;
+  if (nblk > 0x7fffff00LL) return fail(AGGF_ERR_ARG, "gram grid too large");
+  hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, false, 1, true, true>), dim3((unsigned)round_up(nblk, 512)),
+                     dim3(512), lds3, stream, F, rows, (int64_t)N * 3, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs, F2,
+                     (int64_t)N2 * 3, N / TILE);
+  AGGF_LAUNCH_OK();
+  hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit,
+                     N + N2, accumulate, G, 0);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" size_t aggf_gram_pair_workspace_bytes(int64_t T, int32_t N, int32_t N2, int dtype) {
+  if (T <= 0 || N <= 0 || N2 <= 0) return 0;
+  return aggf_gram_workspace_bytes(T, N + N2, N + N2, dtype, dtype, 0);
+}
+
+extern "C" int aggf_gram_pair(const void* F, int32_t N, const void* F2, int32_t N2, int64_t T, int dtype, double* G,
+                              int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!F || !F2 || !G || !ws) return fail(AGGF_ERR_ARG, "aggf_gram_pair: NULL pointer");
+  if (T <= 0 || N <= 0 || N2 <= 0) return fail(AGGF_ERR_ARG, "aggf_gram_pair: empty problem");
+  if (dtype != AGGF_F32 && dtype != AGGF_F64) return fail(AGGF_ERR_ARG, "aggf_gram_pair: bad dtype");
+  if (N % TILE != 0 || N2 % TILE != 0)
+    return fail(AGGF_ERR_ARG, "aggf_gram_pair: both site counts must be multiples of 128 (concatenate and use aggf_gram otherwise)");
+  if ((((uintptr_t)F | (uintptr_t)F2) & 15) != 0) return fail(AGGF_ERR_ARG, "aggf_gram_pair: arrays must be 16-byte aligned");
+  if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram_pair: workspace not 256-byte aligned");
+  GramPlan p;
+  int rc = make_plan(T, N + N2, N + N2, dtype, dtype, false, true, ws_bytes, false, &p, 0);
+  if (rc) return rc;
+  if (!p.direct || p.staging == STAGE_SMALL) return fail(AGGF_ERR_ARG, "aggf_gram_pair: unsupported layout");
+  p.staging = STAGE_DMA8;
+  p.n_entries = p.n_tiles;
+  if (table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) > ws_bytes)
+    return fail(AGGF_ERR_WORKSPACE, "aggf_gram_pair: workspace too small");
+  char* w = reinterpret_cast<char*>(ws);
+  if (dtype == AGGF_F64)
+    return gram_pair_typed<double>((const double*)F, (const double*)F2, T, N, N2, p, w, G, accumulate, stream);
+  return gram_pair_typed<float>((const float*)F, (const float*)F2, T, N, N2, p, w, G, accumulate, stream);
 }
 
 extern "C" int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,

@@ -10,6 +10,8 @@ from abc import ABC, abstractmethod
 from typing import Callable, Final, Iterable, Tuple, TypeVar
 from warnings import warn
 
+import numpy as np
+
 from ..trajectory.augment import Augmenter
 from ..trajectory.core import (
     AugmentedTrajectory,
@@ -94,7 +96,53 @@ class AugmentedTMap(TMap):
         self.kbt: Final = kbt
 
     def __call__(self, t: Trajectory) -> Trajectory:
+        fused = self._call_without_extended_arrays(t)
+        if fused is not None:
+            return fused
         return self.tmap(AugmentedTrajectory.from_trajectory(t=t, kbt=self.kbt, augmenter=self.augmenter))
+
+    def _call_without_extended_arrays(self, t: Trajectory):
+        """``self.tmap`` on the extended trajectory [x | y], [F - Fa C | Fa] without forming it, for the map
+        joptgauss_map returns (linear force map W over N + n_cg sites, coordinate map = the generated sites):
+        W [F - Fa C | Fa] = W_N F + (W_a - W_N C') Fa, mapped coordinates = y.  None when the pieces are of
+        another kind (custom augmenters, other TMaps, NaN handling on the input)."""
+        from .. import _kernels as K
+        from .core import LinearMap
+
+        noise_sites = getattr(self.augmenter, "noise_sites", None)
+        sub = self.tmap
+        if (noise_sites is None or type(sub) is not SeperableTMap or not isinstance(sub.force_map, LinearMap)
+                or not isinstance(sub.coord_map, LinearMap) or isinstance(t, AugmentedTrajectory)):
+            return None
+        n_real = t.forces.shape[1]
+        premap = getattr(self.augmenter, "premap", None)
+        if premap is None or premap.n_fg_sites != n_real:
+            return None
+        n_aug = premap.n_cg_sites
+        W = sub.force_map.standard_matrix
+        idx = sub.coord_map._onehot_index()
+        if (W.shape[1] != n_real + n_aug or idx is None or len(idx) != n_aug
+                or not np.array_equal(idx, np.arange(n_real, n_real + n_aug))):
+            return None
+        import torch
+
+        forces = K.as_device(t.forces)
+        if forces.shape[0] == 0 or K.has_nan(forces):
+            return None  # the reference's NaN policy acts on the extended array: general path
+        y, fa, cols = noise_sites(t.coords, self.kbt)
+        cp, ci, cv = (x.cpu().numpy() for x in cols)
+        C = np.zeros((n_aug, n_real))
+        C[ci, np.repeat(np.arange(n_real), np.diff(cp))] = cv
+        W_n = np.ascontiguousarray(W[:, :n_real])
+        D = np.ascontiguousarray(W[:, n_real:] - W_n @ C.T)
+        main = LinearMap(W_n, handle_nans=False)(forces)
+        side = LinearMap(D, handle_nans=False)(fa)
+        if main.dtype != torch.float64 or side.dtype != torch.float64:
+            main, side = main.to(torch.float64), side.to(torch.float64)
+        out = K.axpby(1.0, main, 1.0, side, out=main)
+        if out.dtype != K.torch_dtype(np.result_type(K.np_dtype_of(t.forces), W.dtype)):
+            out = out.to(K.torch_dtype(np.result_type(K.np_dtype_of(t.forces), W.dtype)))
+        return Trajectory(coords=K.like_input(y, t.coords), forces=K.like_input(out, t.forces))
 
     def astype(self, *args, **kwargs) -> "AugmentedTMap":
         return self.__class__(

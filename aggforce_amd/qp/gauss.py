@@ -53,12 +53,58 @@ def joptgauss_map(
     augmenter = CondNormal(var=var, premap=coord_map, seed=seed, frame_offset=frame_offset)
     if noise is not None:
         augmenter.inject_noise(*noise)
+    fused = _joptgauss_without_extended_arrays(traj, augmenter, kbt, constraints, kwargs)
+    if fused is not None:
+        return fused
     aug_traj = AugmentedTrajectory.from_trajectory(t=traj, augmenter=augmenter, kbt=kbt)
     # constraints are index sets over the real sites, which keep their indices (the generated
     # sites are appended at the end)
     aug_tmap = qp_linear_map(
         traj=aug_traj, coord_map=lmap_augvariables(aug_traj), constraints=constraints, **kwargs
     )
+    return AugmentedTMap(aug_tmap=aug_tmap, augmenter=augmenter, kbt=kbt)
+
+
+def _joptgauss_without_extended_arrays(traj, augmenter, kbt, constraints, kwargs):
+    """joptgauss_map's fit without the (n_frames, N + n_cg, 3) arrays, or None when the layout does not allow it.
+
+    The extended forces are [F - Fa C | Fa] (Fa = the generated sites' forces, C = the premap), so their Gram
+    matrix is Tm' Gx Tm with Gx the Gram matrix of [F | Fa] -- K1 reads F where it lies and the small Fa beside it
+    (``aggf_gram_pair``), ``aggf_augmented_gram`` applies Tm, constraint groups are summed on the matrix
+    (``aggf_sym_group_reduce``).  Round 2 wrote and re-read 2 x 13 GB of copies per fit at BASELINE config 4's size
+    (and again per application): 19.5 % of the step.  Needs N and n_cg to be multiples of 128 (K1's in-place
+    layout), float32/float64 forces in the augmenter's promoted dtype and products in that dtype; anything else
+    takes the general path."""
+    from ..distributed import all_reduce_sum_sym_
+    from .qplinear import LinearProblem
+
+    extra = set(kwargs) - {"l2_regularization", "solver_args", "gram_dtype", "comm"}
+    if extra or not isinstance(traj, Trajectory) or isinstance(traj, AugmentedTrajectory):
+        return None
+    forces = K.as_device(traj.forces)
+    n_real, n_aug = forces.shape[1], augmenter.premap.n_cg_sites
+    gram_dtype = kwargs.get("gram_dtype")
+    if (forces.shape[0] == 0 or n_real % 128 or n_aug % 128
+            or (gram_dtype is not None and K.torch_dtype(gram_dtype) != forces.dtype)):
+        return None
+    coords = K.as_device(traj.coords)
+    import torch
+
+    if (torch.promote_types(coords.dtype, K.torch_dtype(augmenter.dtype)) != forces.dtype
+            or not forces.is_contiguous() or forces.data_ptr() % 16):
+        return None
+    y, fa, cols = augmenter.noise_sites(coords, kbt)
+    assert K.gram_pair_ok(forces, fa)
+    del y
+    Gx = K.gram_pair(forces, fa)
+    all_reduce_sum_sym_(Gx, kwargs.get("comm"))  # linear in Gx: the transform commutes with the sum over ranks
+    G = K.augmented_gram(Gx, n_real, cols)
+    del Gx
+    aug_cmap = LinearMap(mapping=[[i] for i in range(n_real, n_real + n_aug)], n_fg_sites=n_real + n_aug)
+    prob = LinearProblem(aug_cmap, constraints, forces.device)
+    if prob.grp_ptr is not None:
+        G = K.sym_group_reduce(G, prob.grp_ptr, prob.grp_atoms, prob.n_red)
+    aug_tmap = prob.tmap(prob.solve(G, float(kwargs.get("l2_regularization", 0.0))))
     return AugmentedTMap(aug_tmap=aug_tmap, augmenter=augmenter, kbt=kbt)
 
 

@@ -106,6 +106,25 @@ class CondNormal(Augmenter):
                                       self.frame_offset)
         return K.like_input(oc, coords), K.like_input(of, coords)
 
+    def noise_sites(self, coords, kbt: float):
+        """(y, Fa, C columns): the generated sites' coordinates and forces -kbt r as device arrays (n_frames,
+        n_generated, 3) and the correction matrix C (compressed columns, float64) with which the extended forces
+        are [F - Fa C | Fa] -- everything of ``augment_trajectory`` except the copies (same noise, same stream
+        bookkeeping).  Used by the noised maps to fit and apply without the (n_frames, N + n_generated, 3) arrays."""
+        import torch
+
+        c = K.as_device(coords)
+        M = self._matrix(c.shape[1])
+        m_dev = torch.from_numpy(np.ascontiguousarray(M)).to(c.device)
+        mean = self._mean(c, m_dev, M)
+        noise = self._next_noise(c.device)
+        stream_seed = self.seed + 0x9E3779B97F4A7C15 * self._calls
+        self._calls += 1
+        out_dtype = torch.promote_types(c.dtype, K.torch_dtype(self.dtype))
+        y, fa = K.condnormal_sites(mean, self.var, kbt, noise, stream_seed, self.frame_offset, out_dtype)
+        cols = K.premap_columns(self._correction_matrix(M).astype(np.float64), torch.float64, c.device)
+        return y, fa, cols
+
     def sample(self, source):
         import torch
 

@@ -201,6 +201,34 @@ int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, i
                             int64_t frame_offset, double var, double kbt, void* out_coords,
                             void* out_forces, void* stream);
 
+/* The noised maps without the extended trajectory (qp/jgauss.py:114-131 runs qp_linear_map on the
+ * (T, N + n_cg, 3) arrays that AugmentedTrajectory._augment concatenates, trajectory/core.py:382-390).
+ * The extended forces are [F - Fa C | Fa] with Fa = -kbt r the generated sites' forces (T, n_cg, 3) and
+ * C (n_cg x N) the premap (or premap x source_postmap'), so their Gram matrix is Tm' Gx Tm with Gx the
+ * Gram matrix of the plain concatenation [F | Fa] and Tm = [[I, 0], [-C, I]]:
+ *   aggf_condnormal_sites  y (generated coordinates) and Fa, (T, n_cg, 3) each, by the same expressions and
+ *                          the same Philox stream as aggf_condnormal_augment (out_dtype: aug_dtype or AGGF_F64);
+ *   aggf_gram_pair         Gx ((N + N2)^2 float64) of [F | F2] read where they lie: same dtype for both arrays
+ *                          and the products, N % 128 == 0, N2 % 128 == 0, 16-byte aligned (otherwise
+ *                          AGGF_ERR_ARG: concatenate and call aggf_gram); workspace as aggf_gram's for N + N2 sites;
+ *   aggf_augmented_gram    G_aug = Tm' Gx Tm (exactly symmetric); C as compressed columns: for atom a the entries
+ *                          c_idx[k], c_val[k], k in [c_ptr[a], c_ptr[a+1]);
+ *   aggf_sym_group_reduce  C' G C for the 0/1 constraint matrix of qplinear.py:147-164 given as CSR groups
+ *                          (what aggf_gram's fused group sums give when it reads the trajectory itself).
+ * The map is applied the same way: W [F - Fa C | Fa] = W_N F + (W_a - W_N C') Fa -- two aggf_linearmap_apply
+ * calls and an aggf_daxpby, mapped coordinates = y. */
+int aggf_condnormal_sites(const void* mean, const void* noise, uint64_t seed, int64_t frame_offset, int64_t T,
+                          int32_t n_cg, int aug_dtype, double var, double kbt, void* out_y, void* out_f,
+                          int out_dtype, void* stream);
+size_t aggf_gram_pair_workspace_bytes(int64_t T, int32_t N, int32_t N2, int dtype);
+int aggf_gram_pair(const void* F, int32_t N, const void* F2, int32_t N2, int64_t T, int dtype, double* G,
+                   int accumulate, void* ws, size_t ws_bytes, void* stream);
+size_t aggf_augmented_gram_workspace_bytes(int32_t N, int32_t n2);
+int aggf_augmented_gram(const double* Gx, int32_t N, int32_t n2, const int32_t* c_ptr, const int32_t* c_idx,
+                        const double* c_val, double* G_aug, void* ws, size_t ws_bytes, void* stream);
+int aggf_sym_group_reduce(const double* G, int32_t n, const int32_t* grp_ptr, const int32_t* grp_atoms,
+                          int32_t n_red, double* G_red, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K4  Gaussian-basis distance featuriser (gb_feat) and the featurised regression
  *     matrix, without the one-hot (T, N, n_feat) feature tensor.

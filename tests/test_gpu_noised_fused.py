@@ -1,0 +1,129 @@
+"""GPU: the noised map (joptgauss_map, qp/jgauss.py:27-140) WITHOUT the extended (T, N + n_cg, 3) arrays.
+
+When N and n_cg are multiples of 128 the fit reads the forces where they lie (aggf_gram_pair on [F | Fa]), transforms
+the Gram matrix (aggf_augmented_gram, aggf_sym_group_reduce) and the returned map is applied as
+W_N F + (W_a - W_N C') Fa.  Checked against the CPU oracle (which concatenates, like the reference) with injected
+noise, and against the general path of the product itself."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from aggforce_amd import LinearMap, Trajectory, joptgauss_map, project_forces  # noqa: E402
+from aggforce_amd import _kernels as K  # noqa: E402
+from aggforce_amd.qp import gauss as gauss_mod  # noqa: E402
+from oracle import aggforce_oracle as orc  # noqa: E402
+
+KBT, VAR = 0.6955215, 0.04
+
+
+def rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+
+def case(name):
+    rng = np.random.default_rng(31)
+    if name == "slice_f32":
+        T, N, n_cg, dt = 700, 256, 128, np.float32
+        cmat = orc.list_mapping_matrix([[2 * i] for i in range(n_cg)], N)
+        cons, l2 = set(), 0.0
+    elif name == "dense_f64_constraints":
+        T, N, n_cg, dt = 900, 384, 128, np.float64
+        cmat = orc.list_mapping_matrix([[3 * i, 3 * i + 1, 3 * i + 2] for i in range(n_cg)], N)
+        cons, l2 = {frozenset([6 * i, 6 * i + 1]) for i in range(40)} | {frozenset([6 * i + 1, 6 * i + 4]) for i in range(0, 40, 3)}, 0.5
+    else:
+        raise KeyError(name)
+    coords = (5 * rng.random((T, N, 3))).astype(dt)
+    forces = (30 * rng.standard_normal((T, N, 3))).astype(dt)
+    eps = [rng.standard_normal((T, n_cg, 3)).astype(np.float32) for _ in range(2)]
+    return coords, forces, cmat, cons, l2, eps, dt
+
+
+@pytest.mark.parametrize("name", ["slice_f32", "dense_f64_constraints"])
+def test_noised_map_without_extended_arrays_matches_oracle_and_general_path(name, monkeypatch):
+    coords, forces, cmat, cons, l2, eps, dt = case(name)
+    N, n_cg = cmat.shape[1], cmat.shape[0]
+    cmap = LinearMap(cmat)
+    traj = Trajectory(coords=coords, forces=forces)
+    calls = {"pair": 0}
+    real_pair = K.gram_pair
+    monkeypatch.setattr(K, "gram_pair", lambda a, b: (calls.__setitem__("pair", calls["pair"] + 1), real_pair(a, b))[1])
+    tm = joptgauss_map(traj, cmap, var=VAR, kbt=KBT, constraints=cons, noise=list(eps), l2_regularization=l2)
+    assert calls["pair"] == 1                                           # the fit took the in-place path
+    W = tm.tmap.force_map.standard_matrix
+    o = orc.joptgauss_force_map(coords, forces, cmat, VAR, KBT, eps[0], cons, l2, dtype=np.float32 if dt == np.float32 else np.float64)
+    # float32: MFMA products in float32 against the oracle's float64 Gram (BASELINE's float32 bound); float64
+    # trajectories: the augmenter still works in float32 like the reference's JCondNormal (jaxgausstraj.py:202-206),
+    # the oracle here in float64 -- the generated sites differ at the 1e-7 level
+    tol = 1e-3 if dt == np.float32 else 2e-5
+    assert W.shape == (n_cg, N + n_cg) and rel(W, o["force_map"]) < tol, rel(W, o["force_map"])
+    assert np.max(np.abs(o["aug_coord_matrix"] @ W.T - np.eye(n_cg))) < 1e-8
+    # application: fresh noise eps[1]; the oracle concatenates and applies W to the extended forces
+    big = {"n": 0}
+    real_aug = K.condnormal_augment
+    monkeypatch.setattr(K, "condnormal_augment", lambda *a, **k: (big.__setitem__("n", big["n"] + 1), real_aug(*a, **k))[1])
+    mapped = tm(traj)
+    assert big["n"] == 0                                                # no extended array was built
+    full_c, full_f = orc.augment(coords, forces, cmat, VAR, KBT, eps[1], dtype=np.float32 if dt == np.float32 else np.float64)
+    want_f = orc.linearmap_apply(full_f, o["force_map"])
+    assert rel(mapped.coords, full_c[:, N:, :]) < 1e-6
+    assert rel(mapped.forces, want_f) < tol
+    # ... and the product's own general path (extended arrays, aggf_gram on them) with the same noise
+    monkeypatch.setattr(gauss_mod, "_joptgauss_without_extended_arrays", lambda *a, **k: None)
+    gen = joptgauss_map(traj, cmap, var=VAR, kbt=KBT, constraints=cons, noise=list(eps), l2_regularization=l2)
+    assert calls["pair"] == 1
+    assert rel(W, gen.tmap.force_map.standard_matrix) < (1e-3 if dt == np.float32 else 1e-9)
+    monkeypatch.setattr(type(gen), "_call_without_extended_arrays", lambda self, t: None)
+    mapped_gen = gen(traj)
+    assert big["n"] == 1
+    assert rel(mapped_gen.forces, mapped.forces) < (1e-3 if dt == np.float32 else 1e-9)
+    assert rel(mapped_gen.coords, mapped.coords) < 1e-6
+
+
+def test_gram_pair_and_augmented_gram_kernels():
+    """aggf_gram_pair == aggf_gram of the concatenation (bit for bit: same tiles, same order); aggf_augmented_gram and
+    aggf_sym_group_reduce against dense NumPy algebra."""
+    rng = np.random.default_rng(5)
+    for dt, T, N, N2 in [(torch.float64, 333, 256, 128), (torch.float32, 1000, 384, 256), (torch.float64, 64, 128, 128)]:
+        a = torch.from_numpy(rng.standard_normal((T, N, 3))).to(dt).cuda()
+        b = torch.from_numpy(rng.standard_normal((T, N2, 3))).to(dt).cuda()
+        assert K.gram_pair_ok(a, b)
+        Gp = K.gram_pair(a, b)
+        Gc = K.gram(torch.cat([a, b], dim=1).contiguous(), None, None, N + N2, dt)
+        assert torch.equal(Gp, Gc)
+    assert not K.gram_pair_ok(a[:, :100].contiguous(), b)
+    n, n2 = 200, 56
+    X = rng.standard_normal((n + n2, n + n2))
+    Gx = X @ X.T
+    C = np.where(rng.random((n2, n)) < 0.03, rng.standard_normal((n2, n)), 0.0)
+    cols = K.premap_columns(C, torch.float64, "cuda")
+    got = K.augmented_gram(torch.from_numpy(Gx).cuda(), n, cols).cpu().numpy()
+    Tm = np.block([[np.eye(n), np.zeros((n, n2))], [-C, np.eye(n2)]])
+    assert rel(got, Tm.T @ Gx @ Tm) < 1e-13 and np.array_equal(got, got.T)
+    cons = {frozenset([0, 5]), frozenset([5, 9]), frozenset([20, 21, 22]), frozenset([100, 255])}
+    Cm = orc.make_bond_constraint_matrix(n + n2, cons)
+    from aggforce_amd.constraints import group_layout, groups_csr
+
+    goa, n_red = group_layout(n + n2, cons)
+    gp, ga = groups_csr(goa, n_red)
+    red = K.sym_group_reduce(torch.from_numpy(Gx).cuda(), torch.from_numpy(gp).cuda(), torch.from_numpy(ga).cuda(), n_red)
+    assert rel(red.cpu().numpy(), Cm.T @ Gx @ Cm) < 1e-13
+
+
+def test_project_forces_with_noised_method_in_place():
+    """Through project_forces (method=joptgauss_map) on device arrays, Philox noise: feasibility, finiteness and the
+    residual identity mean(mapped^2) ~ x'G x / (3 T n_cg) up to the fresh noise of the application."""
+    T, N, n_cg = 20000, 512, 128
+    forces = K.synth_normal(T, N, torch.float32, 1, sigma=30.0)
+    coords = K.synth_normal(T, N, torch.float32, 2, sigma=0.3, lattice=1.5)
+    cmap = LinearMap([[4 * i] for i in range(n_cg)], n_fg_sites=N)
+    out = project_forces(coords, forces, cmap, constrained_inds=None, method=joptgauss_map, var=0.01, kbt=KBT, seed=3)
+    W = out["tmap"].tmap.force_map.standard_matrix
+    assert W.shape == (n_cg, N + n_cg) and np.max(np.abs(W[:, N:] - np.eye(n_cg))) < 1e-9
+    assert tuple(out["mapped_forces"].shape) == (T, n_cg, 3) and bool(torch.isfinite(out["mapped_forces"]).all())
+    assert tuple(out["mapped_coords"].shape) == (T, n_cg, 3)
+    dev = out["mapped_coords"].double() - coords[:, ::4, :][:, :n_cg].double()
+    assert abs(dev.var().item() / 0.01 - 1.0) < 2e-2
+    assert np.isfinite(out["residual"]) and out["residual"] > 0
