@@ -205,6 +205,21 @@ def eq_qp_solve(
     return X, stats
 
 
+def eq_qp_solve_pinned(G: torch.Tensor, l2: float, l2_diag: Optional[torch.Tensor], pin_idx: torch.Tensor):
+    """X (m, n) and stats (4,) for one-hot constraint rows: row i of the constraint matrix is the unit vector at
+    pin_idx[i] (int32 device array, distinct entries), right-hand sides = identity; see aggf_eq_qp_solve_pinned."""
+    l = lib()
+    n, m = G.shape[0], pin_idx.numel()
+    X = torch.empty((m, n), dtype=torch.float64, device=G.device)
+    stats = torch.empty(4, dtype=torch.float64, device=G.device)
+    need = l.aggf_eq_qp_pinned_workspace_bytes(n, m)
+    ws = workspace(need, G.device, "solve")
+    with _timed("solve"):
+        check(l.aggf_eq_qp_solve_pinned(ptr(G), n, float(l2), ptr(l2_diag), ptr(pin_idx), m, ptr(X), ptr(stats), ptr(ws),
+                                        need, stream_ptr()), "aggf_eq_qp_solve_pinned")
+    return X, stats
+
+
 def eq_qp_batched_bytes(n: int, m: int, nrhs: int, n_problems: int) -> int:
     return int(lib().aggf_eq_qp_batched_workspace_bytes(n, m, nrhs, n_problems))
 

@@ -439,7 +439,9 @@ __global__ void fix_pad_diag_kernel(double* __restrict__ S, int m, int mpad, int
   if (i < mpad) S[(int64_t)i * mpad + i] = 1.0;
 }
 
-// R -= Bp elementwise on (rows x cols), then out[0] = max |R| over the valid block
+// R -= Bp elementwise on (rows x cols), then out[0] = max(out[0], max |R| over the valid block); out[0] must hold 0
+// (or an earlier maximum) on entry: the workgroups of a problem combine through an atomic max on the bit pattern of
+// the non-negative double (order-preserving; NaN is reported as +inf).  One workgroup took 104 us per call.
 __global__ __launch_bounds__(256) void resid_kernel(double* __restrict__ R, const double* __restrict__ Bp,
                                                     int rows, int cols, int ld, int64_t mat_ps,
                                                     double* __restrict__ out, int64_t out_ps) {
@@ -448,7 +450,7 @@ __global__ __launch_bounds__(256) void resid_kernel(double* __restrict__ R, cons
   Bp += blockIdx.y * mat_ps;
   double m = 0.0;
   const int64_t total = (int64_t)rows * cols;
-  for (int64_t e = threadIdx.x; e < total; e += 256) {
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
     const int i = (int)(e / cols), j = (int)(e - (int64_t)i * cols);
     const double v = R[(int64_t)i * ld + j] - Bp[(int64_t)i * ld + j];
     R[(int64_t)i * ld + j] = v;
@@ -461,8 +463,11 @@ __global__ __launch_bounds__(256) void resid_kernel(double* __restrict__ R, cons
     if ((int)threadIdx.x < w) sh[threadIdx.x] = fmax(sh[threadIdx.x], sh[threadIdx.x + w]);
     __syncthreads();
   }
-  if (threadIdx.x == 0) out[blockIdx.y * out_ps] = sh[0];
+  if (threadIdx.x == 0)
+    atomicMax(reinterpret_cast<unsigned long long*>(out + blockIdx.y * out_ps), (unsigned long long)__double_as_longlong(sh[0]));
 }
+
+__global__ void zero_scalar_kernel(double* dst, int64_t dst_ps) { dst[blockIdx.x * dst_ps] = 0.0; }
 
 __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ x, const double* __restrict__ y,
                                                    double a, int64_t n) {
@@ -810,9 +815,12 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, Lam, 0.0, Z);
   solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
   // refinement on the constraint residual R = A Xt - B:  Xt -= P~^-1 A' S^-1 R
+  int64_t rb = ceil_div((int64_t)m * nrhs, 256 * 8);
+  const unsigned resid_blocks = (unsigned)(rb < 1 ? 1 : rb > 64 ? 64 : rb);
   for (int it = 0; it < n_refine; ++it) {
     gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, Xt, 0.0, Lam);
-    hipLaunchKernelGGL(resid_kernel, dim3(1, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps,
+    if (it > 0) hipLaunchKernelGGL(zero_scalar_kernel, dim3(np), dim3(1), 0, st, scal + 1, (int64_t)4);
+    hipLaunchKernelGGL(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps,
                        it == 0 ? stats + 2 : scal + 1, (int64_t)4);
     // padded rows/cols of A Xt - Bp are exact zeros, so the padded residual needs no masking.
     // Bw's storage is reused as the (mpad x rpad) scratch for S^-1 R: per problem it holds at least
@@ -825,12 +833,99 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
                        (int64_t)np * (int64_t)l.e_nr);
   }
   gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, Xt, 0.0, Lam);
-  hipLaunchKernelGGL(resid_kernel, dim3(1, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps, stats + 1, (int64_t)4);
+  hipLaunchKernelGGL(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps, stats + 1,
+                     (int64_t)4);
   hipLaunchKernelGGL(crop_transpose_kernel, flat_grid((int64_t)nrhs * n, np), dim3(256), 0, st, Xt.p, rpad, Xt.ps, n,
                      nrhs, X);
   AGGF_LAUNCH_OK();
   return c.rc;
 }
+
+// ---------------------------------------------------------------------------
+// One-hot constraint rows (slice coordinate maps: every configuration of BASELINE.json and every test of the
+// reference): A x = e_i merely PINS m variables, x[pin[j]] = delta_ij.  With f the free variables,
+//     x_f = -P_ff^-1 P[f, pin[i]],
+// i.e. one Cholesky factorisation of the (n - m)^2 free block and one pair of triangular solves with m right-hand
+// sides -- no A'A product, no Schur complement, no refinement (the constraints hold exactly by construction):
+// about 90 of the general path's 330 dependent launches go, 2 ms of 7 at n = 4096, m = 256.
+
+// free[0..n-m) = the indices not in pin, ascending; bad[0] = 1 if a pin is out of range or repeated.  One workgroup.
+__global__ __launch_bounds__(256) void pinned_free_list_kernel(const int32_t* __restrict__ pin, int m, int n,
+                                                               int32_t* __restrict__ mark, int32_t* __restrict__ free_idx,
+                                                               double* __restrict__ stats) {
+  __shared__ int part[256];
+  __shared__ int bad;
+  if (threadIdx.x == 0) bad = 0;
+  for (int i = threadIdx.x; i < n; i += 256) mark[i] = 0;
+  __syncthreads();
+  for (int j = threadIdx.x; j < m; j += 256) {
+    const int p = pin[j];
+    if (p < 0 || p >= n || atomicAdd(&mark[p], 1) != 0) bad = 1;
+  }
+  __syncthreads();
+  const int per = (n + 255) / 256, lo = threadIdx.x * per, hi = lo + per < n ? lo + per : n;
+  int cnt = 0;
+  for (int i = lo; i < hi; ++i) cnt += mark[i] == 0;
+  part[threadIdx.x] = cnt;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    int run = 0;
+    for (int t = 0; t < 256; ++t) {
+      const int c = part[t];
+      part[t] = run;
+      run += c;
+    }
+    if (bad) stats[0] = -1.0;
+  }
+  __syncthreads();
+  int o = part[threadIdx.x];
+  for (int i = lo; i < hi; ++i)
+    if (mark[i] == 0) free_idx[o++] = i;
+}
+
+// Pt (npad x npad) = (G[f,f] + l2 diag)/s, identity on the padding; Bw (npad x rpad) = -G[f, pin]/s, zero padded
+__global__ __launch_bounds__(256) void pinned_build_kernel(const double* __restrict__ G, int n, const int32_t* __restrict__ free_idx,
+                                                           int nf, const int32_t* __restrict__ pin, int m, int npad, int rpad,
+                                                           double l2, const double* __restrict__ l2d,
+                                                           const double* __restrict__ scale, double* __restrict__ Pt,
+                                                           double* __restrict__ Bw) {
+  const double inv_s = 1.0 / scale[0];
+  const int64_t tp = (int64_t)npad * npad, total = tp + (int64_t)npad * rpad;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    if (e < tp) {
+      const int i = (int)(e / npad), j = (int)(e - (int64_t)i * npad);
+      double v;
+      if (i < nf && j < nf) {
+        const int gi = free_idx[i], gj = free_idx[j];
+        v = G[(int64_t)gi * n + gj];
+        if (i == j) v += l2 * (l2d ? l2d[gi] : 1.0);
+        v *= inv_s;
+      } else {
+        v = (i == j) ? 1.0 : 0.0;
+      }
+      Pt[e] = v;
+    } else {
+      const int64_t r = e - tp;
+      const int i = (int)(r / rpad), c = (int)(r - (int64_t)i * rpad);
+      Bw[r] = (i < nf && c < m) ? -G[(int64_t)free_idx[i] * n + pin[c]] * inv_s : 0.0;
+    }
+  }
+}
+
+// X (m x n): X[c, free[i]] = Xt[i, c];  X[c, pin[j]] = (j == c)
+__global__ __launch_bounds__(256) void pinned_scatter_kernel(const double* __restrict__ Xt, int rpad,
+                                                             const int32_t* __restrict__ free_idx, int nf,
+                                                             const int32_t* __restrict__ pin, int m, int n,
+                                                             double* __restrict__ X) {
+  const int64_t total = (int64_t)m * n;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int c = (int)(e / n), k = (int)(e - (int64_t)c * n);  // k-th entry of row c: free ones first, then the pins
+    if (k < nf) X[(int64_t)c * n + free_idx[k]] = Xt[(int64_t)k * rpad + c];
+    else X[(int64_t)c * n + pin[k - nf]] = (k - nf == c) ? 1.0 : 0.0;
+  }
+}
+
+static size_t pinned_index_bytes(int n) { return (size_t)round_up((int64_t)n * 8, 256); }
 
 }  // namespace aggf
 
@@ -929,4 +1024,50 @@ extern "C" int aggf_daxpby(int64_t n, double a, const double* x, double b, const
   hipLaunchKernelGGL(axpby_kernel, flat_grid(n), dim3(256), 0, st, n, a, x, b, y, out);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
+}
+
+// ---- one-hot constraint rows: m pinned variables (see pinned_* kernels) -------------------------------
+extern "C" size_t aggf_eq_qp_pinned_workspace_bytes(int32_t n, int32_t m) {
+  if (n <= 0 || m <= 0 || m >= n) return 0;
+  return solve_layout(n - m, m, m, 1).total + pinned_index_bytes(n);
+}
+
+extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, const double* l2_diag,
+                                       const int32_t* pin_idx, int32_t m, double* X, double* stats, void* ws,
+                                       size_t ws_bytes, void* stream_v) {
+  const char* who = "aggf_eq_qp_solve_pinned";
+  if (!G || !pin_idx || !X || !stats || !ws) return fail(AGGF_ERR_ARG, "%s: NULL pointer", who);
+  if (n <= 0 || m <= 0 || m >= n) return fail(AGGF_ERR_ARG, "%s: needs 0 < m < n", who);
+  if (n > 256 * 4096) return fail(AGGF_ERR_ARG, "%s: n too large", who);
+  if (!(l2 >= 0.0)) return fail(AGGF_ERR_ARG, "%s: l2 must be >= 0", who);
+  if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "%s: workspace not 256-byte aligned", who);
+  const int nf = n - m;
+  const SolveLayout l = solve_layout(nf, m, m, 1);
+  if (ws_bytes < l.total + pinned_index_bytes(n)) return fail(AGGF_ERR_WORKSPACE, "%s: workspace too small", who);
+  Ctx c;
+  c.stream = (hipStream_t)stream_v;
+  c.nprob = 1;
+  hipStream_t st = c.stream;
+  char* w = (char*)ws;
+  const int npad = l.npad, rpad = l.rpad;
+  auto M_ = [&](size_t off, int64_t ld, size_t elems) { return Mat{reinterpret_cast<double*>(w + off), ld, (int64_t)elems}; };
+  const Mat Pt = M_(l.off_Pt, npad, l.e_Pt), Dinv = M_(l.off_Dinv, NB, l.e_Dinv), Bw = M_(l.off_Bw, rpad, l.e_Bw),
+            Y = M_(l.off_Z, rpad, l.e_nr), Xt = M_(l.off_Xt, rpad, l.e_nr);
+  double* scal = reinterpret_cast<double*>(w + l.off_scal);
+  int32_t* free_idx = reinterpret_cast<int32_t*>(w + l.total);
+  int32_t* mark = free_idx + n;
+  hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(64), 0, st, stats, 4);
+  hipLaunchKernelGGL(pinned_free_list_kernel, dim3(1), dim3(256), 0, st, pin_idx, m, n, mark, free_idx, stats);
+  hipLaunchKernelGGL(max_diag_kernel, dim3(1, 1), dim3(256), 0, st, G, n, (int64_t)0, l2, l2_diag, scal, (int64_t)4);
+  hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
+  hipLaunchKernelGGL(pinned_build_kernel, flat_grid((int64_t)npad * (npad + rpad)), dim3(256), 0, st, G, n, free_idx, nf,
+                     pin_idx, m, npad, rpad, l2, l2_diag, scal, Pt.p, Bw.p);
+  AGGF_LAUNCH_OK();
+  cholesky(c, Pt, npad, Dinv, stats, 0);
+  solve_lower(c, Pt, npad, Dinv, Bw, Y, rpad);
+  solve_lower_t(c, Pt, npad, Dinv, Y, Xt, rpad);
+  hipLaunchKernelGGL(pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
+                     n, X);
+  AGGF_LAUNCH_OK();
+  return c.rc;
 }

@@ -54,15 +54,41 @@ def make_bond_constraint_matrix(n_sites: int, constraints: Constraints) -> np.nd
     return mat
 
 
+def _one_hot_rows(A: np.ndarray):
+    """Column of the single 1 of every row if all rows of A are unit vectors at distinct columns (and A has fewer rows
+    than columns), else None."""
+    m, n = A.shape
+    if m == 0 or m >= n:
+        return None
+    nz = A != 0
+    if not (np.all(nz.sum(axis=1) == 1) and np.all(A[nz] == 1.0)):
+        return None
+    cols = np.argmax(nz, axis=1).astype(np.int32)
+    return cols if len(np.unique(cols)) == m else None
+
+
 def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndarray, what: str = "Map optimization"):
     """Run K2 for all rows of A at once; returns (X device (m, n), stats host)."""
     import torch
 
     dev = G.device
-    A = torch.from_numpy(np.ascontiguousarray(A_host, dtype=np.float64)).to(dev)
-    X, stats = K.eq_qp_solve(G, l2_regularization, l2_diag, A)
+    A_host = np.ascontiguousarray(A_host, dtype=np.float64)
+    pins = _one_hot_rows(A_host)
+    A = None
+
+    def solve(l2, n_refine=1):
+        nonlocal A
+        if pins is not None:
+            # every row of A is a unit vector (slice coordinate map): the constraints pin variables, one
+            # factorisation of the free block does it (aggf_eq_qp_solve_pinned)
+            return K.eq_qp_solve_pinned(G, l2, l2_diag, torch.from_numpy(pins).to(dev))
+        if A is None:
+            A = torch.from_numpy(A_host).to(dev)
+        return K.eq_qp_solve(G, l2, l2_diag, A, n_refine=n_refine)
+
+    X, stats = solve(l2_regularization)
     st = stats.cpu().numpy()
-    if st[0] != 0 and st[0] <= G.shape[0] and np.isfinite(st[3]):
+    if st[0] > 0 and st[0] <= G.shape[0] and np.isfinite(st[3]):
         # P = G + l2 C'C is singular on null(A): fewer independent frames than free variables and no
         # regularisation.  The minimiser is then not unique, but every minimiser maps the training frames
         # identically (the objective is strictly convex in the mapped forces), and the reference's OSQP hands
@@ -74,8 +100,7 @@ def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndar
             "unique -- returning a minimum-norm minimiser. Add frames or use l2_regularization > 0.",
             stacklevel=3,
         )
-        X, stats = K.eq_qp_solve(G, l2_regularization + 1e-10 * float(st[3]), None if l2_diag is None else l2_diag, A,
-                                 n_refine=2)
+        X, stats = solve(l2_regularization + 1e-10 * float(st[3]), n_refine=2)
         st = stats.cpu().numpy()
     if st[0] != 0 or not np.isfinite(st[1]):
         raise ValueError(

@@ -551,7 +551,7 @@ def main():
             if args.workload == "c4":
                 cb = cpu_baseline_featurised(blas_threads())
             elif args.workload == "c5":
-                cb = cpu_baseline(N, n_cg, npdt, T_total, min(args.cpu_frames // 2, T_total), blas_threads(), cmat=cm_host,
+                cb = cpu_baseline(N, n_cg, npdt, T_total, min(args.cpu_frames // 5, T_total), blas_threads(), cmat=cm_host,
                                   noised=(0.01, KBT))
             elif args.workload == "c1":
                 cb = cpu_baseline(N, n_cg, npdt, T_total, min(20 * args.cpu_frames, T_total), blas_threads(), cmat=cm_host,

@@ -128,6 +128,18 @@ int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, const double
                              double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
                              double* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* The same problem when every row of A is a unit vector with the 1 at pin_idx[i] (all distinct) and B is the
+ * identity -- the constraint rows of a slice coordinate map, `coord_map.standard_matrix @ con_mat` of
+ * qplinear.py:82 for every configuration of the reference's tests: the constraints pin m variables,
+ * x_i[pin_idx[j]] = delta_ij, and the rest follows from ONE factorisation of the free block,
+ * x_f = -P_ff^-1 P[f, pin_idx[i]] -- no A'A product, no Schur complement, no refinement.
+ * pin_idx: m int32 (device).  X: (m, n).  stats as above ([1] = [2] = 0: the constraints hold exactly;
+ * [0] = -1 if pin_idx holds an index twice or outside 0..n-1). */
+size_t aggf_eq_qp_pinned_workspace_bytes(int32_t n, int32_t m);
+int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, const double* l2_diag,
+                            const int32_t* pin_idx, int32_t m, double* X, double* stats, void* ws,
+                            size_t ws_bytes, void* stream);
+
 /* Packed upper triangle of `batch` symmetric n x n float64 matrices, row-major:
  *   packed[b][i n - i (i - 1) / 2 + (j - i)] = G[b][i][j], j >= i   (n (n + 1) / 2 elements per matrix).
  * The payload of the Gram all-reduce: the reference has no distributed code; the build sums the per-rank Gram

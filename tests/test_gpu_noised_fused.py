@@ -74,11 +74,13 @@ def test_noised_map_without_extended_arrays_matches_oracle_and_general_path(name
     monkeypatch.setattr(gauss_mod, "_joptgauss_without_extended_arrays", lambda *a, **k: None)
     gen = joptgauss_map(traj, cmap, var=VAR, kbt=KBT, constraints=cons, noise=list(eps), l2_regularization=l2)
     assert calls["pair"] == 1
-    assert rel(W, gen.tmap.force_map.standard_matrix) < (1e-3 if dt == np.float32 else 1e-9)
+    # (float64 trajectories: the general path adds the source-site correction kbt C' r after rounding it to the
+    # augmenter's float32; here it enters through float64 matrix algebra)
+    assert rel(W, gen.tmap.force_map.standard_matrix) < (1e-3 if dt == np.float32 else 1e-7)
     monkeypatch.setattr(type(gen), "_call_without_extended_arrays", lambda self, t: None)
     mapped_gen = gen(traj)
-    assert big["n"] == 1
-    assert rel(mapped_gen.forces, mapped.forces) < (1e-3 if dt == np.float32 else 1e-9)
+    assert big["n"] == 2                                                # the general fit and its application
+    assert rel(mapped_gen.forces, mapped.forces) < (1e-3 if dt == np.float32 else 1e-7)
     assert rel(mapped_gen.coords, mapped.coords) < 1e-6
 
 
