@@ -363,6 +363,167 @@ __global__ __launch_bounds__(256) void potrf_diag_blocked_kernel(double* __restr
   }
 }
 
+// Third version of the diagonal-block kernel (default since round 3; AGGF_POTRF=blocked / wave select the older ones).
+// In-kernel cycle counts of the blocked version above: the four 16 x 16 diagonal sub-blocks 45.7 k of 89 k cycles (16
+// lanes, a v_readlane + FMA pair every ~40 cycles), the block products (panels, trailing updates, inverse levels) 33 k
+// as scalar FMAs with two LDS reads each.  Here
+//  * a 16 x 16 sub-block is factored AND inverted by all 256 threads, thread (i, c) owning entry (i, c) of the block and
+//    of the running inverse Z (Z starts as the identity and receives the same row operations): per column one 16-entry
+//    column buffer + one 16-entry Z-row buffer in LDS and ONE barrier; every thread recomputes the pivot's 1/sqrt itself;
+//  * every block product runs on v_mfma_f64_16x16x4_f64, operands straight from the LDS copies of A / L / X, one
+//    16 x 16 output tile per wave and pass.  The second product of an inverse level, X(bi,bi) W, takes W from the
+//    accumulator registers of the first: the contraction index is walked in the order the D layout holds it
+//    (k = (lane >> 4) + 4 r), so no LDS round trip is needed.
+__device__ __forceinline__ double rsqrt_newton(double d) {
+  double rs = __builtin_amdgcn_rsq(d);
+  double e = fma(-d * rs, rs, 1.0);
+  rs = fma(rs * e, fma(e, 0.375, 0.5), rs);
+  e = fma(-d * rs, rs, 1.0);
+  return fma(rs * 0.5, e, rs);
+}
+
+#ifdef AGGF_POTRF_PROF
+// tools/potrf_probe.hip: shader cycles of thread 0 at the phase boundaries of one diagonal block
+__device__ unsigned long long aggf_potrf_prof[8];
+#define AGGF_PP(i) do { if (threadIdx.x == 0) aggf_potrf_prof[i] = __builtin_readcyclecounter(); } while (0)
+#else
+#define AGGF_PP(i)
+#endif
+constexpr int POTRF3_LDS = (2 * NB * (NB + 1) + 2 * 2 * PB) * (int)sizeof(double);
+__global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict__ Akk, int64_t lda,
+                                                             double* __restrict__ Linv,
+                                                             double* __restrict__ info, int pivot_base,
+                                                             int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
+  using MF = Mfma<double>;
+  extern __shared__ __attribute__((aligned(16))) char potrf_smem[];
+  double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem);        // A, then L (lower)
+  double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem) + NB;   // L^-1
+  double* colbuf = reinterpret_cast<double*>(potrf_smem) + 2 * NB * (NB + 1);    // [2][16] scaled... raw column j
+  double* zrow = colbuf + 2 * PB;                                                // [2][16] row j of Z
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  Akk += blockIdx.x * a_ps;  // blockIdx.x = problem of a batched solve
+  Linv += blockIdx.x * linv_ps;
+  info += blockIdx.x * info_ps;
+  AGGF_PP(0);
+  {
+    // all 16 loads of a thread in flight together (the upper triangle is storage of the same matrix: read and dropped;
+    // with the predicate inside the load the compiler waited for each one: 20 k cycles for this loop)
+    double tmp[NB * NB / 256];
+#pragma unroll
+    for (int q = 0; q < NB * NB / 256; ++q) {
+      const int e = tid + 256 * q;
+      tmp[q] = Akk[(int64_t)(e / NB) * lda + (e % NB)];
+    }
+#pragma unroll
+    for (int q = 0; q < NB * NB / 256; ++q) {
+      const int e = tid + 256 * q, r = e / NB, c = e % NB;
+      a[r][c] = (c <= r) ? tmp[q] : 0.0;
+      x[r][c] = 0.0;
+    }
+  }
+  __syncthreads();
+  AGGF_PP(1);
+  const int si = tid >> 4, sc = tid & 15;  // sub-block entry (row, column) of this thread
+  for (int kb = 0; kb < NB / PB; ++kb) {
+    const int k0 = kb * PB;
+    // 1. diagonal sub-block: right-looking Cholesky on the 256 entries, the identity alongside
+    {
+      double v = a[k0 + si][k0 + sc];     // A[i][c] (lower part meaningful)
+      double z = si == sc ? 1.0 : 0.0;    // Z[i][c]
+#pragma unroll
+      for (int j = 0; j < PB; ++j) {
+        double* cb = colbuf + (j & 1) * PB;
+        double* zb = zrow + (j & 1) * PB;
+        if (sc == j) cb[si] = v;          // column j as it stands (rows >= j matter)
+        if (si == j) zb[sc] = z;          // row j of Z (final: rows are only touched by earlier columns)
+        __syncthreads();
+        double d = cb[j];
+        if (!(d > 0.0)) {
+          if (tid == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + k0 + j + 1);
+          d = 1.0;
+        }
+        const double rs = rsqrt_newton(d);
+        const double l_i = cb[si] * rs, l_c = cb[sc] * rs;   // L[i][j], L[c][j]
+        const double xj = zb[sc] * rs;                         // X[j][c] = Z[j][c] / L[j][j]
+        if (sc == j) v = si == j ? d * rs : (si > j ? l_i : 0.0);
+        else if (si > j && sc > j) v = fma(-l_i, l_c, v);      // (only c <= i is ever read)
+        if (si == j) z = xj;
+        else if (si > j) z = fma(-l_i, xj, z);
+      }
+      a[k0 + si][k0 + sc] = sc <= si ? v : 0.0;
+      x[k0 + si][k0 + sc] = sc <= si ? z : 0.0;
+    }
+    __syncthreads();
+    const int nt16 = (NB - k0 - PB) / PB;  // 16-row tiles below the sub-block: 3, 2, 1, 0
+    // 2. panel below: P = A_panel X_kk'  (wave w takes row tile w); in place -- a wave reads and writes its own rows only
+    if (wave < nt16) {
+      const int r0 = k0 + PB + wave * PB;
+      f64x4 acc = acc_zero<double>();
+#pragma unroll
+      for (int kk = 0; kk < PB / 4; ++kk)
+        acc = MF::mma(a[r0 + li][k0 + kk * 4 + lk], x[k0 + li][k0 + kk * 4 + lk], acc);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) a[r0 + MF::row(lane, r)][k0 + li] = acc[r];
+    }
+    __syncthreads();
+    // 3. trailing block -= P P' on the lower tiles (ti >= tj), dealt to the waves
+    {
+      int q = 0;
+      for (int ti = 0; ti < nt16; ++ti)
+        for (int tj = 0; tj <= ti; ++tj, ++q) {
+          if ((q & 3) != wave) continue;
+          const int r0 = k0 + PB + ti * PB, c0 = k0 + PB + tj * PB;
+          f64x4 acc;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[r] = a[r0 + MF::row(lane, r)][c0 + li];
+#pragma unroll
+          for (int kk = 0; kk < PB / 4; ++kk)
+            acc = MF::mma(-a[r0 + li][k0 + kk * 4 + lk], a[c0 + li][k0 + kk * 4 + lk], acc);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) a[r0 + MF::row(lane, r)][c0 + li] = acc[r];
+        }
+    }
+    __syncthreads();
+  }
+  AGGF_PP(2);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    if (c <= r) Akk[(int64_t)r * lda + c] = a[r][c];
+  }
+  AGGF_PP(3);
+  // sub-blocks of the inverse below the diagonal, by distance d from it:
+  //   X(bi,bj) = -X(bi,bi) * sum_{k = bj}^{bi-1} L(bi,k) X(k,bj)        (one block per wave)
+  for (int d = 1; d < NB / PB; ++d) {
+    const int nblk = NB / PB - d;
+    f64x4 out = acc_zero<double>();
+    const int bj = wave, bi = wave + d;
+    if (wave < nblk) {
+      f64x4 w = acc_zero<double>();
+      for (int kb = bj; kb < bi; ++kb) {
+#pragma unroll
+        for (int kk = 0; kk < PB / 4; ++kk)
+          w = MF::mma(a[bi * PB + li][kb * PB + kk * 4 + lk], x[kb * PB + kk * 4 + lk][bj * PB + li], w);
+      }
+      // out = -X(bi,bi) W with the contraction index in D-layout order: k = lk + 4 r
+#pragma unroll
+      for (int r = 0; r < 4; ++r) out = MF::mma(-x[bi * PB + li][bi * PB + lk + 4 * r], w[r], out);
+    }
+    __syncthreads();  // (every X(k,bj) read above belongs to an earlier level or the diagonal: no hazard with the writes below)
+    if (wave < nblk) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) x[bi * PB + MF::row(lane, r)][bj * PB + li] = out[r];
+    }
+    __syncthreads();
+  }
+  AGGF_PP(4);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    Linv[r * NB + c] = x[r][c];
+  }
+  AGGF_PP(5);
+}
+
 // Helper kernels of the solve.  blockIdx.y = problem of a batched solve; every array argument comes
 // with its per-problem stride (`*_ps`, elements).
 
@@ -620,7 +781,10 @@ static void build_big_inverses(Ctx& c, Mat L, int npad, Mat Dinv) {
 }
 
 // info: first of the 4 stats doubles of problem 0 (stride 4 between problems)
-static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_base) {
+// extra_rows (a multiple of 64): rows npad .. npad+extra_rows-1 of P (same ld) ride along -- they receive every panel
+// and trailing update, i.e. leave as B' L^-T for the B' they held: the forward solve Y = L^-1 B of those right-hand
+// sides comes out of the factorisation and needs no launches of its own.
+static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_base, int extra_rows = 0) {
   const int nb = npad / NB;
   for (int k0 = 0; k0 < nb && !c.rc; k0 += OUTER_PANELS) {
     const int kend = k0 + OUTER_PANELS < nb ? k0 + OUTER_PANELS : nb;
@@ -631,6 +795,17 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
       if (potrf_env && potrf_env[0] == 'w') {
         hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.nprob), dim3(64), 0, c.stream, Akk.p, (int64_t)npad, Dk.p,
                            info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
+      } else if (!(potrf_env && potrf_env[0] == 'b')) {
+        static thread_local PerDeviceOnce attr_once3;
+        bool& attr_done3 = *attr_once3.flag();
+        if (!attr_done3) {
+          if (hipFuncSetAttribute((const void*)potrf_diag_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  POTRF3_LDS) != hipSuccess)
+            c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
+          attr_done3 = true;
+        }
+        hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, (int64_t)npad,
+                           Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
       } else {
         static thread_local PerDeviceOnce attr_once;
         bool& attr_done = *attr_once.flag();
@@ -644,7 +819,7 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
                            (int64_t)npad, Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
       }
       if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
-      const int rem = npad - (k + 1) * NB;
+      const int rem = npad - (k + 1) * NB + extra_rows;
       if (rem <= 0) break;
       const Mat panel = Akk.at(NB, 0);  // rows below the diagonal block, same columns
       // panel <- panel * Linv'  (in place: every workgroup reads exactly the rows it writes)
@@ -655,10 +830,11 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
     }
     const int rem2 = npad - kend * NB;
     if (rem2 > 0) {
-      // trailing <- trailing - L21 L21' with all columns of the outer panel at once
+      // trailing <- trailing - L21 L21' with all columns of the outer panel at once (extra rows: all their tiles
+      // lie below the block diagonal)
       const int kw = (kend - k0) * NB;
       const Mat L21 = P.at((int64_t)kend * NB, (int64_t)k0 * NB);
-      gemm<false, true>(c, rem2, rem2, kw, -1.0, L21, L21, 1.0, P.at((int64_t)kend * NB, (int64_t)kend * NB), 1);
+      gemm<false, true>(c, rem2 + extra_rows, rem2, kw, -1.0, L21, L21, 1.0, P.at((int64_t)kend * NB, (int64_t)kend * NB), 1);
     }
   }
   build_big_inverses(c, P, npad, Dinv);
@@ -883,18 +1059,18 @@ __global__ __launch_bounds__(256) void pinned_free_list_kernel(const int32_t* __
     if (mark[i] == 0) free_idx[o++] = i;
 }
 
-// Pt (npad x npad) = (G[f,f] + l2 diag)/s, identity on the padding; Bw (npad x rpad) = -G[f, pin]/s, zero padded
+// Pt ((npad + rpad) x npad): rows < npad = (G[f,f] + l2 diag)/s with the identity on the padding; rows npad + c =
+// -G[pin[c], f]/s (zero padded): the right-hand sides B = -P[f, pin], transposed, riding along with the factorisation
 __global__ __launch_bounds__(256) void pinned_build_kernel(const double* __restrict__ G, int n, const int32_t* __restrict__ free_idx,
                                                            int nf, const int32_t* __restrict__ pin, int m, int npad, int rpad,
                                                            double l2, const double* __restrict__ l2d,
-                                                           const double* __restrict__ scale, double* __restrict__ Pt,
-                                                           double* __restrict__ Bw) {
+                                                           const double* __restrict__ scale, double* __restrict__ Pt) {
   const double inv_s = 1.0 / scale[0];
-  const int64_t tp = (int64_t)npad * npad, total = tp + (int64_t)npad * rpad;
+  const int64_t total = (int64_t)(npad + rpad) * npad;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-    if (e < tp) {
-      const int i = (int)(e / npad), j = (int)(e - (int64_t)i * npad);
-      double v;
+    const int i = (int)(e / npad), j = (int)(e - (int64_t)i * npad);
+    double v;
+    if (i < npad) {
       if (i < nf && j < nf) {
         const int gi = free_idx[i], gj = free_idx[j];
         v = G[(int64_t)gi * n + gj];
@@ -903,12 +1079,11 @@ __global__ __launch_bounds__(256) void pinned_build_kernel(const double* __restr
       } else {
         v = (i == j) ? 1.0 : 0.0;
       }
-      Pt[e] = v;
     } else {
-      const int64_t r = e - tp;
-      const int i = (int)(r / rpad), c = (int)(r - (int64_t)i * rpad);
-      Bw[r] = (i < nf && c < m) ? -G[(int64_t)free_idx[i] * n + pin[c]] * inv_s : 0.0;
+      const int c = i - npad;
+      v = (c < m && j < nf) ? -G[(int64_t)pin[c] * n + free_idx[j]] * inv_s : 0.0;
     }
+    Pt[e] = v;
   }
 }
 
@@ -924,8 +1099,6 @@ __global__ __launch_bounds__(256) void pinned_scatter_kernel(const double* __res
     else X[(int64_t)c * n + pin[k - nf]] = (k - nf == c) ? 1.0 : 0.0;
   }
 }
-
-static size_t pinned_index_bytes(int n) { return (size_t)round_up((int64_t)n * 8, 256); }
 
 }  // namespace aggf
 
@@ -1027,9 +1200,33 @@ extern "C" int aggf_daxpby(int64_t n, double a, const double* x, double b, const
 }
 
 // ---- one-hot constraint rows: m pinned variables (see pinned_* kernels) -------------------------------
+struct PinnedLayout {
+  int npad, rpad;
+  size_t off_Pt, off_Dinv, off_Z, off_Xt, off_scal, off_idx, total;
+};
+static PinnedLayout pinned_layout(int n, int m) {
+  PinnedLayout l;
+  l.npad = (int)round_up(n - m, NB);
+  l.rpad = (int)round_up(m, NB);
+  size_t o = 0;
+  auto take = [&](size_t bytes) {
+    size_t r = o;
+    o += (size_t)round_up((int64_t)bytes, 256);
+    return r;
+  };
+  l.off_Pt = take((size_t)(l.npad + l.rpad) * l.npad * 8);
+  l.off_Dinv = take(dinv_elems(l.npad) * 8);
+  l.off_Z = take((size_t)l.npad * l.rpad * 8);
+  l.off_Xt = take((size_t)l.npad * l.rpad * 8);
+  l.off_scal = take(32);
+  l.off_idx = take((size_t)n * 8);
+  l.total = o;
+  return l;
+}
+
 extern "C" size_t aggf_eq_qp_pinned_workspace_bytes(int32_t n, int32_t m) {
   if (n <= 0 || m <= 0 || m >= n) return 0;
-  return solve_layout(n - m, m, m, 1).total + pinned_index_bytes(n);
+  return pinned_layout(n, m).total;
 }
 
 extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, const double* l2_diag,
@@ -1042,30 +1239,32 @@ extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, co
   if (!(l2 >= 0.0)) return fail(AGGF_ERR_ARG, "%s: l2 must be >= 0", who);
   if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "%s: workspace not 256-byte aligned", who);
   const int nf = n - m;
-  const SolveLayout l = solve_layout(nf, m, m, 1);
-  if (ws_bytes < l.total + pinned_index_bytes(n)) return fail(AGGF_ERR_WORKSPACE, "%s: workspace too small", who);
+  const PinnedLayout l = pinned_layout(n, m);
+  if (ws_bytes < l.total) return fail(AGGF_ERR_WORKSPACE, "%s: workspace too small", who);
   Ctx c;
   c.stream = (hipStream_t)stream_v;
   c.nprob = 1;
   hipStream_t st = c.stream;
   char* w = (char*)ws;
   const int npad = l.npad, rpad = l.rpad;
-  auto M_ = [&](size_t off, int64_t ld, size_t elems) { return Mat{reinterpret_cast<double*>(w + off), ld, (int64_t)elems}; };
-  const Mat Pt = M_(l.off_Pt, npad, l.e_Pt), Dinv = M_(l.off_Dinv, NB, l.e_Dinv), Bw = M_(l.off_Bw, rpad, l.e_Bw),
-            Y = M_(l.off_Z, rpad, l.e_nr), Xt = M_(l.off_Xt, rpad, l.e_nr);
+  const Mat Pt{reinterpret_cast<double*>(w + l.off_Pt), npad, 0}, Dinv{reinterpret_cast<double*>(w + l.off_Dinv), NB, 0},
+      Z{reinterpret_cast<double*>(w + l.off_Z), rpad, 0}, Xt{reinterpret_cast<double*>(w + l.off_Xt), rpad, 0};
   double* scal = reinterpret_cast<double*>(w + l.off_scal);
-  int32_t* free_idx = reinterpret_cast<int32_t*>(w + l.total);
+  int32_t* free_idx = reinterpret_cast<int32_t*>(w + l.off_idx);
   int32_t* mark = free_idx + n;
   hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(64), 0, st, stats, 4);
   hipLaunchKernelGGL(pinned_free_list_kernel, dim3(1), dim3(256), 0, st, pin_idx, m, n, mark, free_idx, stats);
   hipLaunchKernelGGL(max_diag_kernel, dim3(1, 1), dim3(256), 0, st, G, n, (int64_t)0, l2, l2_diag, scal, (int64_t)4);
   hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
-  hipLaunchKernelGGL(pinned_build_kernel, flat_grid((int64_t)npad * (npad + rpad)), dim3(256), 0, st, G, n, free_idx, nf,
-                     pin_idx, m, npad, rpad, l2, l2_diag, scal, Pt.p, Bw.p);
+  hipLaunchKernelGGL(pinned_build_kernel, flat_grid((int64_t)(npad + rpad) * npad), dim3(256), 0, st, G, n, free_idx, nf,
+                     pin_idx, m, npad, rpad, l2, l2_diag, scal, Pt.p);
   AGGF_LAUNCH_OK();
-  cholesky(c, Pt, npad, Dinv, stats, 0);
-  solve_lower(c, Pt, npad, Dinv, Bw, Y, rpad);
-  solve_lower_t(c, Pt, npad, Dinv, Y, Xt, rpad);
+  // the rows below the matrix leave the factorisation as Y' = B' L^-T: no forward solve of its own
+  cholesky(c, Pt, npad, Dinv, stats, 0, rpad);
+  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * rpad), dim3(256), 0, st, Pt.p + (int64_t)npad * npad, rpad, npad,
+                     (int64_t)0, 1, Z.p, npad, rpad, (int64_t)0);
+  AGGF_LAUNCH_OK();
+  solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
   hipLaunchKernelGGL(pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
                      n, X);
   AGGF_LAUNCH_OK();
