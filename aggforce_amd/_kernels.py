@@ -330,9 +330,37 @@ def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype
     return out
 
 
+_flag_pool: dict = {}
+
+
+def take_flag(device) -> torch.Tensor:
+    """A ZEROED int32 device scalar (shape (1,)) from a per-device pool; hand it back with :func:`read_flag`.
+
+    Why a pool: ``torch.zeros(1)`` is a fill kernel on the current stream, and a one-workgroup kernel queued while a
+    grid-stride kernel of another stream (the coordinate gather underneath the force map's apply) owns every wave
+    slot waits until one of that kernel's workgroups retires -- 1.4 ms + 0.55 ms per step at BASELINE's
+    configuration (rocprofv3 timeline, round 3).  Pool flags are zeroed in blocks of 64 and re-zeroed only after a
+    kernel has actually set them, so the steady state issues no fill at all."""
+    pool = _flag_pool.setdefault(str(device), [])
+    if not pool:
+        block = torch.zeros(64, dtype=torch.int32, device=device)
+        pool.extend(block[i:i + 1] for i in range(64))
+    return pool.pop()
+
+
+def read_flag(flag: torch.Tensor) -> bool:
+    """Host value of a flag from :func:`take_flag` (synchronises); the flag goes back to the pool, zeroed."""
+    v = bool(flag.item())
+    if v:
+        flag.zero_()
+    _flag_pool.setdefault(str(flag.device), []).append(flag)
+    return v
+
+
 def nan_flag(x: torch.Tensor) -> torch.Tensor:
-    """Device int32 flag (shape (1,)): non-zero iff x holds a NaN.  No host synchronisation."""
-    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    """Device int32 flag (shape (1,), from :func:`take_flag`: read it with :func:`read_flag`): non-zero iff x holds a
+    NaN.  No host synchronisation."""
+    flag = take_flag(x.device)
     if x.numel():
         check(lib().aggf_has_nan(ptr(x), x.numel(), dtype_code(x.dtype), ptr(flag), stream_ptr()), "aggf_has_nan")
     return flag
@@ -365,22 +393,22 @@ def has_nan(x: torch.Tensor) -> bool:
     l = lib()
     if x.numel() == 0:
         return False
-    flag = torch.zeros(1, dtype=torch.int32, device=x.device)
+    flag = take_flag(x.device)
     check(l.aggf_has_nan(ptr(x), x.numel(), dtype_code(x.dtype), ptr(flag), stream_ptr()), "aggf_has_nan")
-    return bool(flag.item())
+    return read_flag(flag)
 
 
 def allclose(a: torch.Tensor, b: torch.Tensor, rtol: float = 1e-5, atol: float = 1e-8) -> bool:
     l = lib()
     if a.numel() == 0:
         return True
-    flag = torch.zeros(1, dtype=torch.int32, device=a.device)
+    flag = take_flag(a.device)
     check(
         l.aggf_not_close(ptr(a), ptr(b), a.numel(), dtype_code(a.dtype), float(rtol), float(atol), ptr(flag),
                          stream_ptr()),
         "aggf_not_close",
     )
-    return not bool(flag.item())
+    return not read_flag(flag)
 
 
 def sumsq(x: torch.Tensor) -> torch.Tensor:

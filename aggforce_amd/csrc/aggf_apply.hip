@@ -35,7 +35,7 @@ __device__ unsigned long long aggf_apply_prof[5];
 #endif
 
 template <typename TIn, typename TC, bool NANREP, int AP_THREADS, int AP_TC, int AP_WF = 4>
-__global__ __launch_bounds__(AP_THREADS, (AP_THREADS >= 1024 || AP_WF < 4) ? 4 : 2) void apply_kernel(
+__global__ __launch_bounds__(AP_THREADS, (AP_TC >= 256 && AP_THREADS == 512) ? 2 : (AP_THREADS >= 1024 || AP_WF < 4) ? 4 : 2) void apply_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
     int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
     double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
@@ -591,7 +591,13 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
       (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) >= 16 && (((uintptr_t)P & 15) == 0) && T >= 64)
     return apply_small_launch<TIn, TC>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   // (32 frames x 128 sites with 8 waves -- two independent workgroups per CU -- measured the same 103 ms)
-  const int tile = force ? (force[0] == 'a' ? 3 : force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
+  const int tile = force ? (force[0] == 'h' ? 4 : force[0] == 'a' ? 3 : force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
+  // "huge": 32 frames x 256 sites with 8 waves at TWO waves per SIMD (the 12 accumulator tiles of a wave + staging =
+  // ~170 registers), one workgroup per CU: P is read once for n_cg <= 256, 7 operand reads per 12 MFMAs
+  // (64 frames x 256 sites needs 270 registers: 928 spilled at the 256 of two waves per SIMD)
+  if (tile == 4)
+    return apply_launch<TIn, TC, 512, 256, 2>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
+                                              ws_bytes, stream);
   // "all": one workgroup over 256 sites, so that P is read once for n_cg <= 256.  Measured at C3:
   // see DESIGN section 8 -- 96 accumulator registers + staging at 4 waves per SIMD.
   if (tile == 3)

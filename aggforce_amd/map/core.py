@@ -37,7 +37,7 @@ class _PendingMap:
 
     def result(self):
         self._join()
-        if bool(self._flag.item()):
+        if K.read_flag(self._flag):
             raise ValueError(
                 "NaN handling is on and results seem to depend on NaN "
                 "positions in input array. Check input and standard_matrix."
@@ -46,6 +46,7 @@ class _PendingMap:
 
     def discard(self) -> None:
         self._join()
+        K.read_flag(self._flag)
 
 
 class LinearMap:
@@ -93,25 +94,54 @@ class LinearMap:
             raise ValueError(f"Cannot understand mapping {mapping}.")
         self._standard_matrix = matrix
         self.handle_nans = handle_nans
-        if self.handle_nans and not np.all(np.isfinite(matrix)):
+        # (min and max propagate NaN and show +-inf: two passes without the temporaries of np.isfinite(matrix).all(),
+        # which cost 1 ms per fitted 256 x 4096 force map)
+        if self.handle_nans and matrix.size and not (np.isfinite(matrix.min()) and np.isfinite(matrix.max())):
             raise ValueError("Nan checking can only be performed if standard_matrix is itself finite.")
         self.nan_check_threshold = nan_check_threshold
         self._dev_cache: Dict = {}
         self._onehot = None
+        self._host_ready = None  # event of an asynchronous download still filling _standard_matrix (see from_device)
+
+    @classmethod
+    def from_device(cls, matrix_dev, handle_nans: Union[bool, Literal["safe"]] = True,
+                    nan_check_threshold: float = 1e-6) -> "LinearMap":
+        """A map whose (n_cg, n_fg) matrix was just computed on the GPU (a fitted force map): the device copy is used
+        as it is, the NumPy ``standard_matrix`` is filled by an ASYNCHRONOUS download into pinned memory and waited
+        for on first access.  The fit used to download (8 MB at 256 x 4096), check and classify the matrix on the host
+        -- 3 ms with the GPU idle -- before the apply kernel could be launched.  The matrix must be finite and is
+        taken to be dense (no one-hot rows): what K2 returns when its status says so."""
+        import torch
+
+        host = torch.empty(tuple(matrix_dev.shape), dtype=matrix_dev.dtype, pin_memory=True)
+        host.copy_(matrix_dev, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.current_stream(matrix_dev.device))
+        self = cls.__new__(cls)
+        self._standard_matrix = host.numpy()
+        self.handle_nans = handle_nans
+        self.nan_check_threshold = nan_check_threshold
+        self._dev_cache = {(matrix_dev.dtype, str(matrix_dev.device)): (self._standard_matrix, matrix_dev)}
+        self._onehot = (self._standard_matrix, None)
+        self._host_ready = ev
+        return self
 
     # ------------------------------------------------------------------ properties
     @property
     def standard_matrix(self) -> np.ndarray:
         """The mapping in standard matrix format."""
+        if self._host_ready is not None:
+            self._host_ready.synchronize()
+            self._host_ready = None
         return self._standard_matrix
 
     @property
     def n_cg_sites(self) -> int:
-        return self.standard_matrix.shape[0]
+        return self._standard_matrix.shape[0]  # (shape and dtype need no finished download)
 
     @property
     def n_fg_sites(self) -> int:
-        return self.standard_matrix.shape[1]
+        return self._standard_matrix.shape[1]
 
     @property
     def participating_fg(self) -> List[List[int]]:
@@ -146,13 +176,15 @@ class LinearMap:
         if self._onehot is None or self._onehot[0] is not self._standard_matrix:
             m = self._standard_matrix
             idx = None
-            if m.size and np.all((m == 0) | (m == 1)) and np.all(m.sum(axis=1) == 1):
+            # (a one-hot matrix has exactly one non-zero per row: the count rejects a dense force map in one pass)
+            if (m.size and np.count_nonzero(m) == m.shape[0] and np.all((m == 0) | (m == 1))
+                    and np.all(m.sum(axis=1) == 1)):
                 idx = np.argmax(m, axis=1).astype(np.int32)
             self._onehot = (m, idx)
         return self._onehot[1]
 
     def _out_dtype(self, points) -> np.dtype:
-        dt = np.result_type(K.np_dtype_of(points), self.standard_matrix.dtype)
+        dt = np.result_type(K.np_dtype_of(points), self._standard_matrix.dtype)
         return dt if dt in (np.float32, np.float64) else np.dtype(np.float64)
 
     def __call__(self, points):
@@ -187,9 +219,9 @@ class LinearMap:
             return K.like_input(K.linearmap_apply(p, m), points)
         # plain product with the NaN scan of the input fused into the same pass; only if a NaN was seen
         # (rare) are the reference's two extra products formed (map/core.py:226-236)
-        probe = torch.zeros(1, dtype=torch.int32, device=p.device)
+        probe = K.take_flag(p.device)
         out = K.linearmap_apply(p, m, nan_probe=probe)
-        if not bool(probe.item()):
+        if not K.read_flag(probe):
             return K.like_input(out, points)
         raw = K.linearmap_apply(p, m, nan_fill=0.0)
         pushed = K.linearmap_apply(p, m, nan_fill=-1.0)
@@ -213,9 +245,9 @@ class LinearMap:
         out_t = K.torch_dtype(self._out_dtype(points))
         p = K.as_device(points)
         m = self._device_matrix(out_t, p.device)
-        probe = torch.zeros(1, dtype=torch.int32, device=p.device)
+        probe = K.take_flag(p.device)
         out, ss = K.linearmap_apply(p, m, want_sumsq=True, nan_probe=probe)
-        if bool(probe.item()):
+        if K.read_flag(probe):
             return self(points), None  # NaN policy: the reference's two extra products (rare)
         return K.like_input(out, points), ss
 

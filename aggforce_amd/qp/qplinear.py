@@ -67,13 +67,15 @@ def _one_hot_rows(A: np.ndarray):
     return cols if len(np.unique(cols)) == m else None
 
 
-def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host: np.ndarray, what: str = "Map optimization"):
-    """Run K2 for all rows of A at once; returns (X device (m, n), stats host)."""
+def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host, what: str = "Map optimization", pins=None):
+    """Run K2 for all rows of A at once; returns (X device (m, n), stats host).  ``pins`` (int32 array): the rows of
+    A are unit vectors at these columns (A_host may then be None); otherwise A_host is inspected for that."""
     import torch
 
     dev = G.device
-    A_host = np.ascontiguousarray(A_host, dtype=np.float64)
-    pins = _one_hot_rows(A_host)
+    if pins is None:
+        A_host = np.ascontiguousarray(A_host, dtype=np.float64)
+        pins = _one_hot_rows(A_host)
     A = None
 
     def solve(l2, n_refine=1):
@@ -134,16 +136,38 @@ class LinearProblem:
         self.n_fg = coord_map.n_fg_sites
         self.goa, self.n_red = group_layout(self.n_fg, constraints if constraints is not None else set())
         self.grp_ptr = self.grp_atoms = None
-        # A = M @ C and diag(C'C) without forming C
-        M = np.asarray(coord_map.standard_matrix, dtype=np.float64)
+        self._csr = None
+        self._A = None
         if self.n_red != self.n_fg:
-            ptr_h, atoms_h = groups_csr(self.goa, self.n_red)
-            self.grp_ptr = torch.from_numpy(ptr_h).to(device)
-            self.grp_atoms = torch.from_numpy(atoms_h).to(device)
-            self.A = np.add.reduceat(M[:, atoms_h], ptr_h[:-1], axis=1)
-        else:
-            self.A = M
+            self._csr = groups_csr(self.goa, self.n_red)
+            self.grp_ptr = torch.from_numpy(self._csr[0]).to(device)
+            self.grp_atoms = torch.from_numpy(self._csr[1]).to(device)
         self.sizes = torch.from_numpy(np.bincount(self.goa, minlength=self.n_red).astype(np.float64)).to(device)
+        self._goa_d = None
+        # a slice coordinate map (the map object caches its row -> atom index): A = M C has unit rows at the reduced
+        # variables of the mapped atoms -- the pinned variables of aggf_eq_qp_solve_pinned; A itself is not formed
+        self.pins = None
+        idx = coord_map._onehot_index() if hasattr(coord_map, "_onehot_index") else None
+        if idx is not None and len(idx) < self.n_red:
+            pins = self.goa[idx].astype(np.int32)
+            if len(np.unique(pins)) == len(pins):
+                self.pins = pins
+
+    @property
+    def A(self) -> np.ndarray:
+        """The constraint rows M @ con_mat (qplinear.py:82), (n_cg, n_red): column sums of the coordinate matrix
+        over each constraint group, without forming con_mat."""
+        if self._A is None:
+            M = np.asarray(self.coord_map.standard_matrix, dtype=np.float64)
+            self._A = M if self._csr is None else np.add.reduceat(M[:, self._csr[1]], self._csr[0][:-1], axis=1)
+        return self._A
+
+    def _goa_dev(self):
+        import torch
+
+        if self._goa_d is None:
+            self._goa_d = torch.from_numpy(self.goa).to(self.device)
+        return self._goa_d
 
     def gram(self, forces, gram_dtype=None, out=None, accumulate: bool = False):
         """K1 on one block of frames; ``out``/``accumulate`` add to an existing Gram (frame chunks)."""
@@ -157,16 +181,15 @@ class LinearProblem:
         return K.gram(forces, self.grp_ptr, self.grp_atoms, self.n_red, cdt, out=out, accumulate=accumulate)
 
     def solve(self, G, l2_regularization: float = 0.0):
-        X, _ = solve_constrained_maps(G, float(l2_regularization), self.sizes, self.A)
+        X, _ = solve_constrained_maps(G, float(l2_regularization), self.sizes, self.A if self.pins is None else None,
+                                      pins=self.pins)
         return X
 
     def tmap(self, X) -> SeperableTMap:
         import torch
 
-        W = K.expand_map(X, torch.from_numpy(self.goa).to(self.device), self.n_fg)
-        force_map = LinearMap(W.cpu().numpy())
-        force_map._dev_cache[(torch.float64, str(self.device))] = (force_map.standard_matrix, W)
-        return SeperableTMap(coord_map=self.coord_map, force_map=force_map)
+        W = K.expand_map(X, self._goa_dev(), self.n_fg)
+        return SeperableTMap(coord_map=self.coord_map, force_map=LinearMap.from_device(W))
 
 
 def qp_linear_map(

@@ -1,0 +1,29 @@
+"""Where the host time of one project_forces step goes (c3 geometry, few frames so that the GPU stages are short):
+cProfile over 30 steps, functions sorted by their own time.  `python tools/c3_hostprof.py [frames]`"""
+import cProfile
+import os
+import pstats
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+from aggforce_amd import LinearMap, project_forces  # noqa: E402
+from aggforce_amd import _kernels as K  # noqa: E402
+
+T = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
+N, n_cg = 4096, 256
+forces = K.synth_normal(T, N, torch.float64, 1, sigma=30.0)
+coords = K.synth_normal(T, N, torch.float64, 2, sigma=0.3, lattice=1.5)
+cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
+for _ in range(3):
+    project_forces(coords, forces, cmap, constrained_inds=set())
+torch.cuda.synchronize()
+pr = cProfile.Profile()
+pr.enable()
+for _ in range(30):
+    project_forces(coords, forces, cmap, constrained_inds=set())
+torch.cuda.synchronize()
+pr.disable()
+st = pstats.Stats(pr)
+st.sort_stats("tottime").print_stats(22)
