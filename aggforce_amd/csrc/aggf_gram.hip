@@ -306,6 +306,21 @@ __device__ __forceinline__ void wait_vmcnt() {
   else static_assert(N == 0, "unsupported vmcnt");
 }
 
+template <int MAXN>
+__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
+  // s_waitcnt takes an immediate: dispatch on the (wave-uniform) count
+  if (n <= 0) wait_vmcnt<0>();
+  else if (n == 1) wait_vmcnt<1>();
+  else if (n == 2) wait_vmcnt<2>();
+  else if (n == 3) wait_vmcnt<3>();
+  else if (n == 4) wait_vmcnt<4>();
+  else if (n == 5) wait_vmcnt<5>();
+  else if (n == 6) wait_vmcnt<6>();
+  else if (n == 7) wait_vmcnt<7>();
+  else wait_vmcnt<8>();
+  static_assert(MAXN <= 8, "extend the dispatch");
+}
+
 #ifdef AGGF_SMALL_PROF
 // tools/small_probe.hip: shader cycles per wave of the small-system kernel spent in park (incl. the wait for the
 // fetched frames) / group sums / MFMA / the three barriers, and the stage count
@@ -652,6 +667,226 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
       }
 }
 
+// ---------------------------------------------------------------------------
+// The tile kernel for everything that is NOT a ready-made panel in HBM: constraint groups (`@ con_mat`,
+// qplinear.py:69-70), float32 trajectories with float64 products (the reference's arithmetic: con_mat is float64),
+// site counts that are no multiple of 128.  Round 2 wrote a packed float64 copy of the trajectory for these
+// (pack_groups_kernel: 98 GB read + 66 GB written at C3 with bond-pair constraints) and ran the panel kernel on it.
+// Here the raw frame rows travel HBM -> LDS by the same LDS-DMA ring, exactly as they lie in HBM, and the group sums,
+// the dtype conversion and the zero padding happen in the MFMA OPERAND READ: lane (column c, row r) adds up the
+// members of column c from the raw row (up to MAXM of them; a bit mask selects the ones that exist).
+//   col_off[c * MAXM + j] = 3 * atom of member j of reduced column c (element offset inside a frame), -1 = none;
+//   panel_lo[p]           = first atom of the window of panel p (its 128 columns' members lie in
+//                           [panel_lo[p], panel_lo[p] + span_atoms));
+//   row_slot              = LDS bytes per staged row: the window (span_atoms * 3 * sizeof(TIn) + 16 for the 16-byte
+//                           alignment of the first piece), rounded to 16, + 32 so that the four rows of an operand
+//                           read start in different banks.
+// A row's window starts at an arbitrary 4/8-byte aligned address: the DMA pieces start at the 16-byte boundary below
+// it and the operand offsets carry the misalignment, which depends on the row only through (row mod 4) because every
+// stage starts at a multiple of 4 frames.  Requirements (checked by the host side, else the pack path is taken):
+// F 16-byte aligned, T * 3N * sizeof(TIn) a multiple of 16, at most MAXM <= 4 members per column, two stages in 80 KB.
+template <typename TIn, typename TC, int MAXM>
+__global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
+    const TIn* __restrict__ F, int64_t n_rows, int32_t N, const int32_t* __restrict__ col_off,
+    const int32_t* __restrict__ panel_lo, int32_t span_bytes, int32_t row_slot, int32_t nbuf, int32_t nt1,
+    int32_t n_tiles, int32_t ksplit, const int32_t* __restrict__ tile_table, int64_t frames_per_split,
+    TC* __restrict__ slabs) {
+  using M = Mfma<TC>;
+  using acc_t = typename M::acc_t;
+  constexpr int KB = GramCfg<TC>::KB;   // 4 (float64 products) or 8 (float32 products)
+  constexpr int NW = 8, WN = 4, WCOLS = 32, NACC = 2;
+  constexpr int SI = (int)sizeof(TIn);
+  constexpr int GROUPS = 3 * KB / 4;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  char* smem = smem_raw;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  const int b = blockIdx.x;
+  const int v = (((b >> 3) >> 6) * 8 + (b & 7)) * 64 + ((b >> 3) & 63);  // XCD-aware order, see gram_tile_dma_kernel
+  if (v >= ksplit * n_tiles) return;
+  const int ks = v / n_tiles;
+  const int packed = tile_table[v - ks * n_tiles];
+  const int ti = packed >> 16, tj = packed & 0xffff;
+  const int tile_lin = ti * nt1 - ti * (ti - 1) / 2 + (tj - ti);
+
+  const int64_t t_begin = (int64_t)ks * frames_per_split;  // a multiple of KB (hence of 4)
+  int64_t t_end = t_begin + frames_per_split;
+  if (t_end > n_rows) t_end = n_rows;
+  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KB - 1) / KB) : 0;
+  const int64_t row_bytes = (int64_t)N * 3 * SI;
+  const int stage_bytes = 2 * KB * row_slot;
+
+  // windows of the two panels: first atom (clamped: a bad table must not send a DMA outside the array)
+  int lo[2];
+  lo[0] = panel_lo[ti];
+  lo[1] = panel_lo[tj];
+#pragma unroll
+  for (int p = 0; p < 2; ++p) lo[p] = lo[p] < 0 ? 0 : (lo[p] > N - 1 ? N - 1 : lo[p]);
+  const char* Fb = reinterpret_cast<const char*>(F);
+  const int64_t f_end = (int64_t)n_rows * row_bytes;  // a multiple of 16 (host-checked)
+  // byte misalignment of row r's window (r mod 4 decides, see above)
+  auto mis_of = [&](int p, int r) { return (int)((((int64_t)r * row_bytes) + (int64_t)lo[p] * 3 * SI) & 15); };
+
+  // operand offsets (bytes inside a stage): row term + member offset; absent members alias the slot's first element
+  // and are masked out.  f64: the lane's row is (lane >> 4); f32: rows (lane >> 4) and (lane >> 4) + 4 (same
+  // misalignment), the second one 4 * row_slot further on.
+  const int r_lane = lane >> 4;
+  int offA[4][MAXM], offB[NACC][MAXM];
+  unsigned maskA = 0, maskB = 0;
+  {
+    const int baseA = r_lane * row_slot + mis_of(0, r_lane);
+    const int baseB = KB * row_slot + r_lane * row_slot + mis_of(1, r_lane);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      const int c = ti * TILE + wm * 64 + 16 * m + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < MAXM; ++j) {
+        const int e = col_off[(int64_t)c * MAXM + j];
+        const int rel = (e - 3 * lo[0]) * SI;
+        const bool ok = e >= 0 && rel >= 0 && rel + 3 * SI <= span_bytes;
+        offA[m][j] = baseA + (ok ? rel : 0);
+        maskA |= ok ? (1u << (m * MAXM + j)) : 0u;
+      }
+    }
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) {
+      const int c = tj * TILE + wn * WCOLS + 16 * n + (lane & 15);
+#pragma unroll
+      for (int j = 0; j < MAXM; ++j) {
+        const int e = col_off[(int64_t)c * MAXM + j];
+        const int rel = (e - 3 * lo[1]) * SI;
+        const bool ok = e >= 0 && rel >= 0 && rel + 3 * SI <= span_bytes;
+        offB[n][j] = baseB + (ok ? rel : 0);
+        maskB |= ok ? (1u << (n * MAXM + j)) : 0u;
+      }
+    }
+  }
+
+  // DMA pieces of a stage: piece index -> (panel, row, k-th KiB of the row's aligned window); wave w issues pieces
+  // w, w + 8, ...  All of it wave-uniform arithmetic; nothing is kept in arrays.
+  const int ppr = (span_bytes + 16 + 1023) / 1024;        // pieces per row (the +16: alignment slack)
+  const int n_pieces = 2 * KB * ppr;
+  const int my_pieces = wave < n_pieces ? (n_pieces - 1 - wave) / NW + 1 : 0;
+  const int skew = n_it > 16 ? ((ti + tj) & 7) : 0;
+  auto stage_of = [&](int seq) { const int u = seq + skew; return u >= n_it ? u - n_it : u; };
+  // The stage that holds the split's last frames is "irregular": rows past t_end issue nothing, and a piece that
+  // would cross the end of the array is dropped -- the counted wait below must not assume a full stage there.
+  const int ragged_seq = n_it > 0 ? (n_it - 1 - skew + (n_it - 1 - skew < 0 ? n_it : 0)) : -1;
+  auto issue_piece = [&](int seq, int q) {
+    const int pc = wave + NW * q;
+    if (pc >= n_pieces) return;
+    const int panel = pc / (KB * ppr), rem = pc - panel * KB * ppr, r = rem / ppr, k = rem - r * ppr;
+    const int64_t t = t_begin + (int64_t)stage_of(seq) * KB + r;
+    if (t >= t_end) return;
+    const int64_t start = t * row_bytes + (int64_t)lo[panel] * 3 * SI;   // window start (bytes from F)
+    const int64_t al = start & ~(int64_t)15;
+    const int need = (int)(start - al) + span_bytes;                       // bytes wanted from the aligned start
+    const int64_t off = (int64_t)k * 1024 + lane * 16;
+    // (lane 0 of every piece stays active -- 16 bytes of the same array -- so that a regular stage issues exactly
+    // my_pieces instructions per wave whatever the alignment)
+    if ((off < need || lane == 0) && al + off + 16 <= f_end) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(Fb + al + off),
+          (__attribute__((address_space(3))) void*)(smem + (seq % nbuf) * stage_bytes + panel * KB * row_slot + r * row_slot + k * 1024),
+          16, 0, 0);
+    }
+  };
+  auto prep_stage = [&](int seq) {  // rows past the end of the split read as zeros (one ragged stage at most)
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
+    if (t0 + KB > t_end) {
+      const int first = (int)(t_end - t0);
+      char* base = smem + (seq % nbuf) * stage_bytes;
+      for (int e = tid * 4; e < 2 * (KB - first) * row_slot; e += 512 * 4) {
+        const int panel = e / ((KB - first) * row_slot), rem = e - panel * (KB - first) * row_slot;
+        *reinterpret_cast<int*>(base + panel * KB * row_slot + first * row_slot + rem) = 0;
+      }
+    }
+  };
+  auto wait_landed = [&](bool newest_full) {  // everything but the newest stage's pieces of this wave
+    if (newest_full) wait_vmcnt_dyn<8>(my_pieces); else wait_vmcnt<0>();
+  };
+
+  acc_t acc[4][NACC];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < NACC; ++n) acc[m][n] = acc_zero<TC>();
+
+  const int ahead = nbuf - 1;
+  for (int s0 = 0; s0 < ahead && s0 < n_it; ++s0) {
+    prep_stage(s0);
+    for (int q = 0; q < my_pieces; ++q) issue_piece(s0, q);
+  }
+  wait_landed(ahead > 1 && n_it > 1 && ragged_seq != 1);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int it = 0; it < n_it; ++it) {
+    const bool issue_now = it + ahead < n_it;
+    if (issue_now) prep_stage(it + ahead);
+    const char* st = smem + (it % nbuf) * stage_bytes;
+    int q_next = 0;
+#pragma unroll
+    for (int kk = 0; kk < KB / 4; ++kk) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int g = kk * 3 + d;
+        const int sh = kk * 4 * row_slot + d * SI;
+        TC a[4], bb[NACC];
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+          TC sum = 0;
+#pragma unroll
+          for (int j = 0; j < MAXM; ++j) {
+            const TIn x = *reinterpret_cast<const TIn*>(st + offA[m][j] + sh);
+            sum += (maskA >> (m * MAXM + j)) & 1u ? (TC)x : (TC)0;   // members in table order, like `@ con_mat`
+          }
+          a[m] = sum;
+        }
+#pragma unroll
+        for (int n = 0; n < NACC; ++n) {
+          TC sum = 0;
+#pragma unroll
+          for (int j = 0; j < MAXM; ++j) {
+            const TIn x = *reinterpret_cast<const TIn*>(st + offB[n][j] + sh);
+            sum += (maskB >> (n * MAXM + j)) & 1u ? (TC)x : (TC)0;
+          }
+          bb[n] = sum;
+        }
+        // this group's share of the DMAs of stage it + ahead, between the operand reads and the MFMAs
+        if (issue_now) {
+          const int upto = (my_pieces * (g + 1) + GROUPS - 1) / GROUPS;
+          for (; q_next < upto; ++q_next) issue_piece(it + ahead, q_next);
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m)
+#pragma unroll
+          for (int n = 0; n < NACC; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+      }
+    }
+    // stage it+1 must have landed before anyone reads it; with three slots stage it+2 may stay in flight
+    wait_landed(ahead > 1 && it + 2 < n_it && it + 2 != ragged_seq);
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+  }
+
+  TC* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < NACC; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + m * 16 + M::row(lane, r);
+        const int col = wn * WCOLS + n * 16 + (lane & 15);
+        slab[row * TILE + col] = acc[m][n][r];
+      }
+}
+
 // tile_table[k] = (ti << 16) | tj of the k-th upper-triangle tile in 8x8 super-block order
 // (tiles with tj < first_tile -- a leading block the caller already has -- are left out)
 __global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table, int32_t first_tile = 0) {
@@ -733,20 +968,6 @@ __global__ void build_pair_table_kernel(int32_t nt1, PairEntry* __restrict__ tab
   }
 }
 
-template <int MAXN>
-__device__ __forceinline__ void wait_vmcnt_dyn(int n) {
-  // s_waitcnt takes an immediate: dispatch on the (wave-uniform) count
-  if (n <= 0) wait_vmcnt<0>();
-  else if (n == 1) wait_vmcnt<1>();
-  else if (n == 2) wait_vmcnt<2>();
-  else if (n == 3) wait_vmcnt<3>();
-  else if (n == 4) wait_vmcnt<4>();
-  else if (n == 5) wait_vmcnt<5>();
-  else if (n == 6) wait_vmcnt<6>();
-  else if (n == 7) wait_vmcnt<7>();
-  else wait_vmcnt<8>();
-  static_assert(MAXN <= 8, "extend the dispatch");
-}
 
 template <typename T, int ABL = 0>
 __global__ __launch_bounds__(PAIR_THREADS, 1) void gram_pair_dma_kernel(
@@ -1947,6 +2168,102 @@ extern "C" int aggf_gram_pair(const void* F, int32_t N, const void* F2, int32_t 
   if (dtype == AGGF_F64)
     return gram_pair_typed<double>((const double*)F, (const double*)F2, T, N, N2, p, w, G, accumulate, stream);
   return gram_pair_typed<float>((const float*)F, (const float*)F2, T, N, N2, p, w, G, accumulate, stream);
+}
+
+// ---- fused constraint sums / conversion / padding: the raw trajectory through the gather tile kernel -----------
+struct GatherGeom {
+  int span_bytes, row_slot, nbuf;
+};
+// LDS geometry for a window of span_atoms atoms of `in_size`-byte elements; nbuf == 0: does not fit two stages
+static GatherGeom gather_geom(int32_t span_atoms, int in_size, int kb) {
+  GatherGeom g;
+  g.span_bytes = span_atoms * 3 * in_size;
+  g.row_slot = (int)round_up(g.span_bytes + 16, 16) + 32;
+  if ((g.row_slot / 32) % 2 == 0) g.row_slot += 32;  // odd multiple of 32 bytes: the 4 rows of an operand read start 8 banks apart
+  const int stage = 2 * kb * g.row_slot;
+  g.nbuf = 3 * stage <= 80 * 1024 ? 3 : 2 * stage <= 80 * 1024 ? 2 : 0;
+  return g;
+}
+
+template <typename TIn, typename TC, int MAXM>
+static int gram_gather_launch(const TIn* F, int64_t T, int32_t N, const int32_t* col_off, const int32_t* panel_lo,
+                              const GatherGeom& g, const GramPlan& p, char* ws, double* G, int32_t n_red, int accumulate,
+                              hipStream_t stream) {
+  constexpr int KB = GramCfg<TC>::KB;
+  int32_t* tile_table = reinterpret_cast<int32_t*>(ws);
+  TC* slabs = reinterpret_cast<TC*>(ws + table_bytes(p));
+  const int ksplit = p.ksplit;
+  int64_t fps = round_up(ceil_div(T, ksplit), KB);
+  if (fps < KB) fps = KB;
+  const size_t lds = (size_t)g.nbuf * 2 * KB * g.row_slot;
+  static thread_local PerDeviceOnce attr_once;
+  bool& attr_done = *attr_once.flag();
+  if (!attr_done) {
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_gather_kernel<TIn, TC, MAXM>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
+    attr_done = true;
+  }
+  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, 0);
+  AGGF_LAUNCH_OK();
+  const int64_t nblk = (int64_t)ksplit * p.n_tiles;
+  if (nblk > 0x7fffff00LL) return fail(AGGF_ERR_ARG, "gram grid too large");
+  hipLaunchKernelGGL((gram_tile_gather_kernel<TIn, TC, MAXM>), dim3((unsigned)round_up(nblk, 512)), dim3(512), lds, stream,
+                     F, T, N, col_off, panel_lo, g.span_bytes, g.row_slot, g.nbuf, p.nt1, p.n_tiles, ksplit, tile_table,
+                     fps, slabs);
+  AGGF_LAUNCH_OK();
+  hipLaunchKernelGGL((gram_reduce_kernel<TC>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit,
+                     n_red, accumulate, G, 0);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gram_gather_supported(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
+                                          int32_t max_members, int32_t span_atoms) {
+  if (T <= 0 || N <= 0 || n_red <= TILE || n_red > N || max_members < 1 || max_members > 4 || span_atoms < 1) return 0;
+  if ((in_dtype != AGGF_F32 && in_dtype != AGGF_F64) || (compute_dtype != AGGF_F32 && compute_dtype != AGGF_F64)) return 0;
+  if (in_dtype == AGGF_F64 && compute_dtype == AGGF_F32) return 0;
+  const int in_size = (int)dtype_size(in_dtype);
+  if ((T * (int64_t)N * 3 * in_size) % 16 != 0) return 0;
+  return gather_geom(span_atoms, in_size, compute_dtype == AGGF_F64 ? 4 : 8).nbuf > 0;
+}
+
+extern "C" size_t aggf_gram_gather_workspace_bytes(int64_t T, int32_t n_red, int compute_dtype) {
+  if (T <= 0 || n_red <= 0) return 0;
+  const int32_t n_pad = (int32_t)round_up(n_red, TILE);
+  return aggf_gram_workspace_bytes(T, n_pad, n_pad, compute_dtype, compute_dtype, 0);  // tile table + slabs, no pack chunk
+}
+
+extern "C" int aggf_gram_gather(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
+                                const int32_t* col_off, int32_t max_members, const int32_t* panel_lo, int32_t span_atoms,
+                                int32_t n_red, double* G, int accumulate, void* ws, size_t ws_bytes, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!F || !col_off || !panel_lo || !G || !ws) return fail(AGGF_ERR_ARG, "aggf_gram_gather: NULL pointer");
+  if (!aggf_gram_gather_supported(T, N, n_red, in_dtype, compute_dtype, max_members, span_atoms))
+    return fail(AGGF_ERR_ARG, "aggf_gram_gather: layout not supported (see aggf_gram_gather_supported); use aggf_gram");
+  if (((uintptr_t)F & 15) != 0) return fail(AGGF_ERR_ARG, "aggf_gram_gather: F must be 16-byte aligned");
+  if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram_gather: workspace not 256-byte aligned");
+  const int32_t n_pad = (int32_t)round_up(n_red, TILE);
+  GramPlan p;
+  int rc = make_plan(T, n_pad, n_pad, compute_dtype, compute_dtype, false, true, ws_bytes, false, &p, 0);
+  if (rc) return rc;
+  if (!p.direct || p.staging == STAGE_SMALL) return fail(AGGF_ERR_ARG, "aggf_gram_gather: unsupported layout");
+  p.staging = STAGE_DMA8;
+  p.n_entries = p.n_tiles;
+  if (table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) > ws_bytes)
+    return fail(AGGF_ERR_WORKSPACE, "aggf_gram_gather: workspace too small");
+  const GatherGeom g = gather_geom(span_atoms, (int)dtype_size(in_dtype), compute_dtype == AGGF_F64 ? 4 : 8);
+  char* w = reinterpret_cast<char*>(ws);
+  const int mm = max_members <= 1 ? 1 : max_members <= 2 ? 2 : 4;
+#define AGGF_GG(TIN, TCC)                                                                                             \
+  do {                                                                                                                \
+    if (mm == 1) return gram_gather_launch<TIN, TCC, 1>((const TIN*)F, T, N, col_off, panel_lo, g, p, w, G, n_red, accumulate, stream); \
+    if (mm == 2) return gram_gather_launch<TIN, TCC, 2>((const TIN*)F, T, N, col_off, panel_lo, g, p, w, G, n_red, accumulate, stream); \
+    return gram_gather_launch<TIN, TCC, 4>((const TIN*)F, T, N, col_off, panel_lo, g, p, w, G, n_red, accumulate, stream);  \
+  } while (0)
+  if (in_dtype == AGGF_F64) AGGF_GG(double, double);
+  if (compute_dtype == AGGF_F64) AGGF_GG(float, double);
+  AGGF_GG(float, float);
+#undef AGGF_GG
 }
 
 extern "C" int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,
