@@ -204,11 +204,14 @@ def gather_layout(n_fg: int, n_red: int, csr=None):
 
 
 def gram_gather_ok(forces: torch.Tensor, n_red: int, compute_dtype: torch.dtype, layout) -> bool:
-    """Can aggf_gram_gather take this trajectory / layout?  (AGGF_GRAM_GATHER=0 in the environment says no: the
-    packed-copy pipeline of aggf_gram, for measurements and tests.)"""
+    """Should (and can) aggf_gram_gather take this trajectory / layout?  OPT-IN, AGGF_GRAM_GATHER=1 in the
+    environment: measured on MI355X (tools/gather_bench.py, profiles/r03_gather_vs_packed.txt) the fused kernel
+    reaches 0.33-0.57 of the MFMA peak where the packed copy + panel kernel reach 0.70-0.82 INCLUDING the pack pass,
+    so the packed pipeline stays the default; the fused kernel is for trajectories that leave no HBM for the packed
+    chunk (it needs the tile table and the slabs only)."""
     import os
 
-    if layout is None or os.environ.get("AGGF_GRAM_GATHER", "1") == "0" or not forces.is_contiguous():
+    if layout is None or os.environ.get("AGGF_GRAM_GATHER", "0") != "1" or not forces.is_contiguous():
         return False
     if forces.data_ptr() % 16 or forces.shape[1] != layout["n_fg"]:
         return False
