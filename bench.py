@@ -172,12 +172,12 @@ def replicated_spread(t, world):
 
 def profiled_traffic(workload, world):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
-    (profiles/r02_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
+    (profiles/r03_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
     and counts 128-byte requests as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM): x 2."""
     if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_rocprof_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_c3_rocprof_summary.json")))
         rd = [e["FETCH_SIZE"]["per_dispatch"] for e in d["pmc_fetch"] if "gram_tile" in e["kernel"]][0]
         wr = [e["WRITE_SIZE"]["per_dispatch"] for e in d.get("pmc_write", []) if "gram_tile" in e["kernel"]]
         return 2.0 * rd * 1024 + (wr[0] * 1024 if wr else 0.0)
@@ -188,7 +188,7 @@ def profiled_traffic(workload, world):
 def profile_label():
     """Where `traffic` / `mfma_busy_frac_pmc` come from: PMC passes are separate rocprofv3 runs by construction, so
     the line quotes the committed profile and says which one (file, commit and date that last touched it)."""
-    rel = "profiles/r02_c3_rocprof_summary.json"
+    rel = "profiles/r03_c3_rocprof_summary.json"
     label = f"{rel} (separate rocprofv3 --pmc passes; NOT measured in this run)"
     try:
         out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cI", "--", rel], stdout=subprocess.PIPE,
@@ -202,11 +202,11 @@ def profile_label():
 
 def profiled_mfma_busy(workload, world):
     """Fraction of the Gram kernel's cycles in which the MFMA pipes were busy, from the committed PMC pass
-    (profiles/r02_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    (profiles/r03_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
     if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r02_c3_mfma_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r03_c3_mfma_counters.json")))
         return [v["mfma_utilisation"] for k, v in d["kernels"].items() if "gram_tile" in k][0]
     except Exception:
         return None
