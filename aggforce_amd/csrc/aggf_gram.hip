@@ -1311,28 +1311,25 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
       if (v < n_vec) reinterpret_cast<v16_t*>(raw)[v] = hold[i];
     }
   };
-  // raw frames -> MFMA panel: group sums in the compute dtype (frames past t_end were fetched as zeros).
-  // An entry e = tid + SM_THREADS * i of a stage is always the same (frame slot, reduced column, xyz), so its member
-  // list is loop-invariant: looked up once, here, and kept in registers (round 2 re-read the table from LDS in every
-  // stage and then read four raw values whatever the group size -- 30 LDS reads per thread and stage, 2700 of the
-  // stage's 9800 cycles; CLN025's columns have 1.8 members on average and a quarter of the 128 columns is padding).
-  __syncthreads();
-  uint2 m_off[SM_ENT];
-#pragma unroll
-  for (int i = 0; i < SM_ENT; ++i) m_off[i] = *reinterpret_cast<const uint2*>(memb_s + ((tid + SM_THREADS * i) % ROW_ELEMS) * 4);
-  const int row_in_i = (int)row_in;
+  // raw frames -> MFMA panel: group sums in the compute dtype (frames past t_end were fetched as zeros)
   auto reduce_groups = [&]() {
+    // all entries' table reads first, then all raw reads, then the sums: six independent LDS chains in flight at
+    // once (with the rare-large-group loop inside the per-entry body the chains ran one after the other)
     TC sum[SM_ENT];
+    uint2 mem[SM_ENT];
 #pragma unroll
     for (int i = 0; i < SM_ENT; ++i) {
-      const int o0 = m_off[i].x & 0xFFFF, o1 = m_off[i].x >> 16, o2 = m_off[i].y & 0xFFFF, o3 = m_off[i].y >> 16;
-      const int mb = ((tid + SM_THREADS * i) / ROW_ELEMS) * row_in_i;  // frame slot of the entry
-      // members in CSR order, like the column sum of `@ con_mat`; absent members are not read at all
-      TC v = o0 != 0xFFFF ? (TC)raw[mb + o0] : (TC)0;
-      if (o1 != 0xFFFF) v += (TC)raw[mb + o1];
-      if (o2 != 0xFFFF) v += (TC)raw[mb + o2];
-      if (o3 != 0xFFFF) v += (TC)raw[mb + o3];
-      sum[i] = v;
+      const int e = tid + SM_THREADS * i;  // (frame in stage, reduced column, xyz); padding columns sum nothing
+      mem[i] = *reinterpret_cast<const uint2*>(memb_s + (e % ROW_ELEMS) * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < SM_ENT; ++i) {
+      const int e = tid + SM_THREADS * i;
+      const int base = (e / ROW_ELEMS) * (int)row_in;
+      const int o0 = mem[i].x & 0xFFFF, o1 = mem[i].x >> 16, o2 = mem[i].y & 0xFFFF, o3 = mem[i].y >> 16;
+      const TC v0 = (TC)raw[o0 == 0xFFFF ? zero_idx : base + o0], v1 = (TC)raw[o1 == 0xFFFF ? zero_idx : base + o1],
+               v2 = (TC)raw[o2 == 0xFFFF ? zero_idx : base + o2], v3 = (TC)raw[o3 == 0xFFFF ? zero_idx : base + o3];
+      sum[i] = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
     }
     if (big_groups) {
 #pragma unroll
