@@ -58,3 +58,29 @@ def test_bench_variants_of_the_linear_workload(variant):
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
     if variant == "pairs":
         assert "n_red 171" in line["cpu_baseline"]["sample"] and "pack_groups_kernel" in line["roofline"]["kernel"]
+
+
+def test_bench_under_torchrun_one_rank_uses_rccl():
+    """The driver's N > 1 form -- `python -m torch.distributed.run --nproc-per-node N bench.py --gpus N` -- with the
+    one rank this box can hold: the process group is RCCL (backend nccl), the Gram matrix goes through the (world of
+    one) all-reduce path, and the line says so."""
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    proc = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1",
+                           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.join(ROOT, "bench.py"),
+                           "--gpus", "1", "--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline"],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=ROOT)
+    assert proc.returncode == 0, proc.stderr.decode(errors="replace")[-3000:]
+    lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip().startswith("{")]
+    assert len(lines) == 1, proc.stdout.decode()[-2000:]
+    line = json.loads(lines[0])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["backend"] == "nccl (RCCL)" and cfg["world_size_seen"] == 1
+    assert "RCCL all-reduce" in cfg["collective"] and cfg["replicated_solve_max_abs_diff_across_ranks"] == 0.0
+    assert cfg["constraint_residual"] < 1e-8 and line["value"] > 0
