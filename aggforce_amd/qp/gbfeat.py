@@ -273,7 +273,16 @@ def fit_id_gb(
     # float32 products of float32 forces widened on store -- K1 multiplies in float64, see below), feature
     # columns padded to a multiple of the 128-wide tile.  No pack pass, no float32 round trip.
     ld = -(-n_max // 128) * 128
-    R3 = torch.zeros((geo.T, ld, 3), dtype=torch.float64, device=geo.dev)
+    # The sites' K1 launches are short (4.5 ms at BASELINE config 4: ~140 tiles x a few frame ranges on 512 workgroup
+    # slots) and end in a tail of half-empty CUs; dealt over a few streams, each with its own regression-matrix
+    # buffer, the next site's workgroups fill the slots the previous launch leaves idle (AGGF_FEAT_STREAMS, default 3)
+    import os
+
+    n_str = max(1, min(8, int(os.environ.get("AGGF_FEAT_STREAMS", "3"))))
+    main_stream = torch.cuda.current_stream(geo.dev)
+    streams = K.side_streams(geo.dev, n_str) if n_str > 1 else [main_stream]
+    R3s = [torch.zeros((geo.T, ld, 3), dtype=torch.float64, device=geo.dev) for _ in range(n_str)]
+    lead_ready = None  # event: the first site's Gram matrix (the shared leading block) is complete
     # Sites are independent problems (own P, own A, one right-hand side): a batch of them is fitted side by
     # side -- K1 per site into one (sites, n_max, n_max) stack, ONE all-reduce of the stack, then ONE batched
     # K2 in which every step of the factorisation is a single launch over all sites.  (One solve alone is a
@@ -290,7 +299,14 @@ def fit_id_gb(
         Gs = torch.zeros((len(sites), n_max, n_max), dtype=torch.float64, device=geo.dev)
         As = torch.empty((len(sites), S * n_cg, n_max), dtype=torch.float64, device=geo.dev)
         bs = torch.empty((len(sites), S * n_cg, 1), dtype=torch.float64, device=geo.dev)
+        phase = K._timed("fit_sites")  # main-stream bracket of the whole site loop (the per-launch timers overlap)
+        phase.__enter__()
+        for st in streams:
+            if st is not main_stream:
+                st.wait_stream(main_stream)
         for j, site in enumerate(sites):
+          with torch.cuda.stream(streams[j % n_str]):
+            R3 = R3s[j % n_str]
             cols = torch.from_numpy(cols_of[site]).to(geo.dev)
             na = n_act[site]
             K.gb_regmat_cols(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, cols, centers, width, CLIP, kbt, R3)
@@ -307,9 +323,12 @@ def fit_id_gb(
                 Gsite = torch.empty((na, na), dtype=torch.float64, device=geo.dev)
                 K.gram(R3, None, None, na, torch.float64, out=Gsite, first_col=lead)
             if lead:
+                torch.cuda.current_stream(geo.dev).wait_event(lead_ready)
                 Gsite[:lead, :lead] = shared_lead
             elif shared_lead is None and n_id >= 128:
                 shared_lead = Gsite[: (n_id // 128) * 128, : (n_id // 128) * 128].clone()
+                lead_ready = torch.cuda.Event()
+                lead_ready.record(torch.cuda.current_stream(geo.dev))
             if na != n_max:
                 Gs[j, :na, :na] = Gsite
                 Gs[j].diagonal()[na:] = 1.0
@@ -319,6 +338,10 @@ def fit_id_gb(
                 gauss, _ = K.gb_channels(Pg_sel[lo_s:hi_s].contiguous(), cg_sel[lo_s:hi_s].contiguous(), site,
                                          geo.sizes, n_ch, centers, width, CLIP)
             K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j], cols=cols)  # K4b
+        for st in streams:
+            if st is not main_stream:
+                main_stream.wait_stream(st)
+        phase.__exit__(None, None, None)
         all_reduce_sum_sym_(Gs, comm)
         X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3)
         st_all = stats.cpu().numpy()
