@@ -129,3 +129,21 @@ def test_project_forces_with_noised_method_in_place():
     dev = out["mapped_coords"].double() - coords[:, ::4, :][:, :n_cg].double()
     assert abs(dev.var().item() / 0.01 - 1.0) < 2e-2
     assert np.isfinite(out["residual"]) and out["residual"] > 0
+
+
+def test_generated_sites_equal_the_extended_arrays_bit_for_bit():
+    """aggf_condnormal_sites draws the noise aggf_condnormal_augment draws (same Philox stream and expressions), also
+    for shards whose first element is not quad-aligned in the global stream."""
+    from aggforce_amd.trajectory import CondNormal
+
+    rng = np.random.default_rng(2)
+    for T, N, n_cg, off in [(257, 40, 5, 3), (100, 64, 16, 0), (33, 9, 3, 1_000_001)]:
+        coords = rng.random((T, N, 3)).astype(np.float32)
+        forces = rng.standard_normal((T, N, 3)).astype(np.float32)
+        cmap = LinearMap([[i, i + 1] for i in range(n_cg)], n_fg_sites=N)
+        a = CondNormal(var=0.09, premap=cmap, seed=77, frame_offset=off)
+        b = CondNormal(var=0.09, premap=cmap, seed=77, frame_offset=off)
+        for _ in range(2):                                  # two draws: the per-call stream offset advances alike
+            oc, of = a.augment_trajectory(coords, forces, KBT)
+            y, fa, _ = b.noise_sites(coords, KBT)
+            assert np.array_equal(oc[:, N:, :], y.cpu().numpy()) and np.array_equal(of[:, N:, :], fa.cpu().numpy())
