@@ -1,5 +1,5 @@
 """Test geometries of the featurised fit at 20 constraint frames per site (TEST INFRASTRUCTURE, like everything
-under oracle/): shared by tests/test_gpu_feat20.py, tests/test_oracle_golden.py and tools/feat_conditioning.py.
+under oracle/): shared by tests/test_gpu_feat20.py, tests/test_oracle_golden.py and oracle/feat_conditioning.py.
 
 Every geometry is a seeded synthetic trajectory; cg sites never coincide with a (group-mean) atom position, because
 at r = 0 the reference's norm gradient is NaN (jaxfeat.py:451 through jnp.linalg.norm)."""
@@ -27,7 +27,7 @@ def geometry(name):
         # 14 atoms in a 6 A box, widely varying distances; two-atom sites touching pair/chain constraints.
         # "_degenerate": site 2 averages two UNCONSTRAINED atoms, so both are exactly equidistant from the site
         # (it is their midpoint), their Gaussian rows coincide in exact arithmetic and the constraint rows lose
-        # rank -- a rank that float32 rounding of the features restores (see tools/feat_conditioning.py)
+        # rank -- a rank that float32 rounding of the features restores (see oracle/feat_conditioning.py)
         rng = np.random.default_rng(0)
         T, N = 60, 14
         coords = 6 * rng.random((T, N, 3)) + 1

@@ -1,7 +1,7 @@
 """Conditioning of the featurised fit (featlinearmap.py:349-384) at 20 constraint frames per site -- CPU only,
 the oracle against itself.  Backs the tolerances of tests/test_gpu_feat20.py:
 
-    python tools/feat_conditioning.py > profiles/r03_feat_conditioning.txt
+    python oracle/feat_conditioning.py > profiles/r03_feat_conditioning.txt
 
 Per geometry and cg site: numerical rank of the 20 n_cg constraint rows for float64 / float32 features, the
 smallest kept singular value, the condition number of the reduced Hessian Z'(R'R + l2 I)Z, and how far the EXACT
@@ -16,7 +16,7 @@ import sys
 
 import numpy as np
 
-sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))  # repo root
 from oracle import aggforce_oracle as orc  # noqa: E402
 from oracle.feat_cases import GEOMETRIES, KBT, L2, dense_features, geometry, numerical_rank  # noqa: E402
 

@@ -1,7 +1,7 @@
 """GPU: the featurised fit at the reference's default of 20 constraint frames per site
 (featlinearmap.py:254,445-459), end to end against the CPU oracle.
 
-Two regimes (`tools/feat_conditioning.py`):
+Two regimes (`oracle/feat_conditioning.py`):
 
 * ``feature_dtype=np.float64`` -- product and oracle evaluate the same expressions in the same arithmetic:
   coefficients within 1e-6, mapped forces within 1e-7.  The constraint rows are rank deficient by construction
