@@ -126,6 +126,16 @@ class LinearMap:
         self._host_ready = ev
         return self
 
+    def __getstate__(self):
+        """Maps are plain objects that users pickle (the reference's are): finish a pending download, keep the
+        matrix as an ordinary array and drop what belongs to this process (device copies, events)."""
+        state = dict(self.__dict__)
+        state["_standard_matrix"] = np.array(self.standard_matrix)
+        state["_dev_cache"] = {}
+        state["_onehot"] = None
+        state["_host_ready"] = None
+        return state
+
     # ------------------------------------------------------------------ properties
     @property
     def standard_matrix(self) -> np.ndarray:

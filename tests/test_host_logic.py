@@ -369,3 +369,17 @@ def test_sharded_frame_helpers_gloo(tmp_path):
     assert np.array_equal(g0, g1) and np.array_equal(g0, full[i0])
     for r in range(world):
         assert np.array_equal(np.load(tmp_path / f"mm{r}.npy"), [[0.0, 4.0], [1.0, 5.0]])
+
+
+def test_linear_map_survives_pickling():
+    """Users keep fitted maps by pickling them (the reference's maps are plain Python objects)."""
+    import pickle
+
+    from aggforce_amd import LinearMap
+
+    lm = LinearMap([[0, 2, 3], [4]], n_fg_sites=6, handle_nans="safe", nan_check_threshold=1e-5)
+    lm.tags = {"note": "kept"} if hasattr(lm, "tags") else None
+    back = pickle.loads(pickle.dumps(lm))
+    assert np.array_equal(back.standard_matrix, lm.standard_matrix) and back.handle_nans == "safe"
+    assert back.nan_check_threshold == 1e-5 and back.n_cg_sites == 2 and back.n_fg_sites == 6
+    assert back._dev_cache == {} and back._host_ready is None
