@@ -685,8 +685,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
 // it and the operand offsets carry the misalignment, which depends on the row only through (row mod 4) because every
 // stage starts at a multiple of 4 frames.  Requirements (checked by the host side, else the pack path is taken):
 // F 16-byte aligned, T * 3N * sizeof(TIn) a multiple of 16, at most MAXM <= 4 members per column, two stages in 80 KB.
+constexpr int GA_HDR = 32;     // zeroed bytes in front of every staged row: what absent members and padding columns read
+constexpr int GA_MAXPPW = 6;   // DMA pieces per wave and stage, at most (host-checked)
+
 template <typename TIn, typename TC, int MAXM>
-__global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
+__global__ __launch_bounds__(512, MAXM <= 2 ? 4 : 2) void gram_tile_gather_kernel(
     const TIn* __restrict__ F, int64_t n_rows, int32_t N, const int32_t* __restrict__ col_off,
     const int32_t* __restrict__ panel_lo, int32_t span_bytes, int32_t row_slot, int32_t nbuf, int32_t nt1,
     int32_t n_tiles, int32_t ksplit, const int32_t* __restrict__ tile_table, int64_t frames_per_split,
@@ -726,18 +729,23 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
   for (int p = 0; p < 2; ++p) lo[p] = lo[p] < 0 ? 0 : (lo[p] > N - 1 ? N - 1 : lo[p]);
   const char* Fb = reinterpret_cast<const char*>(F);
   const int64_t f_end = (int64_t)n_rows * row_bytes;  // a multiple of 16 (host-checked)
-  // byte misalignment of row r's window (r mod 4 decides, see above)
+  // byte misalignment of row r's window (r mod 4 decides: every stage starts at a multiple of 4 frames)
   auto mis_of = [&](int p, int r) { return (int)((((int64_t)r * row_bytes) + (int64_t)lo[p] * 3 * SI) & 15); };
 
-  // operand offsets (bytes inside a stage): row term + member offset; absent members alias the slot's first element
-  // and are masked out.  f64: the lane's row is (lane >> 4); f32: rows (lane >> 4) and (lane >> 4) + 4 (same
-  // misalignment), the second one 4 * row_slot further on.
+  // zero headers of every row slot of every ring slot (the DMAs never write there)
+  for (int e = tid; e < nbuf * 2 * KB * (GA_HDR / 4); e += 512) {
+    const int row = e / (GA_HDR / 4), w = e - row * (GA_HDR / 4);
+    *reinterpret_cast<int*>(smem + row * row_slot + w * 4) = 0;
+  }
+
+  // operand offsets (bytes inside a stage): row slot + header + misalignment + member offset; an absent member (and
+  // every member of a padding column) reads the zero header of the lane's row.  f64 products: the lane's row is
+  // (lane >> 4); f32 products: rows (lane >> 4) and (lane >> 4) + 4 (same misalignment), 4 * row_slot apart.
   const int r_lane = lane >> 4;
   int offA[4][MAXM], offB[NACC][MAXM];
-  unsigned maskA = 0, maskB = 0;
   {
-    const int baseA = r_lane * row_slot + mis_of(0, r_lane);
-    const int baseB = KB * row_slot + r_lane * row_slot + mis_of(1, r_lane);
+    const int baseA = r_lane * row_slot, baseB = KB * row_slot + r_lane * row_slot;
+    const int dataA = GA_HDR + mis_of(0, r_lane), dataB = GA_HDR + mis_of(1, r_lane);
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
       const int c = ti * TILE + wm * 64 + 16 * m + (lane & 15);
@@ -746,8 +754,7 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
         const int e = col_off[(int64_t)c * MAXM + j];
         const int rel = (e - 3 * lo[0]) * SI;
         const bool ok = e >= 0 && rel >= 0 && rel + 3 * SI <= span_bytes;
-        offA[m][j] = baseA + (ok ? rel : 0);
-        maskA |= ok ? (1u << (m * MAXM + j)) : 0u;
+        offA[m][j] = baseA + (ok ? dataA + rel : 0);
       }
     }
 #pragma unroll
@@ -758,42 +765,53 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
         const int e = col_off[(int64_t)c * MAXM + j];
         const int rel = (e - 3 * lo[1]) * SI;
         const bool ok = e >= 0 && rel >= 0 && rel + 3 * SI <= span_bytes;
-        offB[n][j] = baseB + (ok ? rel : 0);
-        maskB |= ok ? (1u << (n * MAXM + j)) : 0u;
+        offB[n][j] = baseB + (ok ? dataB + rel : 0);
       }
     }
   }
 
-  // DMA pieces of a stage: piece index -> (panel, row, k-th KiB of the row's aligned window); wave w issues pieces
-  // w, w + 8, ...  All of it wave-uniform arithmetic; nothing is kept in arrays.
-  const int ppr = (span_bytes + 16 + 1023) / 1024;        // pieces per row (the +16: alignment slack)
-  const int n_pieces = 2 * KB * ppr;
-  const int my_pieces = wave < n_pieces ? (n_pieces - 1 - wave) / NW + 1 : 0;
+  // DMA pieces of a stage, fixed per wave: piece index pc = wave + 8 q -> (panel, row, k-th KiB of the row's aligned
+  // window).  Per lane: the byte offset from the stage's first frame row (g_off) and whether the lane takes part.
+  const int ppr = (span_bytes + 15 + 1023) / 1024;        // pieces per row (15: largest misalignment)
+  const int n_pieces = 2 * KB * ppr;                        // a multiple of 8
+  const int ppw = n_pieces / NW;                            // pieces per wave, <= GA_MAXPPW
+  int64_t g_off[GA_MAXPPW];
+  int l_dst[GA_MAXPPW], p_row[GA_MAXPPW];
+  unsigned act = 0;
+#pragma unroll
+  for (int q = 0; q < GA_MAXPPW; ++q) {
+    const int pc = wave + NW * q;
+    const int panel = pc / (KB * ppr), rem = pc - panel * KB * ppr, r = rem / ppr, k = rem - r * ppr;
+    const int pn = panel > 1 ? 1 : panel;
+    const int64_t start = (int64_t)r * row_bytes + (int64_t)lo[pn] * 3 * SI;
+    const int64_t al = start & ~(int64_t)15;
+    const int need = (int)(start - al) + span_bytes;
+    const int off = k * 1024 + lane * 16;
+    g_off[q] = al + k * 1024;  // wave-uniform (scalar registers); the lane's 16 bytes are added when the piece is issued
+    l_dst[q] = pn * KB * row_slot + r * row_slot + GA_HDR + k * 1024;
+    p_row[q] = r;
+    // (lane 0 of every piece stays active -- 16 bytes of the same array -- so that a regular stage issues exactly ppw
+    // instructions per wave whatever the alignment)
+    act |= (q < ppw && (off < need || lane == 0)) ? (1u << q) : 0u;
+  }
   const int skew = n_it > 16 ? ((ti + tj) & 7) : 0;
   auto stage_of = [&](int seq) { const int u = seq + skew; return u >= n_it ? u - n_it : u; };
-  // The stage that holds the split's last frames is "irregular": rows past t_end issue nothing, and a piece that
-  // would cross the end of the array is dropped -- the counted wait below must not assume a full stage there.
-  const int ragged_seq = n_it > 0 ? (n_it - 1 - skew + (n_it - 1 - skew < 0 ? n_it : 0)) : -1;
+  // The stage that holds the split's last frames is "irregular": rows past t_end issue nothing and a piece that would
+  // cross the end of the array is dropped -- the counted waits must not assume a full stage there.
+  const int irr_seq = n_it > 0 ? (n_it - 1 - skew + (n_it - 1 - skew < 0 ? n_it : 0)) : -1;
   auto issue_piece = [&](int seq, int q) {
-    const int pc = wave + NW * q;
-    if (pc >= n_pieces) return;
-    const int panel = pc / (KB * ppr), rem = pc - panel * KB * ppr, r = rem / ppr, k = rem - r * ppr;
-    const int64_t t = t_begin + (int64_t)stage_of(seq) * KB + r;
-    if (t >= t_end) return;
-    const int64_t start = t * row_bytes + (int64_t)lo[panel] * 3 * SI;   // window start (bytes from F)
-    const int64_t al = start & ~(int64_t)15;
-    const int need = (int)(start - al) + span_bytes;                       // bytes wanted from the aligned start
-    const int64_t off = (int64_t)k * 1024 + lane * 16;
-    // (lane 0 of every piece stays active -- 16 bytes of the same array -- so that a regular stage issues exactly
-    // my_pieces instructions per wave whatever the alignment)
-    if ((off < need || lane == 0) && al + off + 16 <= f_end) {
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(Fb + al + off),
-          (__attribute__((address_space(3))) void*)(smem + (seq % nbuf) * stage_bytes + panel * KB * row_slot + r * row_slot + k * 1024),
-          16, 0, 0);
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
+    const int64_t src = t0 * row_bytes + g_off[q] + lane * 16;
+    bool ok = (act >> q) & 1u;
+    if (seq == irr_seq) ok = ok && (t0 + p_row[q] < t_end) && (src + 16 <= f_end);
+    if (ok) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(Fb + src),
+                                       (__attribute__((address_space(3))) void*)(smem + (seq % nbuf) * stage_bytes + l_dst[q]),
+                                       16, 0, 0);
     }
   };
   auto prep_stage = [&](int seq) {  // rows past the end of the split read as zeros (one ragged stage at most)
+    if (seq != irr_seq) return;
     const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
     if (t0 + KB > t_end) {
       const int first = (int)(t_end - t0);
@@ -804,9 +822,6 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
       }
     }
   };
-  auto wait_landed = [&](bool newest_full) {  // everything but the newest stage's pieces of this wave
-    if (newest_full) wait_vmcnt_dyn<8>(my_pieces); else wait_vmcnt<0>();
-  };
 
   acc_t acc[4][NACC];
 #pragma unroll
@@ -814,12 +829,17 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
 #pragma unroll
     for (int n = 0; n < NACC; ++n) acc[m][n] = acc_zero<TC>();
 
-  const int ahead = nbuf - 1;
+  const int ahead = nbuf - 1;  // 2 (three ring slots) or 1
+  // which MFMA group a piece goes with: spread over the groups (three slots) or all in front of the first (two slots:
+  // the stage's own duration is all the time its successor's DMAs get)
+  auto group_of_piece = [&](int q) { return ahead > 1 ? q * GROUPS / ppw : 0; };
   for (int s0 = 0; s0 < ahead && s0 < n_it; ++s0) {
     prep_stage(s0);
-    for (int q = 0; q < my_pieces; ++q) issue_piece(s0, q);
+#pragma unroll
+    for (int q = 0; q < GA_MAXPPW; ++q)
+      if (q < ppw) issue_piece(s0, q);
   }
-  wait_landed(ahead > 1 && n_it > 1 && ragged_seq != 1);
+  if (ahead > 1 && n_it > 1 && irr_seq != 1) wait_vmcnt_dyn<8>(ppw); else wait_vmcnt<0>();
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -827,39 +847,51 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
   for (int it = 0; it < n_it; ++it) {
     const bool issue_now = it + ahead < n_it;
     if (issue_now) prep_stage(it + ahead);
-    const char* st = smem + (it % nbuf) * stage_bytes;
-    int q_next = 0;
+    const int so = (it % nbuf) * stage_bytes;
+    // pieces of stage it + ahead issued in front of the barrier group (the last group's own pieces follow the barrier)
+    int issued_before = 0;
 #pragma unroll
     for (int kk = 0; kk < KB / 4; ++kk) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const int g = kk * 3 + d;
-        const int sh = kk * 4 * row_slot + d * SI;
+        const int sh = so + kk * 4 * row_slot + d * SI;
         TC a[4], bb[NACC];
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
-          TC sum = 0;
+          TC sum = (TC) * reinterpret_cast<const TIn*>(smem + offA[m][0] + sh);
 #pragma unroll
-          for (int j = 0; j < MAXM; ++j) {
-            const TIn x = *reinterpret_cast<const TIn*>(st + offA[m][j] + sh);
-            sum += (maskA >> (m * MAXM + j)) & 1u ? (TC)x : (TC)0;   // members in table order, like `@ con_mat`
-          }
+          for (int j = 1; j < MAXM; ++j) sum += (TC) * reinterpret_cast<const TIn*>(smem + offA[m][j] + sh);  // table order, like `@ con_mat`
           a[m] = sum;
         }
 #pragma unroll
         for (int n = 0; n < NACC; ++n) {
-          TC sum = 0;
+          TC sum = (TC) * reinterpret_cast<const TIn*>(smem + offB[n][0] + sh);
 #pragma unroll
-          for (int j = 0; j < MAXM; ++j) {
-            const TIn x = *reinterpret_cast<const TIn*>(st + offB[n][j] + sh);
-            sum += (maskB >> (n * MAXM + j)) & 1u ? (TC)x : (TC)0;
-          }
+          for (int j = 1; j < MAXM; ++j) sum += (TC) * reinterpret_cast<const TIn*>(smem + offB[n][j] + sh);
           bb[n] = sum;
         }
-        // this group's share of the DMAs of stage it + ahead, between the operand reads and the MFMAs
-        if (issue_now) {
-          const int upto = (my_pieces * (g + 1) + GROUPS - 1) / GROUPS;
-          for (; q_next < upto; ++q_next) issue_piece(it + ahead, q_next);
+        const bool last = g == GROUPS - 1;
+        if (issue_now && !last) {
+#pragma unroll
+          for (int q = 0; q < GA_MAXPPW; ++q)
+            if (q < ppw && group_of_piece(q) == g) {
+              issue_piece(it + ahead, q);
+              ++issued_before;
+            }
+        }
+        if (last) {
+          // the stage's barrier IN FRONT of the MFMAs of its last group: their operands are in registers once the LDS
+          // reads have returned, so the slot is free, and the MFMAs run while the waves meet (as in the panel kernel)
+          if (ahead > 1 && it + 2 < n_it && it + 2 != irr_seq) wait_vmcnt_dyn<8>(issued_before); else wait_vmcnt<0>();
+          asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+          __builtin_amdgcn_s_barrier();
+          asm volatile("" ::: "memory");
+          if (issue_now && ahead > 1) {
+#pragma unroll
+            for (int q = 0; q < GA_MAXPPW; ++q)
+              if (q < ppw && group_of_piece(q) == g) issue_piece(it + ahead, q);
+          }
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m)
@@ -867,11 +899,6 @@ __global__ __launch_bounds__(512, 2) void gram_tile_gather_kernel(
           for (int n = 0; n < NACC; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
       }
     }
-    // stage it+1 must have landed before anyone reads it; with three slots stage it+2 may stay in flight
-    wait_landed(ahead > 1 && it + 2 < n_it && it + 2 != ragged_seq);
-    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
-    asm volatile("" ::: "memory");
   }
 
   TC* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
@@ -2178,10 +2205,12 @@ struct GatherGeom {
 static GatherGeom gather_geom(int32_t span_atoms, int in_size, int kb) {
   GatherGeom g;
   g.span_bytes = span_atoms * 3 * in_size;
-  g.row_slot = (int)round_up(g.span_bytes + 16, 16) + 32;
+  g.row_slot = GA_HDR + (int)round_up(g.span_bytes + 16, 16);
   if ((g.row_slot / 32) % 2 == 0) g.row_slot += 32;  // odd multiple of 32 bytes: the 4 rows of an operand read start 8 banks apart
   const int stage = 2 * kb * g.row_slot;
   g.nbuf = 3 * stage <= 80 * 1024 ? 3 : 2 * stage <= 80 * 1024 ? 2 : 0;
+  const int ppr = (g.span_bytes + 15 + 1023) / 1024;
+  if (2 * kb * ppr / 8 > GA_MAXPPW) g.nbuf = 0;  // more DMA pieces per wave and stage than the kernel keeps track of
   return g;
 }
 
