@@ -206,8 +206,9 @@ def gather_layout(n_fg: int, n_red: int, csr=None):
 def gram_gather_ok(forces: torch.Tensor, n_red: int, compute_dtype: torch.dtype, layout) -> bool:
     """Should (and can) aggf_gram_gather take this trajectory / layout?  OPT-IN, AGGF_GRAM_GATHER=1 in the
     environment: measured on MI355X (tools/gather_bench.py, profiles/r03_gather_vs_packed.txt) the fused kernel
-    reaches 0.33-0.57 of the MFMA peak where the packed copy + panel kernel reach 0.70-0.82 INCLUDING the pack pass,
-    so the packed pipeline stays the default; the fused kernel is for trajectories that leave no HBM for the packed
+    reaches 0.30-0.72 of the MFMA peak where the packed copy + panel kernel reach 0.40-0.82 INCLUDING the pack pass
+    (the member sums are redone in every tile column, on the SIMD that issues the MFMAs), so the packed pipeline
+    stays the default; the fused kernel is for trajectories that leave no HBM for the packed
     chunk (it needs the tile table and the slabs only)."""
     import os
 
