@@ -279,6 +279,9 @@ def fit_id_gb(
     import os
 
     n_str = max(1, min(8, int(os.environ.get("AGGF_FEAT_STREAMS", "3"))))
+    free_b, _ = K.device_memory(geo.dev)
+    while n_str > 1 and n_str * geo.T * ld * 24 > free_b // 4:  # one regression-matrix buffer per stream: never more
+        n_str -= 1                                              # than a quarter of the free HBM between them
     main_stream = torch.cuda.current_stream(geo.dev)
     streams = K.side_streams(geo.dev, n_str) if n_str > 1 else [main_stream]
     R3s = [torch.zeros((geo.T, ld, 3), dtype=torch.float64, device=geo.dev) for _ in range(n_str)]
