@@ -187,14 +187,13 @@ def profiled_traffic(workload, world):
 
 def profile_label():
     """Where `traffic` / `mfma_busy_frac_pmc` come from: PMC passes are separate rocprofv3 runs by construction, so
-    the line quotes the committed profile and says which one (file, commit and date that last touched it)."""
+    the line quotes the committed profile and says which one (file, and the tree / date recorded inside it)."""
     rel = "profiles/r03_c3_rocprof_summary.json"
     label = f"{rel} (separate rocprofv3 --pmc passes; NOT measured in this run)"
     try:
-        out = subprocess.run(["git", "-C", ROOT, "log", "-1", "--format=%h %cI", "--", rel], stdout=subprocess.PIPE,
-                             stderr=subprocess.DEVNULL, timeout=10).stdout.decode().strip()
-        if out:
-            label += f"; profile committed {out}"
+        src = json.load(open(os.path.join(ROOT, rel))).get("profiled_from") or {}
+        if src:
+            label += f"; profiled from tree {src.get('tree')} on {src.get('date')}"
     except Exception:
         pass
     return label
