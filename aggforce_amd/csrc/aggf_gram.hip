@@ -685,6 +685,162 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
 // it and the operand offsets carry the misalignment, which depends on the row only through (row mod 4) because every
 // stage starts at a multiple of 4 frames.  Requirements (checked by the host side, else the pack path is taken):
 // F 16-byte aligned, T * 3N * sizeof(TIn) a multiple of 16, at most MAXM <= 4 members per column, two stages in 80 KB.
+// ---------------------------------------------------------------------------
+// float32 products, "quad" shape: FOUR 4-wave workgroups per CU, each one 128x128 tile with 64x64 wave tiles, 4 frame
+// rows per stage.  Why: the float32 MFMA takes 32 cycles instead of 64, so in the 8-wave shape above (64x32 wave
+// tiles, 8 MFMAs between two operand fetches) every fixed per-group cost -- operand-read latency, s_waitcnt, the
+// barrier -- weighs twice as much as in float64 (MFMA pipes busy 81-85 % against 89 %).  Here a group is 16 MFMAs
+// (512 cycles, as in float64) fed by 8 operand reads instead of 2 x 6, the barrier joins 4 waves instead of 8, and the
+// smaller stage (2 panels x 4 rows x 1.6 KB) lets four workgroups share a CU, so each SIMD still has four waves.
+// Rows lie one by one in LDS (stride 384 + 16 floats: the four k-rows of an operand read start 16 banks apart), a row
+// is one full and one half-used 1-KiB DMA piece.  [X | X2] as in the TWO instantiation of gram_tile_dma_kernel.
+constexpr int Q_KB = 4, Q_NW = 4, Q_THREADS = 256, Q_NBUF = 3;
+constexpr int Q_PANEL = Q_KB * ROW_STRIDE;          // 1600 floats
+constexpr int Q_BUF = 2 * Q_PANEL;                  // 3200 floats = 12.8 KB per stage
+constexpr int Q_PPW = 2 * Q_KB * 2 / Q_NW;          // DMA pieces per wave and stage: 4
+
+__global__ __launch_bounds__(Q_THREADS, 4) void gram_tile_f32q_kernel(
+    const float* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
+    const int32_t* __restrict__ tile_table, int64_t frames_per_split, float* __restrict__ slabs,
+    const float* __restrict__ X2, int64_t ld2, int32_t np1) {
+  using M = Mfma<float>;
+  using acc_t = typename M::acc_t;
+  constexpr int KB = Q_KB, NBUF = Q_NBUF, AHEAD = NBUF - 1, PPW = Q_PPW, GROUPS = 3;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  float* smem = reinterpret_cast<float*>(smem_raw);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const int b = blockIdx.x;
+  const int v = (((b >> 3) >> 6) * 8 + (b & 7)) * 64 + ((b >> 3) & 63);  // XCD-aware order, see gram_tile_dma_kernel
+  if (v >= ksplit * n_tiles) return;
+  const int ks = v / n_tiles;
+  const int packed = tile_table[v - ks * n_tiles];
+  const int ti = packed >> 16, tj = packed & 0xffff;
+  const int tile_lin = ti * nt1 - ti * (ti - 1) / 2 + (tj - ti);
+
+  const int64_t t_begin = (int64_t)ks * frames_per_split;
+  int64_t t_end = t_begin + frames_per_split;
+  if (t_end > n_rows) t_end = n_rows;
+  const int n_it = t_begin < t_end ? (int)((t_end - t_begin + KB - 1) / KB) : 0;
+
+  // this wave's DMA pieces: piece p = wave + 4 q -> (panel, row, half); a row = [0, 256) by all lanes + [256, 384) by
+  // lanes 0..31
+  const float* g_base[PPW];
+  int64_t g_ld[PPW], g_off[PPW];
+  int l_off[PPW], p_row[PPW];
+  bool lane_on[PPW];
+#pragma unroll
+  for (int q = 0; q < PPW; ++q) {
+    const int p = wave + Q_NW * q;
+    const int panel = p >> 3, row = (p & 7) >> 1, cp = p & 1;
+    const int pj = panel ? tj : ti;
+    const bool second = pj >= np1;
+    g_base[q] = second ? X2 : X;
+    g_ld[q] = second ? ld2 : ld;
+    g_off[q] = (int64_t)row * g_ld[q] + (int64_t)(second ? pj - np1 : pj) * ROW_ELEMS + cp * 256 + lane * 4;
+    l_off[q] = panel * Q_PANEL + row * ROW_STRIDE + cp * 256;
+    p_row[q] = row;
+    lane_on[q] = cp == 0 || lane < 32;
+  }
+  const int skew = n_it > 16 ? ((ti + tj) & 7) : 0;
+  auto stage_of = [&](int seq) { const int u = seq + skew; return u >= n_it ? u - n_it : u; };
+  const bool ragged = n_it > 0 && (t_end - t_begin) % KB != 0;
+  const int ragged_seq = ragged ? (n_it - 1 - skew + (n_it - 1 - skew < 0 ? n_it : 0)) : -1;
+  auto prep_stage = [&](int seq) {
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
+    if (t0 + KB > t_end) {
+      float* lbase = smem + (seq % NBUF) * Q_BUF;
+      const int first = (int)(t_end - t0);
+      for (int e = tid; e < 2 * (KB - first) * ROW_ELEMS; e += Q_THREADS) {
+        const int panel = e / ((KB - first) * ROW_ELEMS);
+        const int rem = e - panel * (KB - first) * ROW_ELEMS;
+        const int r = first + rem / ROW_ELEMS, c = rem % ROW_ELEMS;
+        lbase[panel * Q_PANEL + r * ROW_STRIDE + c] = 0.f;
+      }
+    }
+  };
+  auto issue_piece = [&](int seq, int q) {
+    const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
+    if (lane_on[q] && t0 + p_row[q] < t_end) {
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(g_base[q] + t0 * g_ld[q] + g_off[q]),
+          (__attribute__((address_space(3))) void*)(smem + (seq % NBUF) * Q_BUF + l_off[q]), 16, 0, 0);
+    }
+  };
+
+  acc_t acc[4][4];
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[m][n] = acc_zero<float>();
+  const int offA = (lane >> 4) * ROW_STRIDE + 3 * (wm * 64 + (lane & 15));
+  const int offB = Q_PANEL + (lane >> 4) * ROW_STRIDE + 3 * (wn * 64 + (lane & 15));
+
+  if (n_it > 0) {
+    prep_stage(0);
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) issue_piece(0, q);
+  }
+  if (n_it > 1) {
+    prep_stage(1);
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) issue_piece(1, q);
+  }
+  if (n_it > 1 && ragged_seq != 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  for (int it = 0; it < n_it; ++it) {
+    const bool issue_now = it + AHEAD < n_it;
+    if (issue_now) prep_stage(it + AHEAD);
+    const float* pa = smem + (it % NBUF) * Q_BUF;
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      float a[4], bb[4];
+#pragma unroll
+      for (int m = 0; m < 4; ++m) a[m] = pa[offA + 48 * m + d];
+#pragma unroll
+      for (int n = 0; n < 4; ++n) bb[n] = pa[offB + 48 * n + d];
+      // pieces 0, 1 go with group 0, piece 2 with group 1, piece 3 with the last group -- behind its barrier
+      if (issue_now) {
+        if (d == 0) {
+          issue_piece(it + AHEAD, 0);
+          issue_piece(it + AHEAD, 1);
+        } else if (d == 1) {
+          issue_piece(it + AHEAD, 2);
+        }
+      }
+      if (d == 2) {
+        // the stage's barrier in front of the MFMAs of its last group (operands in registers: the slot is free)
+        if (it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<3>(); else wait_vmcnt<0>();
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issue_now) issue_piece(it + AHEAD, 3);
+      }
+#pragma unroll
+      for (int m = 0; m < 4; ++m)
+#pragma unroll
+        for (int n = 0; n < 4; ++n) acc[m][n] = M::mma(a[m], bb[n], acc[m][n]);
+    }
+  }
+
+  float* slab = slabs + ((int64_t)tile_lin * ksplit + ks) * (TILE * TILE);
+#pragma unroll
+  for (int m = 0; m < 4; ++m)
+#pragma unroll
+    for (int n = 0; n < 4; ++n)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = wm * 64 + m * 16 + M::row(lane, r);
+        const int col = wn * 64 + n * 16 + (lane & 15);
+        slab[row * TILE + col] = acc[m][n][r];
+      }
+}
+
 constexpr int GA_HDR = 32;     // zeroed bytes in front of every staged row: what absent members and padding columns read
 constexpr int GA_MAXPPW = 6;   // DMA pieces per wave and stage, at most (host-checked)
 
@@ -1693,7 +1849,7 @@ __global__ __launch_bounds__(256) void gram_reduce_small_kernel(const T* __restr
 }
 
 // ---------------------------------------------------------------------------
-enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3, STAGE_SMALL = 4 };
+enum GramStaging { STAGE_REG = 0, STAGE_DMA = 1, STAGE_PAIR = 2, STAGE_DMA8 = 3, STAGE_SMALL = 4, STAGE_QUAD = 5 };
 
 struct GramPlan {
   int32_t n_pad, nt1, n_tiles;
@@ -1746,7 +1902,8 @@ static int choose_staging(int compute_dtype, int nt1) {
   static const char* force = getenv("AGGF_GRAM_STAGING");
   int st = STAGE_DMA8;
   (void)compute_dtype;
-  if (force) st = force[0] == 'p' ? STAGE_PAIR : force[0] == 'd' ? STAGE_DMA : force[0] == '8' ? STAGE_DMA8 : STAGE_REG;
+  if (force) st = force[0] == 'p' ? STAGE_PAIR : force[0] == 'd' ? STAGE_DMA : force[0] == '8' ? STAGE_DMA8 : force[0] == 'q' ? STAGE_QUAD : STAGE_REG;
+  if (st == STAGE_QUAD && compute_dtype != AGGF_F32) st = STAGE_DMA8;  // the quad shape exists for float32 products only
   if (st == STAGE_PAIR && nt1 < 2) st = STAGE_DMA;
   return st;
 }
@@ -1806,9 +1963,10 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->n_entries = p->n_tiles - p->first_tile * (p->first_tile + 1) / 2;
   }
   const int upw = pair ? 2 : 1;
-  const int kb = compute_dtype == AGGF_F64 ? GramCfg<double>::KB : GramCfg<float>::KB;
+  const bool quad = p->staging == STAGE_QUAD;
+  const int kb = quad ? Q_KB : compute_dtype == AGGF_F64 ? GramCfg<double>::KB : GramCfg<float>::KB;
   const size_t cs = dtype_size(compute_dtype);
-  const int slots = (pair ? 1 : 2) * device_cu_count();
+  const int slots = (pair ? 1 : quad ? 4 : 2) * device_cu_count();
   const size_t slab1 = (size_t)p->n_tiles * TILE * TILE * cs;  // one split
   const size_t row_bytes = (size_t)p->n_pad * 3 * cs;
   if (query) {
@@ -1886,6 +2044,22 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                        slabs, p.nt1, ksplit, n_red, accumulate, G);
     AGGF_LAUNCH_OK();
     return AGGF_OK;
+  }
+  if constexpr (sizeof(T) == 4) {
+    if (p.staging == STAGE_QUAD) {
+      int64_t fq = round_up(ceil_div(rows, ksplit), Q_KB);
+      if (fq < Q_KB) fq = Q_KB;
+      hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, 0);
+      AGGF_LAUNCH_OK();
+      hipLaunchKernelGGL(gram_tile_f32q_kernel, dim3((unsigned)round_up(nblocks, 512)), dim3(Q_THREADS),
+                         (size_t)Q_NBUF * Q_BUF * sizeof(float), stream, X, rows, ld, p.nt1, p.n_tiles, ksplit, tile_table, fq,
+                         slabs, (const float*)nullptr, (int64_t)0, p.nt1);
+      AGGF_LAUNCH_OK();
+      hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit, n_red,
+                         accumulate, G, 0);
+      AGGF_LAUNCH_OK();
+      return AGGF_OK;
+    }
   }
   if (p.staging == STAGE_DMA8) {
     const size_t lds3 = (size_t)3 * 2 * dma_panel_elems<T>() * sizeof(T);
