@@ -81,3 +81,73 @@ def test_bench_contract_on_tiny_workload():
     assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12 and "traffic" in r
     c = d["cpu_baseline"]
     assert c["kind"] in ("port", "reference") and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+
+
+def test_random_pinned_solve_and_noised_fit_sweeps():
+    """Round 3's new paths on random shapes: aggf_eq_qp_solve_pinned against the general solve and the oracle
+    (sizes around the 64 / 256 panel edges, group-size weighted l2, pins anywhere), and the noised fit without the
+    extended arrays against the oracle's concatenating restatement (slice and dense premaps, constraints, both
+    dtypes, N and n_cg multiples of 128)."""
+    import torch
+
+    from aggforce_amd import LinearMap, Trajectory, joptgauss_map
+    from aggforce_amd import _kernels as K
+    from oracle import aggforce_oracle as orc
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+    rng = np.random.default_rng(2024)
+    worst = 0.0
+    for case in range(24):
+        n = int(rng.choice([65, 127, 128, 129, 200, 255, 257, 320, 511, 513, 700]))
+        m = int(rng.integers(1, max(2, min(n - 1, 130))))
+        l2 = float(rng.choice([0.0, 0.0, 0.3, 10.0]))
+        F = rng.standard_normal((3 * n + 20, n)) * rng.uniform(0.5, 80, size=n)
+        Gh = F.T @ F
+        pins = rng.choice(n, size=m, replace=False).astype(np.int32)
+        sizes = rng.integers(1, 5, size=n).astype(np.float64)
+        A = np.zeros((m, n))
+        A[np.arange(m), pins] = 1.0
+        Xp, sp = K.eq_qp_solve_pinned(torch.from_numpy(Gh).cuda(), l2, torch.from_numpy(sizes).cuda(),
+                                      torch.from_numpy(pins).cuda())
+        assert sp.cpu().numpy()[0] == 0, (case, n, m)
+        Xo = orc.eq_qp_solve(Gh + l2 * np.diag(sizes), None, A, np.eye(m)).T
+        worst = max(worst, rel(Xp.cpu().numpy(), Xo))
+        assert np.array_equal(Xp.cpu().numpy()[:, pins], np.eye(m))
+    assert worst < 1e-8, worst
+    print(f"24 pinned-solve cases ok (worst rel {worst:.1e})")
+    for case in range(6):
+        N = int(rng.choice([128, 256, 384]))
+        n_cg = 128
+        dt = rng.choice([np.float32, np.float64])
+        T = int(rng.integers(N + 150, N + 400))
+        coords = (4 * rng.random((T, N, 3))).astype(dt)
+        forces = (25 * rng.standard_normal((T, N, 3))).astype(dt)
+        if rng.random() < 0.5:
+            cmat = orc.list_mapping_matrix([[int(i)] for i in rng.choice(N, size=n_cg, replace=False)], N)
+        else:
+            cmat = orc.list_mapping_matrix([[int(i) for i in rng.choice(N, size=int(rng.integers(1, 4)), replace=False)]
+                                            for _ in range(n_cg)], N)
+            if np.linalg.matrix_rank(cmat) < n_cg:
+                continue
+        cons = {frozenset(int(i) for i in rng.choice(N, size=2, replace=False)) for _ in range(int(rng.integers(0, N // 8)))}
+        l2 = float(rng.choice([0.0, 0.5]))
+        var = float(rng.choice([0.01, 0.2]))
+        eps = [rng.standard_normal((T, n_cg, 3)).astype(np.float32) for _ in range(2)]
+        try:
+            o = orc.joptgauss_force_map(coords, forces, cmat, var, 0.7, eps[0], cons, l2,
+                                        dtype=np.float32 if dt == np.float32 else np.float64)
+        except np.linalg.LinAlgError:
+            continue
+        tm = joptgauss_map(Trajectory(coords=coords, forces=forces), LinearMap(cmat), var=var, kbt=0.7, constraints=cons,
+                           noise=list(eps), l2_regularization=l2)
+        tol = 2e-3 if dt == np.float32 else 5e-5
+        W = tm.tmap.force_map.standard_matrix
+        assert rel(W, o["force_map"]) < tol, (case, N, dt, rel(W, o["force_map"]))
+        fc, ff = orc.augment(coords, forces, cmat, var, 0.7, eps[1], dtype=np.float32 if dt == np.float32 else np.float64)
+        mapped = tm(Trajectory(coords=coords, forces=forces))
+        assert rel(mapped.forces, orc.linearmap_apply(ff, o["force_map"])) < tol
+        assert rel(mapped.coords, fc[:, N:, :]) < 1e-5
+    print("noised-fit cases ok")
