@@ -299,9 +299,11 @@ def eq_qp_solve_batched(
     B: Optional[torch.Tensor] = None,
     schur_reg: float = 0.0,
     n_refine: int = 1,
+    AtA: Optional[torch.Tensor] = None,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Independent problems side by side: G (p, n, n), A (p, m, n), B (p, m, nrhs) or None ->
-    X (p, nrhs, n), stats (p, 4); see aggf_eq_qp_solve_batched."""
+    X (p, nrhs, n), stats (p, 4); see aggf_eq_qp_solve_batched.  ``AtA`` (p, n, n): the caller's A'A (lower
+    triangle read), aggf_eq_qp_solve_batched_shift."""
     l = lib()
     if G.dim() != 3 or A.dim() != 3 or G.shape[0] != A.shape[0] or G.shape[1] != G.shape[2] or A.shape[2] != G.shape[1]:
         raise ValueError(f"shape mismatch: G {tuple(G.shape)}, A {tuple(A.shape)}")
@@ -318,6 +320,17 @@ def eq_qp_solve_batched(
     stats = torch.empty((npb, 4), dtype=torch.float64, device=dev)
     need = l.aggf_eq_qp_batched_workspace_bytes(n, m, nrhs, npb)
     ws = workspace(need, dev, "solve")
+    if AtA is not None:
+        if AtA.shape != G.shape or AtA.dtype != torch.float64 or not AtA.is_contiguous():
+            raise ValueError(f"AtA must be contiguous float64 of G's shape, got {tuple(AtA.shape)}")
+        with _timed("solve"):
+            check(
+                l.aggf_eq_qp_solve_batched_shift(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), ptr(AtA), m, ptr(B), nrhs,
+                                                 float(schur_reg), int(n_refine), npb, ptr(X), ptr(stats), ptr(ws), need,
+                                                 stream_ptr()),
+                "aggf_eq_qp_solve_batched_shift",
+            )
+        return X, stats
     with _timed("solve"):
         check(
             l.aggf_eq_qp_solve_batched(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), m, ptr(B), nrhs, float(schur_reg),
@@ -820,6 +833,27 @@ def gb_constraint_rows(Mg: torch.Tensor, gauss: Optional[torch.Tensor], S: int, 
     check(lib().aggf_gb_constraint_rows(ptr(Mg), ptr(gauss), gd, S, n_cg, G, n_id, n_ch, n_basis, ptr(cols), n_cols, ld,
                                         int(site), ptr(A), ptr(b), stream_ptr()), "aggf_gb_constraint_rows")
     return A, b
+
+
+def gb_group_overlap(Mg: torch.Tensor) -> torch.Tensor:
+    """Mg' Mg (G, G) float64; see aggf_gb_group_overlap."""
+    n_cg, G = Mg.shape
+    M2 = torch.empty((G, G), dtype=torch.float64, device=Mg.device)
+    check(lib().aggf_gb_group_overlap(ptr(Mg), n_cg, G, ptr(M2), stream_ptr()), "aggf_gb_group_overlap")
+    return M2
+
+
+def gb_constraint_gram(M2: torch.Tensor, gauss: Optional[torch.Tensor], S: int, n_id: int, n_ch: int, n_basis: int,
+                       out: torch.Tensor, cols: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """A'A of gb_constraint_rows' rows into the lower triangle of ``out`` (ld, ld); see aggf_gb_constraint_gram."""
+    G = M2.shape[0]
+    n_cols = n_ch * n_basis if cols is None else int(cols.numel())
+    if out.dim() != 2 or out.shape[0] != out.shape[1] or out.dtype != torch.float64 or not out.is_contiguous():
+        raise ValueError("out must be a contiguous square float64 matrix")
+    gd = _lib.F32 if gauss is None else dtype_code(gauss.dtype)
+    check(lib().aggf_gb_constraint_gram(ptr(M2), ptr(gauss), gd, S, G, n_id, n_ch, n_basis, ptr(cols), n_cols,
+                                        out.shape[0], ptr(out), stream_ptr()), "aggf_gb_constraint_gram")
+    return out
 
 
 def gb_distance_range(Pg: torch.Tensor, cg: torch.Tensor, n_ch: int):

@@ -38,6 +38,7 @@ PROTOTYPES = {
     "aggf_eq_qp_solve": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_eq_qp_batched_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "aggf_eq_qp_solve_batched": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_eq_qp_solve_batched_shift": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_eq_qp_pinned_workspace_bytes": (_sz, [_i32, _i32]),
     "aggf_eq_qp_solve_pinned": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_expand_map": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
@@ -65,6 +66,8 @@ PROTOTYPES = {
     "aggf_feat_contract": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dbl, _i64, _i32, _i32, _i32, _vp, C.c_int, _vp]),
     "aggf_feat_constraint_rows": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp]),
     "aggf_gb_constraint_rows": (C.c_int, [_vp, _vp, C.c_int, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp]),
+    "aggf_gb_group_overlap": (C.c_int, [_vp, _i32, _i32, _vp, _vp]),
+    "aggf_gb_constraint_gram": (C.c_int, [_vp, _vp, C.c_int, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _vp]),
     "aggf_gb_distance_range": (C.c_int, [_vp, _vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp]),
     "aggf_gb_regmat_cols": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
     "aggf_feat_weights": (C.c_int, [_vp, C.c_int, _i64, _i32, _i32, _vp, _i64, _vp, _vp]),

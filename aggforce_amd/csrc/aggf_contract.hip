@@ -13,6 +13,7 @@
 //                          A[(s,c),f] = sum_a M[c,a] feat[idx[s],a,f],  b[(s,c)] = [c == site]
 //   gb_rows_kernel         the same rows for the fused [id_feat | gb_feat] features, from the compact
 //                          per-channel Gaussians (never forming the one-hot feature tensor)
+//   gb_ata_kernel          A'A of those rows from their structure (S multiply-adds per entry instead of S n_cg)
 //   feat_weights_kernel    scale_f of _feat_linear_mapping (featlinearmap.py:512-515):
 //                          w[t,a] = sum_f feat[t,a,f] coef[f]
 #include "aggf_common.h"
@@ -233,6 +234,102 @@ __global__ __launch_bounds__(256) void gb_rows_kernel(const double* __restrict__
   }
 }
 
+// M2 = Mg' Mg (G x G): the overlap of the constraint-adjusted mapping rows, shared by every site's A'A
+__global__ __launch_bounds__(256) void gb_overlap_kernel(const double* __restrict__ Mg, int32_t n_cg, int32_t G,
+                                                         double* __restrict__ M2) {
+  const int64_t total = (int64_t)G * G;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int i = (int)(e / G), j = (int)(e - (int64_t)i * G);
+    double acc = 0.0;
+    for (int c = 0; c < n_cg; ++c) acc = fma(Mg[(int64_t)c * G + i], Mg[(int64_t)c * G + j], acc);
+    M2[e] = acc;
+  }
+}
+
+// A'A of gb_rows_kernel's rows WITHOUT forming the product over the S n_cg rows.  Row (s, c) of A is
+// Mg[c, g(f)] w_s(f) with g(f) the constraint group behind column f (f itself for an id column, the channel for a
+// Gaussian column) and w_s(f) = 1 or gauss[s, ch, k], so
+//     (A'A)[f, f'] = M2[g(f), g(f')] * sum_s w_s(f) w_s(f'):
+// S multiply-adds per entry instead of S n_cg (BASELINE config 4: 20 against 1280, and the n x n x 1280 product was a
+// quarter of the batched solve's flops).  One workgroup = one 64 x 64 tile of the LOWER triangle (the factorisation
+// reads nothing else), each thread a 4 x 4 block of it; the tile's w columns sit in LDS in chunks of GA_SC frames.
+// Entries beyond the n_feat columns (up to ld) are written as zeros.
+constexpr int GA_SC = 32;
+
+template <typename TG>
+__global__ __launch_bounds__(256) void gb_ata_kernel(const double* __restrict__ M2, const TG* __restrict__ gauss,
+                                                     int32_t S, int32_t G, int32_t n_id, int32_t n_ch, int32_t nb,
+                                                     const int32_t* __restrict__ cols, int32_t n_cols, int32_t ld,
+                                                     double* __restrict__ out) {
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  __shared__ double wI[GA_SC][64], wJ[GA_SC][64];
+  __shared__ int gI[64], gJ[64], oI[64], oJ[64];  // group of a column; offset of its Gaussian in a frame (-1: w = 1, -2: w = 0)
+  const int tid = threadIdx.x, n_feat = n_id + n_cols;
+  if (tid < 128) {
+    const int f = (tid < 64 ? bi : bj) * 64 + (tid & 63);
+    int g = 0, o = -2;
+    if (f < n_id) {
+      g = f;
+      o = -1;
+    } else if (f < n_feat) {
+      const int full = cols ? cols[f - n_id] : f - n_id;
+      g = full / nb;
+      o = full;  // (ch * nb + k): gauss[(s * n_ch) * nb + full]
+    }
+    if (tid < 64) {
+      gI[tid] = g;
+      oI[tid] = o;
+    } else {
+      gJ[tid - 64] = g;
+      oJ[tid - 64] = o;
+    }
+  }
+  const int ty = tid >> 4, tx = tid & 15;
+  double acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[r][q] = 0.0;
+  for (int s0 = 0; s0 < S; s0 += GA_SC) {
+    __syncthreads();
+    const int ns = S - s0 < GA_SC ? S - s0 : GA_SC;
+    for (int e = tid; e < 2 * GA_SC * 64; e += 256) {
+      const int side = e / (GA_SC * 64), r = (e / 64) % GA_SC, col = e & 63;
+      const int o = side ? oJ[col] : oI[col];
+      double w = 0.0;
+      if (r < ns) w = o == -1 ? 1.0 : (o >= 0 ? (double)gauss[((int64_t)(s0 + r) * n_ch) * nb + o] : 0.0);
+      (side ? wJ : wI)[r][col] = w;
+    }
+    __syncthreads();
+    for (int r = 0; r < ns; ++r) {
+      double a[4], b[4];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        a[q] = wI[r][ty * 4 + q];
+        b[q] = wJ[r][tx * 4 + q];
+      }
+#pragma unroll
+      for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[p][q] = fma(a[p], b[q], acc[p][q]);
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < 4; ++p) {
+    const int i = bi * 64 + ty * 4 + p;
+    if (i >= ld) continue;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = bj * 64 + tx * 4 + q;
+      if (j >= ld) continue;
+      double v = 0.0;
+      if (i < n_feat && j < n_feat) v = acc[p][q] * M2[(int64_t)gI[ty * 4 + p] * G + gJ[tx * 4 + q]];
+      out[(int64_t)i * ld + j] = v;
+    }
+  }
+}
+
 // w[t*ld_t + a] = sum_f feat[t,a,f] coef[f]; one wave per (t,a) row
 template <typename TX>
 __global__ __launch_bounds__(256) void feat_weights_kernel(const TX* __restrict__ feat, int64_t T, int32_t N,
@@ -339,6 +436,39 @@ extern "C" int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t 
     hipLaunchKernelGGL(feat_rows_kernel<double>, grid, block, 0, stream, (const double*)feat, N, n_feat, frame_idx, M, n_cg, site, A, b);
   else
     return fail(AGGF_ERR_ARG, "aggf_feat_constraint_rows: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_group_overlap(const double* Mg, int32_t n_cg, int32_t G, double* M2, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Mg || !M2) return fail(AGGF_ERR_ARG, "aggf_gb_group_overlap: NULL pointer");
+  if (n_cg <= 0 || G <= 0) return fail(AGGF_ERR_ARG, "aggf_gb_group_overlap: bad shape");
+  hipLaunchKernelGGL(gb_overlap_kernel, stream_grid(ceil_div((int64_t)G * G, 256)), dim3(256), 0, stream, Mg, n_cg, G, M2);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_constraint_gram(const double* M2, const void* gauss, int g_dtype, int32_t S, int32_t G,
+                                       int32_t n_id, int32_t n_ch, int32_t n_basis, const int32_t* cols,
+                                       int32_t n_cols, int32_t ld, double* AtA, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!cols) n_cols = n_ch * n_basis;
+  if (!M2 || !AtA || (n_cols > 0 && !gauss)) return fail(AGGF_ERR_ARG, "aggf_gb_constraint_gram: NULL pointer");
+  if (S <= 0 || G <= 0 || n_id < 0 || n_id > G || n_ch < 0 || n_ch > G || n_basis <= 0 || n_cols < 0 ||
+      n_cols > n_ch * n_basis || n_id + n_cols <= 0 || ld < n_id + n_cols)
+    return fail(AGGF_ERR_ARG, "aggf_gb_constraint_gram: bad shape");
+  const unsigned nt = (unsigned)ceil_div(ld, 64);
+  if (nt > 65535) return fail(AGGF_ERR_ARG, "aggf_gb_constraint_gram: too many columns");
+  const dim3 grid(nt, nt), block(256);
+  if (g_dtype == AGGF_F32)
+    hipLaunchKernelGGL(gb_ata_kernel<float>, grid, block, 0, stream, M2, (const float*)gauss, S, G, n_id, n_ch, n_basis,
+                       cols, n_cols, ld, AtA);
+  else if (g_dtype == AGGF_F64)
+    hipLaunchKernelGGL(gb_ata_kernel<double>, grid, block, 0, stream, M2, (const double*)gauss, S, G, n_id, n_ch,
+                       n_basis, cols, n_cols, ld, AtA);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_gb_constraint_gram: bad dtype");
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

@@ -547,12 +547,15 @@ __global__ __launch_bounds__(256) void max_diag_kernel(const double* __restrict_
   if (threadIdx.x == 0) scale[blockIdx.y * scale_ps] = (sh[0] > 0.0 && sh[0] < 1e300) ? sh[0] : 1.0;
 }
 
-// Pt (npad x npad) = (G + l2*diag)/s on the n x n block, identity on the padding
+// Pt (npad x npad) = (G + l2*diag)/s [+ shift] on the n x n block, identity on the padding; `shift` (n x n per
+// problem, may be NULL) is a caller-formed A'A of which only the lower triangle is read
 __global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict__ G, int n, int64_t g_ps, int npad,
                                                        double l2, const double* __restrict__ l2d,
                                                        const double* __restrict__ scale, int64_t scale_ps,
+                                                       const double* __restrict__ shift,
                                                        double* __restrict__ Pt, int64_t pt_ps) {
   G += blockIdx.y * g_ps;
+  if (shift) shift += blockIdx.y * g_ps;
   Pt += blockIdx.y * pt_ps;
   const double inv_s = 1.0 / scale[blockIdx.y * scale_ps];
   const int64_t total = (int64_t)npad * npad;
@@ -564,6 +567,7 @@ __global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict_
       v = G[(int64_t)i * n + j];
       if (i == j) v += l2 * (l2d ? l2d[i] : 1.0);
       v *= inv_s;
+      if (shift && j <= i) v += shift[(int64_t)i * n + j];
     } else {
       v = (i == j) ? 1.0 : 0.0;
     }
@@ -930,7 +934,7 @@ static SolveLayout solve_layout(int n, int m, int nrhs, int nprob) {
 static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double* l2_diag, const double* A,
                             int32_t m, const double* B, int32_t nrhs, double schur_reg, int32_t n_refine,
                             int32_t nprob, double* X, double* stats, void* ws, size_t ws_bytes, void* stream_v,
-                            const char* who) {
+                            const char* who, const double* AtA = nullptr) {
   if (!G || !A || !X || !stats || !ws) return fail(AGGF_ERR_ARG, "%s: NULL pointer", who);
   if (n <= 0 || m <= 0 || nrhs <= 0 || nprob <= 0) return fail(AGGF_ERR_ARG, "%s: empty problem", who);
   if (!B && nrhs != m) return fail(AGGF_ERR_ARG, "%s: B == NULL needs nrhs == m", who);
@@ -962,14 +966,15 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   hipLaunchKernelGGL(max_diag_kernel, dim3(1, np), dim3(256), 0, st, G, n, g_ps, l2, l2_diag, scal, (int64_t)4);
   hipLaunchKernelGGL(copy_scalar_kernel, dim3(np), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
   hipLaunchKernelGGL(build_pt_kernel, flat_grid((int64_t)npad * npad, np), dim3(256), 0, st, G, n, g_ps, npad, l2,
-                     l2_diag, scal, (int64_t)4, Pt.p, Pt.ps);
+                     l2_diag, scal, (int64_t)4, AtA, Pt.p, Pt.ps);
   hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad, np), dim3(256), 0, st, A, m, n, a_ps, 0, Ap.p,
                      mpad, npad, Ap.ps);
   hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * rpad, np), dim3(256), 0, st, B,
                      B ? m : (m < nrhs ? m : nrhs), nrhs, b_ps, 0, Bp.p, mpad, rpad, Bp.ps);
   AGGF_LAUNCH_OK();
-  // P~ = P/s + A'A  (the factorisation reads the lower triangle only)
-  gemm<true, false>(c, npad, npad, mpad, 1.0, Ap, Ap, 1.0, Pt, 1);
+  // P~ = P/s + A'A  (the factorisation reads the lower triangle only); a caller that knows the structure of its
+  // rows has formed A'A itself and build_pt_kernel has added it
+  if (!AtA) gemm<true, false>(c, npad, npad, mpad, 1.0, Ap, Ap, 1.0, Pt, 1);
   cholesky(c, Pt, npad, Dinv, stats, 0);
   // Y = L^-1 A'
   hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * mpad, np), dim3(256), 0, st, A, m, n, a_ps, 1, Bw_m.p,
@@ -1128,6 +1133,15 @@ extern "C" int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, c
                                         double* stats, void* ws, size_t ws_bytes, void* stream_v) {
   return eq_qp_solve_impl(G, n, l2, l2_diag, A, m, B, nrhs, schur_reg, n_refine, n_problems, X, stats, ws, ws_bytes,
                           stream_v, "aggf_eq_qp_solve_batched");
+}
+
+extern "C" int aggf_eq_qp_solve_batched_shift(const double* G, int32_t n, double l2, const double* l2_diag,
+                                              const double* A, const double* AtA, int32_t m, const double* B,
+                                              int32_t nrhs, double schur_reg, int32_t n_refine, int32_t n_problems,
+                                              double* X, double* stats, void* ws, size_t ws_bytes, void* stream_v) {
+  if (!AtA) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve_batched_shift: NULL pointer");
+  return eq_qp_solve_impl(G, n, l2, l2_diag, A, m, B, nrhs, schur_reg, n_refine, n_problems, X, stats, ws, ws_bytes,
+                          stream_v, "aggf_eq_qp_solve_batched_shift", AtA);
 }
 
 // ---- Gram algebra for cross-validation (project_forces_grid_cv with Gram reuse) ---------------

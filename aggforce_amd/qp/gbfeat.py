@@ -194,10 +194,45 @@ def _sites_per_batch(n_cg: int, n_feat: int, m: int, device) -> int:
     the batch size fixes the shape and the number of the all-reduces."""
     import torch
 
-    per_site = 8 * (n_feat * n_feat + m * n_feat + m) + K.eq_qp_batched_bytes(n_feat, m, 1, 1)
+    per_site = 8 * (2 * n_feat * n_feat + m * n_feat + m) + K.eq_qp_batched_bytes(n_feat, m, 1, 1)
     _, total = torch.cuda.mem_get_info(device)
     usable = total - torch.cuda.memory_allocated(device)
     return int(max(1, min(n_cg, (_SOLVE_MEMORY_FRACTION * usable) // per_site)))
+
+
+# Grouping of the sites for the batched solve, measured at BASELINE config 4 (tools/c4_batch_sweep.sh, solve ms per
+# step): one batch of 64 sites 77.3; two of 32 64.9; four of 16 69.7; six of 8-16 78.0 -- below ~32 problems per
+# launch the factorisation's kernels no longer fill the GPU.  Running a batch's solve on its own stream beside the
+# next batch's Gram launches was tried and gains nothing (392.7 against 390.8 ms per step: the Gram kernel holds
+# every CU's LDS, the solve's workgroups wait for its workgroups to retire and the sum stays the same).
+_BATCH_MIN_SITES = 32
+_BATCH_SIZE_RATIO = 0.85  # sites within 15 % of a batch's largest share its padding
+
+
+def _solve_batches(n_act: List[int], per_batch: int, min_sites: int = _BATCH_MIN_SITES,
+                   ratio: float = _BATCH_SIZE_RATIO) -> List[List[int]]:
+    """Sites grouped for the batched solve: every problem of a batch is padded to the batch's largest, and the
+    work of a solve grows with n^2..n^3, so sites are taken in order of decreasing size and a batch is closed
+    when the next site is more than ``1 - ratio`` smaller than its first (once it holds ``min_sites``) or when
+    it holds ``per_batch`` (the memory bound).  With a cut-off basis the sizes differ a lot between sites --
+    BASELINE config 4: 1255..3049 kept columns, mean 2134 -- and one batch of all 64 sites padded to 3049 did
+    2.6x the flops of the problems themselves.  Pure function of (n_act, per_batch): the same on every rank."""
+    pad = lambda n: -(-n // 64) * 64
+    order = sorted(range(len(n_act)), key=lambda i: (-n_act[i], i))
+    out: List[List[int]] = []
+    cur: List[int] = []
+    for i in order:
+        if cur and (len(cur) >= per_batch or (len(cur) >= min_sites and pad(n_act[i]) < ratio * pad(n_act[cur[0]]))):
+            out.append(cur)
+            cur = []
+        cur.append(i)
+    if cur:
+        # a short last batch costs a whole chain of launches: it joins its predecessor when the memory allows
+        if out and len(cur) < min_sites and len(out[-1]) + len(cur) <= per_batch:
+            out[-1].extend(cur)
+        else:
+            out.append(cur)
+    return out
 
 
 def fit_id_gb(
@@ -233,6 +268,7 @@ def fit_id_gb(
         raise ValueError("featuriser produces no features")
     Fg = geo.group_forces(traj.forces)
     Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).to(geo.dev)  # (n_cg, G) float64
+    M2 = K.gb_group_overlap(Mg)  # Mg' Mg: every site's A'A is this, weighted (aggf_gb_constraint_gram)
     n_cg = coord_map.n_cg_sites
     gen = np.random.default_rng() if rng is None else rng
     coefs: List[np.ndarray] = [None] * n_cg  # type: ignore [list-item]
@@ -296,12 +332,18 @@ def fit_id_gb(
     per_batch = _sites_per_batch(n_cg, n_max, m_rows, geo.dev) if len(n_sel) == 1 else 1
     per_batch = agree_on_min(per_batch, comm, geo.dev)  # shapes and count of the collectives below depend on it
     shared_lead = None  # leading (id x id) Gram block, identical for all sites
-    for c0 in range(0, n_cg, per_batch):
-        sites = list(range(c0, min(n_cg, c0 + per_batch)))
+    batches = (_solve_batches(n_act, per_batch, int(os.environ.get("AGGF_FEAT_BATCH_MIN", _BATCH_MIN_SITES)),
+                              float(os.environ.get("AGGF_FEAT_BATCH_RATIO", _BATCH_SIZE_RATIO)))
+               if per_batch > 1 else [[i] for i in range(n_cg)])
+    use_ata = os.environ.get("AGGF_FEAT_ATA", "1") != "0"
+    for sites in batches:
         S = len(used[sites[0]])
-        Gs = torch.zeros((len(sites), n_max, n_max), dtype=torch.float64, device=geo.dev)
-        As = torch.empty((len(sites), S * n_cg, n_max), dtype=torch.float64, device=geo.dev)
+        nb_max = max(n_act[i] for i in sites)  # this batch's padding
+        Gs = torch.zeros((len(sites), nb_max, nb_max), dtype=torch.float64, device=geo.dev)
+        As = torch.empty((len(sites), S * n_cg, nb_max), dtype=torch.float64, device=geo.dev)
         bs = torch.empty((len(sites), S * n_cg, 1), dtype=torch.float64, device=geo.dev)
+        # A'A (the solve's positive shift) from the rows' structure, 20 multiply-adds per entry instead of 1280
+        AtAs = torch.empty((len(sites), nb_max, nb_max), dtype=torch.float64, device=geo.dev)
         phase = K._timed("fit_sites")  # main-stream bracket of the whole site loop (the per-launch timers overlap)
         phase.__enter__()
         for st in streams:
@@ -319,7 +361,7 @@ def fit_id_gb(
             # the id block of the regression matrix (the group force sums) is the same for every site: its
             # Gram block is taken from the first site's matrix (whole 128-tiles of it) and not computed again
             lead = (n_id // 128) * 128 if (shared_lead is not None and na >= 256) else 0
-            if na == n_max:
+            if na == nb_max:
                 K.gram(R3, None, None, na, torch.float64, out=Gs[j], first_col=lead)
                 Gsite = Gs[j]
             else:
@@ -332,7 +374,7 @@ def fit_id_gb(
                 shared_lead = Gsite[: (n_id // 128) * 128, : (n_id // 128) * 128].clone()
                 lead_ready = torch.cuda.Event()
                 lead_ready.record(torch.cuda.current_stream(geo.dev))
-            if na != n_max:
+            if na != nb_max:
                 Gs[j, :na, :na] = Gsite
                 Gs[j].diagonal()[na:] = 1.0
             lo_s, hi_s = int(sel_begin[site]), int(sel_begin[site + 1])
@@ -341,12 +383,15 @@ def fit_id_gb(
                 gauss, _ = K.gb_channels(Pg_sel[lo_s:hi_s].contiguous(), cg_sel[lo_s:hi_s].contiguous(), site,
                                          geo.sizes, n_ch, centers, width, CLIP)
             K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j], cols=cols)  # K4b
+            if use_ata:
+                K.gb_constraint_gram(M2, gauss, S, n_id, n_ch, n_basis, AtAs[j], cols=cols)
         for st in streams:
             if st is not main_stream:
                 main_stream.wait_stream(st)
         phase.__exit__(None, None, None)
         all_reduce_sum_sym_(Gs, comm)
-        X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3)
+        X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3,
+                                         AtA=AtAs if use_ata else None)
         st_all = stats.cpu().numpy()
         X_host = X[:, 0, :].cpu().numpy()
         for j, site in enumerate(sites):
@@ -360,11 +405,12 @@ def fit_id_gb(
             full[:n_id] = X_host[j, :n_id]
             full[n_id + cols_of[site]] = X_host[j, n_id:n_act[site]]
             coefs[site] = full
-        del Gs, As, bs, X, stats
+        del Gs, As, bs, AtAs, X, stats
     # the batched solve's scratch (up to _SOLVE_MEMORY_FRACTION of the HBM) is not kept for the life of the
     # process: the next Gram / apply / streamed fit would find the memory gone
     K.drop_workspace("solve", geo.dev)
     fit_info = {"kept_columns": n_act, "n_feat": n_feat, "sites_per_batch": per_batch,
+                "solve_batches": [(len(b), max(n_act[i] for i in b)) for b in batches],
                 "kept_gauss_columns": cols_of, "feature_dtype": str(fdt)}
     coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
 

@@ -489,12 +489,12 @@ def main():
                                    for i, k in enumerate(kept)]))
             gram_note = (f"{len(kept)} launches per step over {min(kept)}..{max(kept)} kept feature columns of "
                          f"{out['tmap'].force_map.tags['fit_info']['n_feat']} (mean {np.mean(kept):.0f}); the launches of "
-                         "different sites overlap on 3 streams, so ms_per_launch = (HIP-event time of the whole site loop on "
+                         f"different sites overlap on 3 streams (solve batches {out['tmap'].force_map.tags['fit_info']['solve_batches']}), so ms_per_launch = (HIP-event time of the whole site loop on "
                          "the main stream, which also contains the gb_regmat_cols and constraint-row kernels) / launches: "
                          "a lower bound of the kernel's own rate")
             phase = stages.get("fit_sites")
             if phase:
-                gram_ms = phase["ms"] / max(1, phase["calls"]) / len(kept)
+                gram_ms = phase["ms"] / args.steps / len(kept)  # one bracket per batch of sites, all launches of a step
         if args.workload == "c1":
             # HBM-bound: algorithmic bytes of the Gram pass = one read of the forces (3 N s per frame)
             algo_bytes = 3.0 * N * s_bytes * T_local

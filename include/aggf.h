@@ -148,6 +148,14 @@ int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, const double
                              double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
                              double* stats, void* ws, size_t ws_bytes, void* stream);
 
+/* aggf_eq_qp_solve_batched with the positive shift A'A of every problem formed by the CALLER (AtA: n x n per
+ * problem, lower triangle read) -- for constraint rows whose structure makes it cheap (aggf_gb_constraint_gram:
+ * S multiply-adds per entry instead of m = S*n_cg).  Same workspace, same results up to the rounding of A'A. */
+int aggf_eq_qp_solve_batched_shift(const double* G, int32_t n, double l2, const double* l2_diag,
+                                   const double* A, const double* AtA, int32_t m, const double* B, int32_t nrhs,
+                                   double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
+                                   double* stats, void* ws, size_t ws_bytes, void* stream);
+
 /* The same problem when every row of A is a unit vector with the 1 at pin_idx[i] (all distinct) and B is the
  * identity -- the constraint rows of a slice coordinate map, `coord_map.standard_matrix @ con_mat` of
  * qplinear.py:82 for every configuration of the reference's tests: the constraints pin m variables,
@@ -363,6 +371,11 @@ int aggf_trjdot_frames(const void* points, int p_dtype, const void* factor, int 
  *   n_ch*nb Gaussian columns in (ch, k) order; else cols[j] = ch*nb + k for the n_cols
  *   columns kept by the compacted fit (see aggf_gb_distance_range).  A has row stride
  *   ld >= n_id + n_cols; columns beyond are zero.
+ * aggf_gb_group_overlap / aggf_gb_constraint_gram: A'A of those rows (the positive shift of the solve,
+ *   aggf_eq_qp_solve_batched_shift) from their structure instead of a product over the S*n_cg rows:
+ *     (A'A)[f,f'] = M2[g(f), g(f')] * sum_s w_s(f) w_s(f'),   M2 = Mg' Mg  (G x G, aggf_gb_group_overlap),
+ *   g(f) = f for an id column, ch for a Gaussian column; w_s(f) = 1 resp. gauss[s,ch,k].  AtA is (ld, ld),
+ *   ld >= n_id + n_cols; the LOWER triangle is written (whole 64 x 64 tiles of it), zeros beyond the columns.
  * aggf_feat_weights: scale_f of _feat_linear_mapping (featlinearmap.py:512-515):
  *     w[t*ld_t + a] = sum_f feat[t,a,f] * coef[f]     (ld_t >= N lets the caller stack sites)
  * ------------------------------------------------------------------------- */
@@ -375,6 +388,10 @@ int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t T, int32_t 
 int aggf_gb_constraint_rows(const double* Mg, const void* gauss, int g_dtype, int32_t S, int32_t n_cg, int32_t G,
                             int32_t n_id, int32_t n_ch, int32_t n_basis, const int32_t* cols,
                             int32_t n_cols, int32_t ld, int32_t site, double* A, double* b, void* stream);
+int aggf_gb_group_overlap(const double* Mg, int32_t n_cg, int32_t G, double* M2, void* stream);
+int aggf_gb_constraint_gram(const double* M2, const void* gauss, int g_dtype, int32_t S, int32_t G, int32_t n_id,
+                            int32_t n_ch, int32_t n_basis, const int32_t* cols, int32_t n_cols, int32_t ld,
+                            double* AtA, void* stream);
 int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32_t N, int32_t n_feat,
                       const double* coef, int64_t ld_t, double* w, void* stream);
 

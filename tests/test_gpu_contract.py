@@ -183,6 +183,47 @@ def test_gb_constraint_rows_match_dense_oracle():
     assert rel(A_id.cpu().numpy(), orc.feat_constraint_arrays(onehot.astype(np.float64), 0, cmat, idx)[0]) < 1e-15
 
 
+@pytest.mark.parametrize("gdt", [torch.float32, torch.float64])
+def test_gb_constraint_gram_matches_the_product_of_the_rows(gdt):
+    """aggf_gb_constraint_gram forms A'A from the structure of the rows (S multiply-adds per entry): against the
+    float64 product of the rows aggf_gb_constraint_rows writes -- all columns and a compacted selection, more
+    sampled frames than one LDS chunk, a padded leading dimension; then the batched solve with that A'A against
+    the batched solve forming it itself."""
+    rng = np.random.default_rng(31)
+    n_cg, G, nb, S = 7, 150, 5, 45
+    n_ch = G - 1
+    Mg = torch.from_numpy(rng.random((n_cg, G)) * (rng.random((n_cg, G)) < 0.3)).cuda()
+    gauss = torch.from_numpy(rng.random((S, n_ch, nb))).to(gdt).cuda()
+    M2 = K.gb_group_overlap(Mg)
+    assert rel(M2.cpu().numpy(), (Mg.T @ Mg).cpu().numpy()) < 1e-14
+    keep = np.sort(rng.choice(n_ch * nb, size=300, replace=False)).astype(np.int32)
+    for cols, n_id in ((None, G), (torch.from_numpy(keep).cuda(), G), (torch.from_numpy(keep).cuda(), 0)):
+        A, _ = K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, nb, 2, cols=cols)
+        n = A.shape[1]
+        ld = n + 37
+        out = torch.full((ld, ld), float("nan"), dtype=torch.float64, device="cuda")
+        K.gb_constraint_gram(M2, gauss, S, n_id, n_ch, nb, out, cols=cols)
+        got = out.cpu().numpy()
+        want = np.zeros((ld, ld))
+        want[:n, :n] = (A.T @ A).cpu().numpy()
+        lower = np.tril(np.ones((ld, ld), dtype=bool))
+        assert np.isfinite(got[lower]).all()
+        assert np.max(np.abs(got[lower] - want[lower])) < 1e-13 * np.max(np.abs(want))
+    # the solve: same minimiser whichever way the shift was formed
+    p, n, m = 3, 90, 24
+    R = rng.standard_normal((p, 200, n))
+    Gs = torch.from_numpy(np.einsum("ptn,ptm->pnm", R, R)).cuda()
+    As = torch.from_numpy(rng.standard_normal((p, m, n))).cuda()
+    bs = torch.from_numpy(rng.standard_normal((p, m, 1))).cuda()
+    AtA = torch.tril(As.transpose(1, 2) @ As).contiguous()  # the lower triangle is all that is read
+    X0, st0 = K.eq_qp_solve_batched(Gs, 0.5, None, As, bs, schur_reg=1e-12, n_refine=2)
+    X1, st1 = K.eq_qp_solve_batched(Gs, 0.5, None, As, bs, schur_reg=1e-12, n_refine=2, AtA=AtA)
+    assert float(st1[:, 0].abs().max()) == 0.0 and float(st1[:, 1].max()) < 1e-10
+    assert rel(X1.cpu().numpy(), X0.cpu().numpy()) < 1e-10
+    with pytest.raises(ValueError):
+        K.eq_qp_solve_batched(Gs, 0.5, None, As, bs, AtA=AtA[:, :-1])
+
+
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
 def test_generic_featuriser_fit_and_apply_match_oracle(dtype):
     """qp_feat_linear_map with a featuriser the library has never seen: every contraction is a HIP kernel

@@ -383,3 +383,29 @@ def test_linear_map_survives_pickling():
     assert np.array_equal(back.standard_matrix, lm.standard_matrix) and back.handle_nans == "safe"
     assert back.nan_check_threshold == 1e-5 and back.n_cg_sites == 2 and back.n_fg_sites == 6
     assert back._dev_cache == {} and back._host_ready is None
+
+
+def test_solve_batches_group_sites_of_similar_size():
+    """The featurised fit's batches (gbfeat._solve_batches): every site exactly once, largest first, no batch
+    above the memory bound, sizes within a batch close once the batch is full enough -- and a pure function
+    of its arguments (the ranks of a sharded fit must form the same batches)."""
+    from aggforce_amd.qp.gbfeat import _solve_batches
+
+    rng = np.random.default_rng(5)
+    n_act = [int(x) for x in rng.integers(1255, 3050, size=64)]
+    b = _solve_batches(n_act, 64, min_sites=16)
+    assert sorted(i for g in b for i in g) == list(range(64))
+    assert b == _solve_batches(list(n_act), 64, min_sites=16)
+    assert [len(g) for g in _solve_batches(n_act, 64)] == [32, 32]  # the default: at least 32 problems per launch
+    assert all(len(g) >= 16 for g in b) and len(b) >= 3
+    tops = [max(n_act[i] for i in g) for g in b]
+    assert tops == sorted(tops, reverse=True)
+    pad = lambda n: -(-n // 64) * 64
+    padded = sum(len(g) * pad(t) ** 3 for g, t in zip(b, tops))
+    assert padded < 0.7 * 64 * pad(max(n_act)) ** 3  # the point of it
+    # the memory bound wins over the minimum size
+    b3 = _solve_batches(n_act, 3)
+    assert max(len(g) for g in b3) == 3 and sorted(i for g in b3 for i in g) == list(range(64))
+    # equal sizes: one batch; one site: one batch
+    assert _solve_batches([500] * 10, 64) == [list(range(10))]
+    assert _solve_batches([7], 1) == [[0]]
