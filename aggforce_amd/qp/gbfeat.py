@@ -382,6 +382,8 @@ def fit_id_gb(
             if n_ch:
                 gauss, _ = K.gb_channels(Pg_sel[lo_s:hi_s].contiguous(), cg_sel[lo_s:hi_s].contiguous(), site,
                                          geo.sizes, n_ch, centers, width, CLIP)
+            # (the constraint kernels stay inside the site loop: issued for all sites ahead of it they run alone,
+            # 5 ms per step at BASELINE config 4 -- here they fill the tails of the Gram launches)
             K.gb_constraint_rows(Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j], cols=cols)  # K4b
             if use_ata:
                 K.gb_constraint_gram(M2, gauss, S, n_id, n_ch, n_basis, AtAs[j], cols=cols)
