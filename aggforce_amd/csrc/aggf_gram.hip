@@ -1071,16 +1071,43 @@ __global__ __launch_bounds__(512, MAXM <= 2 ? 4 : 2) void gram_tile_gather_kerne
 }
 
 // tile_table[k] = (ti << 16) | tj of the k-th upper-triangle tile in 8x8 super-block order
-// (tiles with tj < first_tile -- a leading block the caller already has -- are left out)
-__global__ void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table, int32_t first_tile = 0) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  const int nsb = (nt1 + 7) / 8;
-  int k = 0;
-  for (int si = 0; si < nsb; ++si)
-    for (int sj = si; sj < nsb; ++sj)
-      for (int ti = si * 8; ti < si * 8 + 8 && ti < nt1; ++ti)
-        for (int tj = sj * 8; tj < sj * 8 + 8 && tj < nt1; ++tj)
-          if (tj >= ti && tj >= first_tile) table[k++] = (ti << 16) | tj;
+// (tiles with tj < first_tile -- a leading block the caller already has -- are left out), i.e. the order of
+//     for si, for sj >= si, for ti in super-row si, for tj in super-column sj: keep (ti, tj) if tj >= ti, tj >= first_tile
+// ONE workgroup of 4 waves: a wave takes one super-block per pass (lane = its 64 candidates, kept ones ranked by a
+// ballot), the passes are chained through a running count.  (Until round 3 this was one thread walking the loop
+// nest: 42 us per Gram launch at nt1 = 24, 2.7 ms per step of BASELINE config 4's 64 launches.)
+__global__ __launch_bounds__(256) void build_tile_table_kernel(int32_t nt1, int32_t* __restrict__ table,
+                                                              int32_t first_tile = 0) {
+  __shared__ int wave_count[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t nsb = (nt1 + 7) / 8, n_super = nsb * (nsb + 1) / 2;
+  int64_t base = 0;
+  for (int64_t b0 = 0; b0 < n_super; b0 += 4) {
+    const int64_t sb = b0 + wave;
+    bool keep = false;
+    int ti = 0, tj = 0;
+    if (sb < n_super) {
+      // super-block sb -> (si, sj): row si starts at si nsb - si (si - 1) / 2
+      const double w = 2.0 * (double)nsb + 1.0;
+      int64_t si = (int64_t)((w - sqrt(w * w - 8.0 * (double)sb)) * 0.5);
+      if (si < 0) si = 0;
+      if (si >= nsb) si = nsb - 1;
+      while (si > 0 && si * nsb - si * (si - 1) / 2 > sb) --si;
+      while (si + 1 < nsb && (si + 1) * nsb - (si + 1) * si / 2 <= sb) ++si;
+      const int64_t sj = si + (sb - (si * nsb - si * (si - 1) / 2));
+      ti = (int)si * 8 + (lane >> 3);
+      tj = (int)sj * 8 + (lane & 7);
+      keep = ti < nt1 && tj < nt1 && tj >= ti && tj >= first_tile;
+    }
+    const unsigned long long mask = __ballot(keep);
+    if (lane == 0) wave_count[wave] = __popcll(mask);
+    __syncthreads();
+    int64_t off = base;
+    for (int w2 = 0; w2 < wave; ++w2) off += wave_count[w2];
+    if (keep) table[off + __popcll(mask & ((1ull << lane) - 1ull))] = (ti << 16) | tj;
+    base += wave_count[0] + wave_count[1] + wave_count[2] + wave_count[3];
+    __syncthreads();
+  }
 }
 
 // ---------------------------------------------------------------------------
@@ -1873,6 +1900,8 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
   if (hi < 1) hi = 1;
   if (hi > max_splits) hi = max_splits;
   if (hi > 1024) hi = 1024;
+  static const char* force_k = getenv("AGGF_GRAM_KSPLIT");  // measurement: a fixed split count (tools/gram_ksplit_bench.py)
+  if (force_k && atoi(force_k) > 0) return (int)(atoi(force_k) < hi ? atoi(force_k) : hi);
   const double us_per_frame = 0.64 * 4.0 / kb;     // one LDS stage = 48 MFMAs per wave, 2 waves per SIMD
   const double fixed_frames = 48.0;                // pipeline fill + slab store, in frame units
   const double slab_us = units_per_wg * 2.0 * TILE * TILE * (kb == 4 ? 8 : 4) / 2.0e6;  // write + read at ~2 TB/s
@@ -2049,7 +2078,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
     if (p.staging == STAGE_QUAD) {
       int64_t fq = round_up(ceil_div(rows, ksplit), Q_KB);
       if (fq < Q_KB) fq = Q_KB;
-      hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, 0);
+      hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, 0);
       AGGF_LAUNCH_OK();
       hipLaunchKernelGGL(gram_tile_f32q_kernel, dim3((unsigned)round_up(nblocks, 512)), dim3(Q_THREADS),
                          (size_t)Q_NBUF * Q_BUF * sizeof(float), stream, X, rows, ld, p.nt1, p.n_tiles, ksplit, tile_table, fq,
@@ -2070,7 +2099,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       attr_done = true;
     }
-    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, p.first_tile);
+    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, p.first_tile);
     AGGF_LAUNCH_OK();
     const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
     static const char* f32_mfma = getenv("AGGF_GRAM_F32_MFMA");  // "32": v_mfma_f32_32x32x2_f32 (measurement)
@@ -2130,7 +2159,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
       attr_done = true;
     }
-    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table);
+    hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table);
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_tile_dma_kernel<T>), dim3((unsigned)round_up(nblocks, 512)), dim3(GRAM_THREADS),
                        lds3, stream, X, rows, ld, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs);
@@ -2328,7 +2357,7 @@ static int gram_pair_typed(const T* F, const T* F2, int64_t rows, int32_t N, int
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     attr_done = true;
   }
-  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, 0);
+  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, 0);
   AGGF_LAUNCH_OK();
   const int64_t nblk = (int64_t)ksplit * p.n_tiles;
   if (nblk > 0x7fffff00LL) return fail(AGGF_ERR_ARG, "gram grid too large");
@@ -2406,7 +2435,7 @@ static int gram_gather_launch(const TIn* F, int64_t T, int32_t N, const int32_t*
                                     hipFuncAttributeMaxDynamicSharedMemorySize, 80 * 1024));
     attr_done = true;
   }
-  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(1), 0, stream, p.nt1, tile_table, 0);
+  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, 0);
   AGGF_LAUNCH_OK();
   const int64_t nblk = (int64_t)ksplit * p.n_tiles;
   if (nblk > 0x7fffff00LL) return fail(AGGF_ERR_ARG, "gram grid too large");
