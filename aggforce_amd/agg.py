@@ -188,6 +188,42 @@ def _grid_cv_gram_reuse(grid, forces, folds, kwargs) -> Dict[str, Dict[Any, Any]
     return results
 
 
+_FEAT_REUSE_FIXED_ARGS: Final = frozenset(
+    {"coord_map", "constrained_inds", "method", "featurizer", "kbt", "n_constraint_frames", "l2_regularization"}
+)
+
+
+def _feat_reuse(grid, grid_names, kwargs):
+    """The featuriser's one-pass cross-validation routine if it covers this call, else None: ``qp_feat_linear_map``
+    with the fused [id_feat | gb_feat] featurisers, explicit constraints, a grid over ``l2_regularization`` only with
+    every value > 0 (columns that vanish on a training subset keep an exactly zero coefficient only then), no ``comm``."""
+    from .qp import qp_feat_linear_map
+
+    if kwargs.get("method") is not qp_feat_linear_map or not {"coord_map", "featurizer", "kbt"} <= set(kwargs):
+        return None
+    if not set(grid_names) <= _GRAM_REUSE_GRID_ARGS or not set(kwargs) <= _FEAT_REUSE_FIXED_ARGS:
+        return None
+    if isinstance(kwargs.get("constrained_inds", PROJECT_FORCES_CNSTR_AUTO), str):
+        return None
+    if not all(float(dict(kwargs, **args).get("l2_regularization", 1e1)) > 0.0 for _, args in grid):
+        return None
+    return getattr(kwargs["featurizer"], "fused_cv", None)
+
+
+def _grid_cv_feat_reuse(cv, grid, coords, forces, folds, kwargs, method_rng=None) -> Dict[str, Dict[Any, Any]]:
+    l2_values = [float(dict(kwargs, **args).get("l2_regularization", 1e1)) for _, args in grid]
+    cons = kwargs.get("constrained_inds")
+    table = cv(coords, forces, kwargs["coord_map"], kwargs["kbt"], kwargs.get("n_constraint_frames", 20),
+               set() if cons is None else cons, l2_values, folds, method_rng)
+    results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
+    for (label, _), row in zip(grid, table):
+        scores = [v for v in row if v is not None]
+        results[SCORES_KNAME][label] = mean(scores)
+        results[SDS_KNAME][label] = sample_sd(scores)
+        results[NRUNS_KNAME][label] = len(scores)
+    return results
+
+
 def project_forces_grid_cv(
     cv_arg_dict: Mapping[str, List[T]],
     coords,
@@ -195,6 +231,7 @@ def project_forces_grid_cv(
     n_folds: int = 5,
     rng=None,
     reuse_gram: bool = True,
+    method_rng=None,
     **kwargs,
 ) -> Dict[str, Dict[NamedTuple, T]]:
     """Grid cross-validation over project_forces arguments (reference agg.py:142-235).
@@ -202,10 +239,13 @@ def project_forces_grid_cv(
     For every grid point the map is trained on the frames outside each fold and scored by
     ``force_smoothness`` of the mapped hold-out forces; returns ``{"scores", "sds", "n_runs"}``
     keyed by the grid point.  ``rng`` (a numpy Generator) makes the fold shuffle reproducible; the
-    reference uses an unseeded generator.  When the grid runs over ``l2_regularization`` of the
+    reference uses an unseeded generator.  ``method_rng`` is handed to ``method`` as ``rng=`` in every
+    fit (methods that sample, e.g. the constraint frames of ``qp_feat_linear_map``).  When the grid runs over ``l2_regularization`` of the
     linear optimiser with explicit constraints and ``reuse_gram`` is true, all folds and grid
-    points share one pass over the frames (``_grid_cv_gram_reuse``); otherwise the reference's
-    loop over ``project_forces`` calls is followed.
+    points share one pass over the frames (``_grid_cv_gram_reuse``); the same holds for
+    ``qp_feat_linear_map`` with the fused ``[id_feat | gb_feat]`` featurisers and every
+    ``l2_regularization`` > 0 (``_grid_cv_feat_reuse``); otherwise the reference's loop over
+    ``project_forces`` calls is followed.
 
     (The reference calls ``trained_tmap.from_arrays`` at agg.py:224, which no TMap defines; the
     intended ``map_arrays`` is used here.)
@@ -220,11 +260,16 @@ def project_forces_grid_cv(
         if not K.has_nan(f_dev):  # NaN handling follows the generic path
             return _grid_cv_gram_reuse(grid, f_dev, folds, kwargs)
         del f_dev
+    feat_cv = _feat_reuse(grid, list(cv_arg_dict.keys()), kwargs) if reuse_gram else None
+    if feat_cv is not None and not K.has_nan(K.as_device(forces)) and not K.has_nan(K.as_device(coords)):
+        return _grid_cv_feat_reuse(feat_cv, grid, coords, forces, folds, kwargs, method_rng)
     results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
     take = _take_frames
     for label, args in grid:
         scores = []
         merged = dict(kwargs, **args)
+        if method_rng is not None:
+            merged["rng"] = method_rng
         for k, val_idx in enumerate(folds):
             train_idx = np.concatenate([f for j, f in enumerate(folds) if j != k])
             try:

@@ -121,6 +121,23 @@ class Multifeaturize:
 
         return fit
 
+    @property
+    def fused_cv(self):
+        """One-pass cross-validation over ``l2_regularization`` for the same member lists as ``fused_fit``
+        (``qp/gbfeat.py:cv_id_gb``, used by ``project_forces_grid_cv``); None otherwise."""
+        from .gbfeat import cv_id_gb, recognise
+
+        rec = recognise(self.featurizers)
+        if rec is None:
+            return None
+        use_id, gb_kwargs = rec
+
+        def cv(coords, forces, coord_map, kbt, n_constraint_frames, constraints, l2_values, folds, rng):
+            return cv_id_gb(coords, forces, coord_map, kbt, n_constraint_frames, constraints, l2_values, folds, rng,
+                            use_id, gb_kwargs)
+
+        return cv
+
     def __repr__(self) -> str:
         parts = ["{}():".format(self.__class__)]
         for i, f in enumerate(self.featurizers):

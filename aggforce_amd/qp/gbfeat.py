@@ -235,27 +235,19 @@ def _solve_batches(n_act: List[int], per_batch: int, min_sites: int = _BATCH_MIN
     return out
 
 
-def fit_id_gb(
-    traj,
-    coord_map: LinearMap,
-    kbt: float,
-    n_constraint_frames: int,
-    constraints: Constraints,
-    l2_regularization: float,
-    frame_indices,
-    rng,
-    comm,
-    use_id: bool,
-    gb_kwargs: Optional[dict],
-    dense_featurizer,
-) -> CLAFTMap:
-    """qp_feat_linear_map (featlinearmap.py:249-394) for id_feat and/or gb_feat features, fused."""
+def _fused_setup(coords, forces, coord_map: LinearMap, constraints: Constraints, use_id: bool,
+                 gb_kwargs: Optional[dict], comm):
+    """What the fused [id_feat | gb_feat] fit needs of a trajectory before any constraint frame is drawn: group
+    geometry and group force sums on the device, the Gaussian centres, the feature counts, the group-summed
+    coordinate map with its overlap ``Mg' Mg``, and per site the Gaussian columns that are not identically zero."""
+    import types
+
     import torch
 
     kw = dict(gb_kwargs or {})
     drop_last = kw.pop("drop_last_channel", True)
     fdt = _feature_dtype(kw.pop("feature_dtype", np.float32))
-    geo = _Geometry(traj.coords, coord_map, constraints, drop_last, fdt)
+    geo = _Geometry(coords, coord_map, constraints, drop_last, fdt)
     n_basis = int(kw.get("n_basis", 10)) if gb_kwargs is not None else 1
     width = float(kw.get("width", 1.0))
     centers_h = (gb_centers(kw["outer"], kw.get("inner", 0), n_basis, kw.get("dist_power", 0.5), fdt)
@@ -266,27 +258,10 @@ def fit_id_gb(
     n_feat = n_id + n_ch * n_basis
     if n_feat == 0:
         raise ValueError("featuriser produces no features")
-    Fg = geo.group_forces(traj.forces)
+    Fg = geo.group_forces(forces)
     Mg = torch.from_numpy(np.ascontiguousarray(geo.Mg)).to(geo.dev)  # (n_cg, G) float64
     M2 = K.gb_group_overlap(Mg)  # Mg' Mg: every site's A'A is this, weighted (aggf_gb_constraint_gram)
     n_cg = coord_map.n_cg_sites
-    gen = np.random.default_rng() if rng is None else rng
-    coefs: List[np.ndarray] = [None] * n_cg  # type: ignore [list-item]
-    # Sampled constraint frames (featlinearmap.py:445): numbered over the WHOLE trajectory.  With frames
-    # sharded over ranks every rank must build the same rows A, or the "replicated" solves differ: rank 0's
-    # draw is used everywhere and each sampled frame's geometry comes from the rank that owns it.
-    _, T_total = shard_extent(geo.T, comm, geo.dev)
-    used: List[np.ndarray] = [
-        np.asarray(frame_indices[site]) if frame_indices is not None
-        else gen.choice(T_total, size=n_constraint_frames, replace=False)
-        for site in range(n_cg)
-    ]
-    used = [agree_on_indices(idx, comm, geo.dev) for idx in used]
-    flat_idx = np.concatenate(used) if used else np.zeros(0, dtype=np.int64)
-    Pg_sel = take_global_frames(geo.Pg, flat_idx, comm)
-    cg_sel = take_global_frames(geo.cg, flat_idx, comm)
-    sel_begin = np.concatenate([[0], np.cumsum([len(u) for u in used])]).astype(np.int64)
-    n_sel = {len(u) for u in used}
     # Which Gaussian columns can be non-zero at all?  Column (ch, k) of site c is identically zero when the
     # channel's distance to the site stays outside (c_k - h, c_k + h), h = width sqrt(ln(1/clip)), in every
     # frame (of every rank).  Such a column adds a zero row/column to P and zeros to A: its coefficient in
@@ -304,6 +279,50 @@ def fit_id_gb(
         keep = ((lo[:, :, None] < c + reach) & (hi[:, :, None] > c - reach)).reshape(n_cg, n_ch * n_basis)
     cols_of = [np.nonzero(keep[site])[0].astype(np.int32) for site in range(n_cg)]
     n_act = [n_id + len(cols) for cols in cols_of]
+    return types.SimpleNamespace(geo=geo, fdt=fdt, drop_last=drop_last, n_basis=n_basis, width=width,
+                                 centers_h=centers_h, centers=centers, n_id=n_id, n_ch=n_ch, n_feat=n_feat, Fg=Fg,
+                                 Mg=Mg, M2=M2, n_cg=n_cg, cols_of=cols_of, n_act=n_act)
+
+
+def fit_id_gb(
+    traj,
+    coord_map: LinearMap,
+    kbt: float,
+    n_constraint_frames: int,
+    constraints: Constraints,
+    l2_regularization: float,
+    frame_indices,
+    rng,
+    comm,
+    use_id: bool,
+    gb_kwargs: Optional[dict],
+    dense_featurizer,
+) -> CLAFTMap:
+    """qp_feat_linear_map (featlinearmap.py:249-394) for id_feat and/or gb_feat features, fused."""
+    import torch
+
+    su = _fused_setup(traj.coords, traj.forces, coord_map, constraints, use_id, gb_kwargs, comm)
+    geo, fdt, drop_last, n_basis, width, centers_h, centers = (su.geo, su.fdt, su.drop_last, su.n_basis, su.width,
+                                                                su.centers_h, su.centers)
+    n_id, n_ch, n_feat, Fg, Mg, M2, n_cg = su.n_id, su.n_ch, su.n_feat, su.Fg, su.Mg, su.M2, su.n_cg
+    cols_of, n_act = su.cols_of, su.n_act
+    gen = np.random.default_rng() if rng is None else rng
+    coefs: List[np.ndarray] = [None] * n_cg  # type: ignore [list-item]
+    # Sampled constraint frames (featlinearmap.py:445): numbered over the WHOLE trajectory.  With frames
+    # sharded over ranks every rank must build the same rows A, or the "replicated" solves differ: rank 0's
+    # draw is used everywhere and each sampled frame's geometry comes from the rank that owns it.
+    _, T_total = shard_extent(geo.T, comm, geo.dev)
+    used: List[np.ndarray] = [
+        np.asarray(frame_indices[site]) if frame_indices is not None
+        else gen.choice(T_total, size=n_constraint_frames, replace=False)
+        for site in range(n_cg)
+    ]
+    used = [agree_on_indices(idx, comm, geo.dev) for idx in used]
+    flat_idx = np.concatenate(used) if used else np.zeros(0, dtype=np.int64)
+    Pg_sel = take_global_frames(geo.Pg, flat_idx, comm)
+    cg_sel = take_global_frames(geo.cg, flat_idx, comm)
+    sel_begin = np.concatenate([[0], np.cumsum([len(u) for u in used])]).astype(np.int64)
+    n_sel = {len(u) for u in used}
     n_max = max(n_act)
     # The regression matrix goes straight into the Gram kernel's in-place layout: float64 storage (the
     # float32 products of float32 forces widened on store -- K1 multiplies in float64, see below), feature
@@ -432,3 +451,120 @@ def fit_id_gb(
                        n_cg_sites=n_cg, zeroes_check=False, apply=apply_f,
                        tags={"feat_names": None, "coef_list": coefs, "constraint_frames": used, "fit_info": fit_info})
     return CLAFTMap(coord_map=coord_map, force_map=force_map)
+
+
+def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_frames: int, constraints: Constraints,
+             l2_values: List[float], folds: List[np.ndarray], rng, use_id: bool, gb_kwargs: Optional[dict]
+             ) -> List[List[Optional[float]]]:
+    """Cross-validation of the fused [id_feat | gb_feat] fit over ``l2_regularization`` in ONE pass over the frames
+    (the featurised counterpart of ``agg._grid_cv_gram_reuse``; replaces the loop body of the
+    reference's agg.py:208-231 for this method).
+
+    A site's Gram matrix is a sum over frames and the squared mapped hold-out force is a quadratic form in it: with the
+    frames gathered into fold order once, every site's regression matrix is written once and K1 runs once per (site,
+    fold); the training matrix of fold k is ``total - G_k`` and the hold-out score of the coefficients x_c is
+    ``sum_c x_c' G_k^(c) x_c / (3 T_k n_cg)`` -- what ``force_smoothness`` of the mapped hold-out forces gives.  Per
+    (grid point, fold) only the constraint rows (drawn anew, as a fresh ``qp_feat_linear_map`` call would: the
+    generator is consumed in the order of the reference's loop) and one batched solve are left.  The Gaussian columns
+    kept are those not identically zero over ALL frames, a superset of every training set's (their extra coefficients
+    are exact zeros: needs l2 > 0, which the caller checks).
+
+    Returns ``scores[i][k]`` for l2_values[i] and fold k (None where the solve failed, as the loop would skip it)."""
+    import torch
+
+    n_folds = len(folds)
+    lens = [len(f) for f in folds]
+    bounds = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
+    c_dev, f_dev = K.as_device(coords), K.as_device(forces)
+    pidx = torch.as_tensor(np.concatenate(folds), device=c_dev.device)
+    c_p, f_p = c_dev[pidx].contiguous(), f_dev[pidx].contiguous()  # frames in fold order: a fold is a row range
+    su = _fused_setup(c_p, f_p, coord_map, constraints, use_id, gb_kwargs, None)
+    del c_p, f_p
+    geo, n_id, n_ch, n_basis, n_cg = su.geo, su.n_id, su.n_ch, su.n_basis, su.n_cg
+    cols_of, n_act = su.cols_of, su.n_act
+    dev = geo.dev
+    cols_dev = [torch.from_numpy(c).to(dev) for c in cols_of]
+    n_max = max(n_act)
+    ld = -(-n_max // 128) * 128
+    R3 = torch.zeros((geo.T, ld, 3), dtype=torch.float64, device=dev)
+    lead_n = (n_id // 128) * 128
+    shared_lead: List[Optional[torch.Tensor]] = [None] * n_folds  # the id x id block is the same for every site
+    # The fit minimises |feat'F + kbt div|^2 (featlinearmap.py:361-369), the fitted map adds the divergence term with
+    # weight ONE (trans_f, featlinearmap.py:512-520): the hold-out score is a quadratic form in the Gram matrix of
+    # feat'F + div, the training matrix comes from feat'F + kbt div -- two regression matrices per site unless kbt = 1
+    # (the id x id block holds no divergence: it is shared between the two and between the sites)
+    same = float(kbt) == 1.0
+    fold_grams, score_grams, totals = [], [], []
+    for site in range(n_cg):
+        na = n_act[site]
+        per_alpha = []
+        for alpha in ((float(kbt),) if same else (float(kbt), 1.0)):
+            K.gb_regmat_cols(su.Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, cols_dev[site], su.centers, su.width, CLIP,
+                             alpha, R3)
+            Gf = torch.empty((n_folds, na, na), dtype=torch.float64, device=dev)
+            for k in range(n_folds):
+                lead = lead_n if (shared_lead[k] is not None and na >= 256) else 0
+                K.gram(R3[int(bounds[k]):int(bounds[k + 1])], None, None, na, torch.float64, out=Gf[k], first_col=lead)
+                if lead:
+                    Gf[k][:lead, :lead] = shared_lead[k]
+                elif shared_lead[k] is None and lead_n >= 128:
+                    shared_lead[k] = Gf[k][:lead_n, :lead_n].clone()
+            per_alpha.append(Gf)
+        tot = per_alpha[0][0].clone()
+        for k in range(1, n_folds):
+            K.axpby(1.0, tot, 1.0, per_alpha[0][k], out=tot)
+        fold_grams.append(per_alpha[0])
+        score_grams.append(per_alpha[-1])
+        totals.append(tot)
+    del R3
+    gen = np.random.default_rng() if rng is None else rng
+    S = int(n_constraint_frames)
+    per_batch = _sites_per_batch(n_cg, n_max, S * n_cg, dev)
+    batches = _solve_batches(n_act, per_batch) if per_batch > 1 else [[i] for i in range(n_cg)]
+    scores: List[List[Optional[float]]] = []
+    for l2 in l2_values:
+        row: List[Optional[float]] = []
+        for k in range(n_folds):
+            # the frames a fit on the training subset would draw, numbered in the subset (= fold order without fold k)
+            used = [gen.choice(geo.T - lens[k], size=S, replace=False) for _ in range(n_cg)]
+            flat = np.concatenate([np.where(u < bounds[k], u, u + lens[k]) for u in used])
+            sel = torch.as_tensor(flat, device=dev)
+            Pg_sel, cg_sel = geo.Pg[sel].contiguous(), geo.cg[sel].contiguous()
+            total_q, ok = 0.0, True
+            for sites in batches:
+                nb_max = max(n_act[i] for i in sites)
+                Gs = torch.zeros((len(sites), nb_max, nb_max), dtype=torch.float64, device=dev)
+                As = torch.empty((len(sites), S * n_cg, nb_max), dtype=torch.float64, device=dev)
+                bs = torch.empty((len(sites), S * n_cg, 1), dtype=torch.float64, device=dev)
+                AtAs = torch.empty((len(sites), nb_max, nb_max), dtype=torch.float64, device=dev)
+                for j, site in enumerate(sites):
+                    na = n_act[site]
+                    if na == nb_max:
+                        K.axpby(1.0, totals[site], -1.0, fold_grams[site][k], out=Gs[j])
+                    else:
+                        Gs[j, :na, :na] = K.axpby(1.0, totals[site], -1.0, fold_grams[site][k])
+                        Gs[j].diagonal()[na:] = 1.0
+                    gauss = None
+                    if n_ch:
+                        gauss, _ = K.gb_channels(Pg_sel[site * S:(site + 1) * S], cg_sel[site * S:(site + 1) * S], site,
+                                                 geo.sizes, n_ch, su.centers, su.width, CLIP)
+                    K.gb_constraint_rows(su.Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j],
+                                         cols=cols_dev[site])
+                    K.gb_constraint_gram(su.M2, gauss, S, n_id, n_ch, n_basis, AtAs[j], cols=cols_dev[site])
+                X, stats = K.eq_qp_solve_batched(Gs, float(l2), None, As, bs, schur_reg=1e-12, n_refine=3, AtA=AtAs)
+                st_all = stats.cpu().numpy()
+                bad = [(sites[j], st_all[j]) for j in range(len(sites))
+                       if st_all[j][0] != 0 or not np.isfinite(st_all[j][1])]
+                if bad:
+                    site, st = bad[0]
+                    print(f"Map optimization failed. (site {site}: pivot {int(st[0])}, constraint residual {st[1]:.3e}, "
+                          f"before refinement {st[2]:.3e}, scale {st[3]:.3e})")
+                    ok = False
+                    break
+                q = [K.gram_quadform(score_grams[site][k], X[j, :, :n_act[site]].contiguous()) for j, site in enumerate(sites)]
+                total_q += float(torch.cat(q).sum().item())
+                del Gs, As, bs, AtAs, X, stats
+            row.append(total_q / (3.0 * lens[k] * n_cg) if ok else None)
+        scores.append(row)
+    K.drop_workspace("solve", dev)
+    return scores

@@ -253,3 +253,46 @@ def test_zero_column_compaction_is_exact():
     ocoef = orc.qp_feat_linear_map(forces.astype(np.float64), cmat, feats, divs, KBT, frames, 10.0)
     assert rel(cs, np.stack(ocoef)) < 1e-3
     assert rel(small(traj).forces, orc.cla_apply(forces.astype(np.float64), feats, divs, ocoef)) < 1e-3
+
+
+@pytest.mark.parametrize("with_id", [True, False])
+def test_featurised_grid_cv_one_pass_matches_the_loop(with_id):
+    """project_forces_grid_cv over l2_regularization of the fused featurised fit: the one-pass form (per-fold Gram
+    matrices of every site, training matrix = total - fold, hold-out score as a quadratic form) against the
+    reference's loop of fits and applications, fed by identically seeded generators (the one-pass form draws the
+    constraint frames in the loop's order).  The two score the hold-out frames through different arithmetic (float64
+    quadratic form of the float64 Gram matrix / float32 features applied frame by frame): 1e-5."""
+    from aggforce_amd import agg
+
+    coords, forces, cons, cmat = system(T=240, seed=21)
+    cmap = LinearMap(cmat)
+    gb = Curry(gb_feat, outer=8.0, inner=0.0, n_basis=4, width=1.0)
+    feat = Multifeaturize([id_feat, gb] if with_id else [gb])
+    grid = {"l2_regularization": [0.5, 10.0, 300.0]}
+    calls = {"n": 0}
+    real = agg._grid_cv_feat_reuse
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    def go(reuse):
+        # method_rng is the method's generator (constraint frames); the rng argument shuffles the folds
+        return agg.project_forces_grid_cv(grid, coords, forces, n_folds=4, rng=np.random.default_rng(3),
+                                          reuse_gram=reuse, method_rng=np.random.default_rng(17), coord_map=cmap,
+                                          constrained_inds=cons, method=qp_feat_linear_map, featurizer=feat, kbt=KBT,
+                                          n_constraint_frames=6)
+
+    agg._grid_cv_feat_reuse = counted
+    try:
+        fast, loop = go(True), go(False)
+    finally:
+        agg._grid_cv_feat_reuse = real
+    assert calls["n"] == 1  # the one-pass form really ran, and only for reuse_gram=True
+    assert set(fast) == {"scores", "sds", "n_runs"}
+    for key in loop["scores"]:
+        assert fast["n_runs"][key] == loop["n_runs"][key] == 4
+        assert abs(fast["scores"][key] - loop["scores"][key]) < 1e-5 * abs(loop["scores"][key]), key
+        assert abs(fast["sds"][key] - loop["sds"][key]) < 1e-3 * abs(loop["sds"][key]) + 1e-6 * abs(loop["scores"][key]), key
+    vals = [loop["scores"][k] for k in loop["scores"]]
+    assert len(set(np.round(vals, 6))) == 3  # the grid points really differ

@@ -244,6 +244,31 @@ def test_grid_cv_gram_reuse_applicability():
     assert grid[0][0].l2_regularization == 0.0 and grid[1][0].x == "a"
 
 
+def test_grid_cv_featurised_reuse_applicability():
+    """Which featurised project_forces_grid_cv calls take the one-pass form (host logic only)."""
+    from aggforce_amd import LinearMap
+    from aggforce_amd.agg import _feat_reuse, process_cvargs
+    from aggforce_amd.qp import Multifeaturize, gb_feat, id_feat, qp_feat_linear_map
+    from aggforce_amd.util import Curry
+
+    cmap = LinearMap([[0], [2]], n_fg_sites=4)
+    fused = Multifeaturize([id_feat, Curry(gb_feat, outer=8.0, n_basis=4)])
+    base = dict(coord_map=cmap, constrained_inds=set(), method=qp_feat_linear_map, featurizer=fused, kbt=0.6)
+    grid = process_cvargs({"l2_regularization": [1.0, 10.0]})
+    assert _feat_reuse(grid, ["l2_regularization"], base) is not None
+    assert _feat_reuse(process_cvargs({}), [], dict(base, n_constraint_frames=5)) is not None  # default l2 = 10
+    assert _feat_reuse(process_cvargs({"l2_regularization": [0.0, 1.0]}), ["l2_regularization"], base) is None
+    assert _feat_reuse(grid, ["l2_regularization"], dict(base, constrained_inds="auto")) is None
+    assert _feat_reuse(grid, ["l2_regularization"], dict(base, comm=object())) is None
+    assert _feat_reuse(grid, ["l2_regularization"], dict(base, fused=False)) is None
+    assert _feat_reuse(process_cvargs({"kbt": [0.5]}), ["kbt"], base) is None
+    generic = Multifeaturize([lambda *a, **k: None])
+    assert _feat_reuse(grid, ["l2_regularization"], dict(base, featurizer=generic)) is None
+    plain = dict(base)
+    del plain["method"]
+    assert _feat_reuse(grid, ["l2_regularization"], plain) is None  # the linear optimiser has its own one-pass form
+
+
 def test_staged_map_signatures_match_reference_names():
     import inspect
 
