@@ -164,9 +164,17 @@ def _grid_cv_gram_reuse(grid, forces, folds, kwargs) -> Dict[str, Dict[Any, Any]
     counts = torch.tensor([float(len(idx)) for idx in folds], dtype=torch.float64, device=f_dev.device)
     all_reduce_sum_sym_(fold_grams, comm)
     all_reduce_sum_(counts, comm)
-    counts = counts.tolist()
+    return _score_folds(grid, fold_grams, counts.tolist(), prob, kwargs)
+
+
+def _score_folds(grid, fold_grams, counts, prob, kwargs) -> Dict[str, Dict[Any, Any]]:
+    """Grid points x folds from per-fold Gram matrices: training matrix ``total - G_k``, one solve, hold-out score as
+    the quadratic form of the reduced coefficients in ``G_k``."""
+    import torch
+
+    n_folds = fold_grams.shape[0]
     total = fold_grams[0].clone()
-    for k in range(1, len(folds)):
+    for k in range(1, n_folds):
         K.axpby(1.0, total, 1.0, fold_grams[k], out=total)
     n_cg = prob.A.shape[0]
     results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
@@ -174,7 +182,7 @@ def _grid_cv_gram_reuse(grid, forces, folds, kwargs) -> Dict[str, Dict[Any, Any]
     for label, args in grid:
         l2 = dict(kwargs, **args).get("l2_regularization", 0.0)
         scores = []
-        for k in range(len(folds)):
+        for k in range(n_folds):
             try:
                 K.axpby(1.0, total, -1.0, fold_grams[k], out=train)
                 X = prob.solve(train, l2)
@@ -186,6 +194,24 @@ def _grid_cv_gram_reuse(grid, forces, folds, kwargs) -> Dict[str, Dict[Any, Any]
         results[SDS_KNAME][label] = sample_sd(scores)
         results[NRUNS_KNAME][label] = len(scores)
     return results
+
+
+_NOISED_REUSE_FIXED_ARGS: Final = frozenset(
+    {"coord_map", "constrained_inds", "method", "var", "kbt", "seed", "l2_regularization", "solver_args", "gram_dtype"}
+)
+
+
+def _noised_reuse_applicable(grid_names, kwargs) -> bool:
+    """joptgauss_map with explicit constraints and a grid over ``l2_regularization`` only: one noise realisation, one
+    pass over the frames (``qp/gauss.py:cv_joptgauss_fold_grams``); layouts the in-place fit does not take return
+    None there and the loop is followed."""
+    from .qp import joptgauss_map
+
+    if kwargs.get("method") is not joptgauss_map or not {"coord_map", "var", "kbt"} <= set(kwargs):
+        return False
+    if not set(grid_names) <= _GRAM_REUSE_GRID_ARGS or not set(kwargs) <= _NOISED_REUSE_FIXED_ARGS:
+        return False
+    return not isinstance(kwargs.get("constrained_inds", PROJECT_FORCES_CNSTR_AUTO), str)
 
 
 _FEAT_REUSE_FIXED_ARGS: Final = frozenset(
@@ -232,6 +258,7 @@ def project_forces_grid_cv(
     rng=None,
     reuse_gram: bool = True,
     method_rng=None,
+    cv_noise=None,
     **kwargs,
 ) -> Dict[str, Dict[NamedTuple, T]]:
     """Grid cross-validation over project_forces arguments (reference agg.py:142-235).
@@ -240,7 +267,11 @@ def project_forces_grid_cv(
     ``force_smoothness`` of the mapped hold-out forces; returns ``{"scores", "sds", "n_runs"}``
     keyed by the grid point.  ``rng`` (a numpy Generator) makes the fold shuffle reproducible; the
     reference uses an unseeded generator.  ``method_rng`` is handed to ``method`` as ``rng=`` in every
-    fit (methods that sample, e.g. the constraint frames of ``qp_feat_linear_map``).  When the grid runs over ``l2_regularization`` of the
+    fit (methods that sample, e.g. the constraint frames of ``qp_feat_linear_map``).  ``joptgauss_map``
+    with explicit constraints and a grid over ``l2_regularization`` also takes a one-pass form: ONE
+    noise realisation for all frames (the loop draws afresh for every fit and application), per-fold
+    Gram matrices of the extended system; ``cv_noise`` (n_frames, n_cg, 3) standard normals fixes that
+    realisation (tests).  When the grid runs over ``l2_regularization`` of the
     linear optimiser with explicit constraints and ``reuse_gram`` is true, all folds and grid
     points share one pass over the frames (``_grid_cv_gram_reuse``); the same holds for
     ``qp_feat_linear_map`` with the fused ``[id_feat | gb_feat]`` featurisers and every
@@ -260,6 +291,18 @@ def project_forces_grid_cv(
         if not K.has_nan(f_dev):  # NaN handling follows the generic path
             return _grid_cv_gram_reuse(grid, f_dev, folds, kwargs)
         del f_dev
+    if reuse_gram and _noised_reuse_applicable(list(cv_arg_dict.keys()), kwargs):
+        from .qp.gauss import cv_joptgauss_fold_grams
+
+        f_dev, c_dev = K.as_device(forces), K.as_device(coords)
+        made = None
+        if not K.has_nan(f_dev) and not K.has_nan(c_dev):
+            made = cv_joptgauss_fold_grams(c_dev, f_dev, kwargs["coord_map"], kwargs["var"], kwargs["kbt"],
+                                           kwargs.get("constrained_inds"), kwargs.get("seed"), folds,
+                                           kwargs.get("gram_dtype"), noise=cv_noise)
+        del f_dev, c_dev
+        if made is not None:
+            return _score_folds(grid, made[0], [float(len(f)) for f in folds], made[1], kwargs)
     feat_cv = _feat_reuse(grid, list(cv_arg_dict.keys()), kwargs) if reuse_gram else None
     if feat_cv is not None and not K.has_nan(K.as_device(forces)) and not K.has_nan(K.as_device(coords)):
         return _grid_cv_feat_reuse(feat_cv, grid, coords, forces, folds, kwargs, method_rng)

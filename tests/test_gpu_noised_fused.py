@@ -147,3 +147,46 @@ def test_generated_sites_equal_the_extended_arrays_bit_for_bit():
             oc, of = a.augment_trajectory(coords, forces, KBT)
             y, fa, _ = b.noise_sites(coords, KBT)
             assert np.array_equal(oc[:, N:, :], y.cpu().numpy()) and np.array_equal(of[:, N:, :], fa.cpu().numpy())
+
+
+@pytest.mark.parametrize("name", ["slice_f32", "dense_f64_constraints"])
+def test_noised_grid_cv_one_pass(name):
+    """project_forces_grid_cv over l2_regularization of joptgauss_map in one pass (one noise realisation, per-fold
+    Gram matrices of the extended system read in place): (1) with the realisation fixed, equal to the LINEAR one-pass
+    cross-validation -- itself checked against the loop and the oracle in test_gpu_staged.py -- run on the extended
+    trajectory built with the same noise; (2) against the reference's loop, which draws fresh noise for every fit and
+    application, statistically."""
+    from aggforce_amd import agg
+    from aggforce_amd.map import lmap_augvariables
+    from aggforce_amd.trajectory import AugmentedTrajectory, CondNormal
+
+    coords, forces, cmat, cons, _, eps, dt = case(name)
+    cmap = LinearMap(cmat)
+    grid = {"l2_regularization": [0.0, 1.0, 50.0]}
+    calls = {"n": 0}
+    real = agg._score_folds
+
+    def counted(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    agg._score_folds = counted
+    try:
+        fast = agg.project_forces_grid_cv(grid, coords, forces, n_folds=4, rng=np.random.default_rng(2), cv_noise=eps[0],
+                                          coord_map=cmap, constrained_inds=cons, method=joptgauss_map, var=VAR, kbt=KBT)
+    finally:
+        agg._score_folds = real
+    assert calls["n"] == 1  # the one-pass form ran
+    aug = AugmentedTrajectory.from_trajectory(t=Trajectory(coords=coords, forces=forces), kbt=KBT,
+                                              augmenter=CondNormal(var=VAR, premap=cmap).inject_noise(eps[0]))
+    lin = agg.project_forces_grid_cv(grid, aug.coords, aug.forces, n_folds=4, rng=np.random.default_rng(2),
+                                     coord_map=lmap_augvariables(aug), constrained_inds=cons)
+    tol = 2e-4 if dt == np.float32 else 1e-6  # float32: products in float32 on differently rounded operands
+    for key in lin["scores"]:
+        assert fast["n_runs"][key] == lin["n_runs"][key] == 4
+        assert abs(fast["scores"][key] - lin["scores"][key]) < tol * abs(lin["scores"][key]), key
+    loop = agg.project_forces_grid_cv(grid, coords, forces, n_folds=4, rng=np.random.default_rng(2), reuse_gram=False,
+                                      coord_map=cmap, constrained_inds=cons, method=joptgauss_map, var=VAR, kbt=KBT, seed=5)
+    for key in loop["scores"]:
+        assert loop["n_runs"][key] == 4
+        assert abs(fast["scores"][key] - loop["scores"][key]) < 0.05 * abs(loop["scores"][key]), key

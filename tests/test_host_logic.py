@@ -269,6 +269,23 @@ def test_grid_cv_featurised_reuse_applicability():
     assert _feat_reuse(grid, ["l2_regularization"], plain) is None  # the linear optimiser has its own one-pass form
 
 
+def test_grid_cv_noised_reuse_applicability():
+    from aggforce_amd import LinearMap, joptgauss_map, stagedjoptgauss_map
+    from aggforce_amd.agg import _noised_reuse_applicable
+
+    cmap = LinearMap([[0], [2]], n_fg_sites=4)
+    base = dict(coord_map=cmap, constrained_inds=None, method=joptgauss_map, var=0.01, kbt=0.6)
+    assert _noised_reuse_applicable(["l2_regularization"], base)
+    assert _noised_reuse_applicable([], dict(base, seed=3, l2_regularization=1.0))
+    assert not _noised_reuse_applicable(["var"], base)
+    assert not _noised_reuse_applicable(["l2_regularization"], dict(base, constrained_inds="auto"))
+    assert not _noised_reuse_applicable(["l2_regularization"], dict(base, method=stagedjoptgauss_map))
+    assert not _noised_reuse_applicable(["l2_regularization"], dict(base, comm=object()))
+    assert not _noised_reuse_applicable(["l2_regularization"], dict(base, noise=[None]))
+    del base["var"]
+    assert not _noised_reuse_applicable(["l2_regularization"], base)
+
+
 def test_staged_map_signatures_match_reference_names():
     import inspect
 
