@@ -236,11 +236,13 @@ def _feat_reuse(grid, grid_names, kwargs):
     return getattr(kwargs["featurizer"], "fused_cv", None)
 
 
-def _grid_cv_feat_reuse(cv, grid, coords, forces, folds, kwargs, method_rng=None) -> Dict[str, Dict[Any, Any]]:
+def _grid_cv_feat_reuse(cv, grid, coords, forces, folds, kwargs, method_rng=None) -> Union[Dict[str, Dict[Any, Any]], None]:
     l2_values = [float(dict(kwargs, **args).get("l2_regularization", 1e1)) for _, args in grid]
     cons = kwargs.get("constrained_inds")
     table = cv(coords, forces, kwargs["coord_map"], kwargs["kbt"], kwargs.get("n_constraint_frames", 20),
                set() if cons is None else cons, l2_values, folds, method_rng)
+    if table is None:  # does not fit the device: the loop
+        return None
     results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
     for (label, _), row in zip(grid, table):
         scores = [v for v in row if v is not None]
@@ -305,7 +307,9 @@ def project_forces_grid_cv(
             return _score_folds(grid, made[0], [float(len(f)) for f in folds], made[1], kwargs)
     feat_cv = _feat_reuse(grid, list(cv_arg_dict.keys()), kwargs) if reuse_gram else None
     if feat_cv is not None and not K.has_nan(K.as_device(forces)) and not K.has_nan(K.as_device(coords)):
-        return _grid_cv_feat_reuse(feat_cv, grid, coords, forces, folds, kwargs, method_rng)
+        done = _grid_cv_feat_reuse(feat_cv, grid, coords, forces, folds, kwargs, method_rng)
+        if done is not None:
+            return done
     results: Dict[str, Dict[Any, Any]] = {SCORES_KNAME: {}, SDS_KNAME: {}, NRUNS_KNAME: {}}
     take = _take_frames
     for label, args in grid:

@@ -113,11 +113,11 @@ def cv_joptgauss_fold_grams(coords, forces, coord_map: LinearMap, var: float, kb
     """Per-fold Gram matrices of joptgauss_map's extended system for ``project_forces_grid_cv``'s one-pass form, or
     None when the layout does not allow the in-place fit (see ``_joptgauss_without_extended_arrays``).
 
-    The frames are gathered into fold order, ONE noise realisation is drawn for all of them (the reference's loop
-    draws afresh for every fit and every application: the same distribution, and here every grid point and fold
-    sees common random numbers), and fold k's matrix is ``Tm' Gram([F | Fa] on fold k) Tm`` with the constraint
-    groups summed -- exactly the matrix a fit on those frames alone would form.  Returns (fold_grams (k, n, n),
-    LinearProblem of the extended system)."""
+    ONE noise realisation is drawn for every frame (the reference's loop draws afresh for every fit and every
+    application: the same distribution, and here every grid point and fold sees common random numbers), fold by
+    fold on the gathered frames of the fold, and fold k's matrix is ``Tm' Gram([F | Fa] on fold k) Tm`` with the
+    constraint groups summed -- exactly the matrix a fit on those frames alone would form.  Returns (fold_grams
+    (k, n, n), LinearProblem of the extended system)."""
     import torch
 
     from .qplinear import LinearProblem
@@ -129,26 +129,23 @@ def cv_joptgauss_fold_grams(coords, forces, coord_map: LinearMap, var: float, kb
             or (gram_dtype is not None and K.torch_dtype(gram_dtype) != f_dev.dtype)
             or torch.promote_types(c_dev.dtype, K.torch_dtype(augmenter.dtype)) != f_dev.dtype):
         return None
-    perm = np.concatenate(folds)
-    pidx = torch.as_tensor(perm, device=f_dev.device)
-    f_p, c_p = f_dev[pidx].contiguous(), c_dev[pidx].contiguous()  # frames in fold order: a fold is a row range
-    if noise is not None:
-        augmenter.inject_noise(np.asarray(noise)[perm])
-    y, fa, cols = augmenter.noise_sites(c_p, kbt)
-    del y, c_p
     aug_cmap = LinearMap(mapping=[[i] for i in range(n_real, n_real + n_aug)], n_fg_sites=n_real + n_aug)
     prob = LinearProblem(aug_cmap, constraints, f_dev.device)
-    bounds = np.concatenate([[0], np.cumsum([len(f) for f in folds])]).astype(np.int64)
     grams = []
-    for k in range(len(folds)):
-        a, b = int(bounds[k]), int(bounds[k + 1])
-        fk, fak = f_p[a:b], fa[a:b]
+    for idx in folds:  # one fold's frames at a time: the gathered copies never exceed a fold
+        sel = torch.as_tensor(np.asarray(idx), device=f_dev.device)
+        fk, ck = f_dev[sel].contiguous(), c_dev[sel].contiguous()
+        if noise is not None:
+            augmenter.inject_noise(np.asarray(noise)[np.asarray(idx)])
+        y, fak, cols = augmenter.noise_sites(ck, kbt)  # (every call advances the augmenter's stream: independent draws)
+        del y, ck
         if not K.gram_pair_ok(fk, fak):
             return None
         G = K.augmented_gram(K.gram_pair(fk, fak), n_real, cols)
         if prob.grp_ptr is not None:
             G = K.sym_group_reduce(G, prob.grp_ptr, prob.grp_atoms, prob.n_red)
         grams.append(G)
+        del fk, fak
     return torch.stack(grams), prob
 
 

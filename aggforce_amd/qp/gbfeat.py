@@ -455,7 +455,7 @@ def fit_id_gb(
 
 def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_frames: int, constraints: Constraints,
              l2_values: List[float], folds: List[np.ndarray], rng, use_id: bool, gb_kwargs: Optional[dict]
-             ) -> List[List[Optional[float]]]:
+             ) -> Optional[List[List[Optional[float]]]]:
     """Cross-validation of the fused [id_feat | gb_feat] fit over ``l2_regularization`` in ONE pass over the frames
     (the featurised counterpart of ``agg._grid_cv_gram_reuse``; replaces the loop body of the
     reference's agg.py:208-231 for this method).
@@ -469,7 +469,8 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
     kept are those not identically zero over ALL frames, a superset of every training set's (their extra coefficients
     are exact zeros: needs l2 > 0, which the caller checks).
 
-    Returns ``scores[i][k]`` for l2_values[i] and fold k (None where the solve failed, as the loop would skip it)."""
+    Returns ``scores[i][k]`` for l2_values[i] and fold k (None where the solve failed, as the loop would skip it), or
+    None -- before anything is drawn from ``rng`` -- when the per-fold matrices would not fit the device."""
     import torch
 
     n_folds = len(folds)
@@ -483,9 +484,16 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
     geo, n_id, n_ch, n_basis, n_cg = su.geo, su.n_id, su.n_ch, su.n_basis, su.n_cg
     cols_of, n_act = su.cols_of, su.n_act
     dev = geo.dev
-    cols_dev = [torch.from_numpy(c).to(dev) for c in cols_of]
     n_max = max(n_act)
     ld = -(-n_max // 128) * 128
+    # every site keeps its per-fold matrices (twice unless kbt = 1) for the whole grid: BASELINE config 4 holds 23 GB of
+    # them; a system whose matrices do not fit beside the regression matrix and a batch of solves takes the loop
+    same = float(kbt) == 1.0
+    held = (1 if same else 2) * (n_folds + 1) * 8 * sum(n * n for n in n_act) + geo.T * ld * 24
+    free_b, _ = K.device_memory(dev)
+    if held > 0.5 * free_b:
+        return None
+    cols_dev = [torch.from_numpy(c).to(dev) for c in cols_of]
     R3 = torch.zeros((geo.T, ld, 3), dtype=torch.float64, device=dev)
     lead_n = (n_id // 128) * 128
     shared_lead: List[Optional[torch.Tensor]] = [None] * n_folds  # the id x id block is the same for every site
@@ -493,7 +501,6 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
     # weight ONE (trans_f, featlinearmap.py:512-520): the hold-out score is a quadratic form in the Gram matrix of
     # feat'F + div, the training matrix comes from feat'F + kbt div -- two regression matrices per site unless kbt = 1
     # (the id x id block holds no divergence: it is shared between the two and between the sites)
-    same = float(kbt) == 1.0
     fold_grams, score_grams, totals = [], [], []
     for site in range(n_cg):
         na = n_act[site]
