@@ -300,10 +300,14 @@ def eq_qp_solve_batched(
     schur_reg: float = 0.0,
     n_refine: int = 1,
     AtA: Optional[torch.Tensor] = None,
+    perm: Optional[torch.Tensor] = None,
+    a_first_col: int = 0,
 ) -> Tuple[torch.Tensor, torch.Tensor]:
     """Independent problems side by side: G (p, n, n), A (p, m, n), B (p, m, nrhs) or None ->
     X (p, nrhs, n), stats (p, 4); see aggf_eq_qp_solve_batched.  ``AtA`` (p, n, n): the caller's A'A (lower
-    triangle read), aggf_eq_qp_solve_batched_shift."""
+    triangle read), aggf_eq_qp_solve_batched_shift; with it ``perm`` (p, n) int32 = the order in which the
+    factorisation takes the variables and ``a_first_col`` = the number of leading variables (in that order) no
+    constraint row touches in any problem."""
     l = lib()
     if G.dim() != 3 or A.dim() != 3 or G.shape[0] != A.shape[0] or G.shape[1] != G.shape[2] or A.shape[2] != G.shape[1]:
         raise ValueError(f"shape mismatch: G {tuple(G.shape)}, A {tuple(A.shape)}")
@@ -323,14 +327,19 @@ def eq_qp_solve_batched(
     if AtA is not None:
         if AtA.shape != G.shape or AtA.dtype != torch.float64 or not AtA.is_contiguous():
             raise ValueError(f"AtA must be contiguous float64 of G's shape, got {tuple(AtA.shape)}")
+        if perm is not None and (perm.shape != (npb, n) or perm.dtype != torch.int32 or not perm.is_contiguous()):
+            raise ValueError(f"perm must be contiguous int32 of shape {(npb, n)}, got {tuple(perm.shape)}")
         with _timed("solve"):
             check(
-                l.aggf_eq_qp_solve_batched_shift(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), ptr(AtA), m, ptr(B), nrhs,
+                l.aggf_eq_qp_solve_batched_shift(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), ptr(AtA), ptr(perm),
+                                                 int(a_first_col) if perm is not None else 0, m, ptr(B), nrhs,
                                                  float(schur_reg), int(n_refine), npb, ptr(X), ptr(stats), ptr(ws), need,
                                                  stream_ptr()),
                 "aggf_eq_qp_solve_batched_shift",
             )
         return X, stats
+    if perm is not None:
+        raise ValueError("perm needs AtA (aggf_eq_qp_solve_batched_shift)")
     with _timed("solve"):
         check(
             l.aggf_eq_qp_solve_batched(ptr(G), n, float(l2), ptr(l2_diag), ptr(A), m, ptr(B), nrhs, float(schur_reg),

@@ -38,7 +38,7 @@ PROTOTYPES = {
     "aggf_eq_qp_solve": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_eq_qp_batched_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
     "aggf_eq_qp_solve_batched": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
-    "aggf_eq_qp_solve_batched_shift": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
+    "aggf_eq_qp_solve_batched_shift": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _i32, _dbl, _i32, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_eq_qp_pinned_workspace_bytes": (_sz, [_i32, _i32]),
     "aggf_eq_qp_solve_pinned": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _vp, _vp, _sz, _vp]),
     "aggf_expand_map": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),

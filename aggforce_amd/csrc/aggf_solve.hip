@@ -548,14 +548,17 @@ __global__ __launch_bounds__(256) void max_diag_kernel(const double* __restrict_
 }
 
 // Pt (npad x npad) = (G + l2*diag)/s [+ shift] on the n x n block, identity on the padding; `shift` (n x n per
-// problem, may be NULL) is a caller-formed A'A of which only the lower triangle is read
+// problem, may be NULL) is a caller-formed A'A of which only the lower triangle is read; `perm` (n per problem, may be
+// NULL) reorders the variables
 __global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict__ G, int n, int64_t g_ps, int npad,
                                                        double l2, const double* __restrict__ l2d,
                                                        const double* __restrict__ scale, int64_t scale_ps,
                                                        const double* __restrict__ shift,
+                                                       const int32_t* __restrict__ perm,
                                                        double* __restrict__ Pt, int64_t pt_ps) {
   G += blockIdx.y * g_ps;
   if (shift) shift += blockIdx.y * g_ps;
+  if (perm) perm += (int64_t)blockIdx.y * n;
   Pt += blockIdx.y * pt_ps;
   const double inv_s = 1.0 / scale[blockIdx.y * scale_ps];
   const int64_t total = (int64_t)npad * npad;
@@ -564,10 +567,13 @@ __global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict_
     const int i = (int)(e / npad), j = (int)(e - (int64_t)i * npad);
     double v;
     if (i < n && j < n) {
-      v = G[(int64_t)i * n + j];
-      if (i == j) v += l2 * (l2d ? l2d[i] : 1.0);
+      // variable i of the factorisation = variable perm[i] of the caller (symmetric permutation of G and of the shift,
+      // whose lower triangle is all the caller wrote)
+      const int gi = perm ? perm[i] : i, gj = perm ? perm[j] : j;
+      v = G[(int64_t)gi * n + gj];
+      if (i == j) v += l2 * (l2d ? l2d[gi] : 1.0);
       v *= inv_s;
-      if (shift && j <= i) v += shift[(int64_t)i * n + j];
+      if (shift && j <= i) v += gi >= gj ? shift[(int64_t)gi * n + gj] : shift[(int64_t)gj * n + gi];
     } else {
       v = (i == j) ? 1.0 : 0.0;
     }
@@ -578,9 +584,11 @@ __global__ __launch_bounds__(256) void build_pt_kernel(const double* __restrict_
 // dst (rd x cd, zero padded) = src (rs x cs) or its transpose; identity if src == NULL
 __global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict__ src, int rs, int cs, int64_t src_ps,
                                                        int transpose, double* __restrict__ dst,
-                                                       int rd, int cd, int64_t dst_ps) {
+                                                       int rd, int cd, int64_t dst_ps,
+                                                       const int32_t* __restrict__ colperm = nullptr) {
   if (src) src += blockIdx.y * src_ps;
   dst += blockIdx.y * dst_ps;
+  if (colperm) colperm += (int64_t)blockIdx.y * cs;  // column j of the copy = column colperm[j] of src
   const int64_t total = (int64_t)rd * cd;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
@@ -589,9 +597,9 @@ __global__ __launch_bounds__(256) void pad_copy_kernel(const double* __restrict_
     if (!src) {
       v = (i == j && i < rs) ? 1.0 : 0.0;
     } else if (!transpose) {
-      if (i < rs && j < cs) v = src[(int64_t)i * cs + j];
+      if (i < rs && j < cs) v = src[(int64_t)i * cs + (colperm ? colperm[j] : j)];
     } else {
-      if (j < rs && i < cs) v = src[(int64_t)j * cs + i];
+      if (j < rs && i < cs) v = src[(int64_t)j * cs + (colperm ? colperm[i] : i)];
     }
     dst[e] = v;
   }
@@ -643,14 +651,16 @@ __global__ __launch_bounds__(256) void axpy_kernel(double* __restrict__ x, const
 
 // X (nrhs x n) = Xt (npad x rpad) transposed and cropped
 __global__ __launch_bounds__(256) void crop_transpose_kernel(const double* __restrict__ Xt, int rpad, int64_t xt_ps,
-                                                             int n, int nrhs, double* __restrict__ X) {
+                                                             int n, int nrhs, double* __restrict__ X,
+                                                             const int32_t* __restrict__ perm = nullptr) {
   Xt += blockIdx.y * xt_ps;
   X += blockIdx.y * (int64_t)nrhs * n;
+  if (perm) perm += (int64_t)blockIdx.y * n;
   const int64_t total = (int64_t)nrhs * n;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
        e += (int64_t)gridDim.x * blockDim.x) {
     const int r = (int)(e / n), i = (int)(e - (int64_t)r * n);
-    X[e] = Xt[(int64_t)i * rpad + r];
+    X[(int64_t)r * n + (perm ? perm[i] : i)] = Xt[(int64_t)i * rpad + r];
   }
 }
 
@@ -846,10 +856,11 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
 
 // Y = L^-1 Bw ; Bw (npad x w, ld = w) is consumed.  Full 256-row blocks use their inverted diagonal
 // block, the (< 256 rows) remainder the 64x64 inverses.
-static void solve_lower(Ctx& c, Mat L, int npad, Mat Dinv, Mat Bw, Mat Y, int w) {
+// first_big > 0: rows of Bw above block first_big are zero, and so are Y's -- they are neither read nor written.
+static void solve_lower(Ctx& c, Mat L, int npad, Mat Dinv, Mat Bw, Mat Y, int w, int first_big = 0) {
   const int nb = npad / NB, nbig = npad / BIG;
   const Mat Dbig = dbig_of(Dinv, npad);
-  for (int ob = 0; ob < nbig && !c.rc; ++ob) {
+  for (int ob = first_big; ob < nbig && !c.rc; ++ob) {
     const int64_t r0 = (int64_t)ob * BIG;
     gemm<false, false>(c, BIG, w, BIG, 1.0, Dbig.at(r0, 0), Bw.at(r0, 0), 0.0, Y.at(r0, 0));
     const int rem = npad - (int)(r0 + BIG);
@@ -934,7 +945,8 @@ static SolveLayout solve_layout(int n, int m, int nrhs, int nprob) {
 static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double* l2_diag, const double* A,
                             int32_t m, const double* B, int32_t nrhs, double schur_reg, int32_t n_refine,
                             int32_t nprob, double* X, double* stats, void* ws, size_t ws_bytes, void* stream_v,
-                            const char* who, const double* AtA = nullptr) {
+                            const char* who, const double* AtA = nullptr, const int32_t* perm = nullptr,
+                            int32_t a_first_col = 0) {
   if (!G || !A || !X || !stats || !ws) return fail(AGGF_ERR_ARG, "%s: NULL pointer", who);
   if (n <= 0 || m <= 0 || nrhs <= 0 || nprob <= 0) return fail(AGGF_ERR_ARG, "%s: empty problem", who);
   if (!B && nrhs != m) return fail(AGGF_ERR_ARG, "%s: B == NULL needs nrhs == m", who);
@@ -961,14 +973,22 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   hipStream_t st = c.stream;
   const int np = nprob;
   const int64_t g_ps = (int64_t)n * n, a_ps = (int64_t)m * n, b_ps = (int64_t)m * nrhs;
+  // Columns of A (in the factorisation's variable order) before a_first_col are zero in every problem: L^-1 A' is zero
+  // above that row, so the forward solve, the Schur complement and every product with A or Y start at the 256-row
+  // block holding it.  (Sparse constraint rows -- a slice coordinate map touches 1 + n_basis feature columns per
+  // cg site -- with the touched variables permuted to the end: BASELINE config 4 keeps 576 of ~2100-3000 rows.)
+  if (a_first_col < 0 || a_first_col > n) return fail(AGGF_ERR_ARG, "%s: a_first_col out of range", who);
+  const int ob0 = a_first_col >= n ? (n - 1) / BIG : a_first_col / BIG;  // first 256-row block of Y that is not zero
+  const int64_t r0 = (int64_t)(ob0 < npad / BIG ? ob0 : npad / BIG) * BIG;
+  const int first_big = (int)(r0 / BIG);
 
   hipLaunchKernelGGL(init_stats_kernel, dim3((unsigned)ceil_div(4 * np, 64)), dim3(64), 0, st, stats, 4 * np);
   hipLaunchKernelGGL(max_diag_kernel, dim3(1, np), dim3(256), 0, st, G, n, g_ps, l2, l2_diag, scal, (int64_t)4);
   hipLaunchKernelGGL(copy_scalar_kernel, dim3(np), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
   hipLaunchKernelGGL(build_pt_kernel, flat_grid((int64_t)npad * npad, np), dim3(256), 0, st, G, n, g_ps, npad, l2,
-                     l2_diag, scal, (int64_t)4, AtA, Pt.p, Pt.ps);
+                     l2_diag, scal, (int64_t)4, AtA, perm, Pt.p, Pt.ps);
   hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad, np), dim3(256), 0, st, A, m, n, a_ps, 0, Ap.p,
-                     mpad, npad, Ap.ps);
+                     mpad, npad, Ap.ps, perm);
   hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * rpad, np), dim3(256), 0, st, B,
                      B ? m : (m < nrhs ? m : nrhs), nrhs, b_ps, 0, Bp.p, mpad, rpad, Bp.ps);
   AGGF_LAUNCH_OK();
@@ -978,10 +998,10 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   cholesky(c, Pt, npad, Dinv, stats, 0);
   // Y = L^-1 A'
   hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * mpad, np), dim3(256), 0, st, A, m, n, a_ps, 1, Bw_m.p,
-                     npad, mpad, Bw_m.ps);
-  solve_lower(c, Pt, npad, Dinv, Bw_m, Y, mpad);
-  // S = Y'Y (identity on the padding), factor it
-  gemm<true, false>(c, mpad, mpad, npad, 1.0, Y, Y, 0.0, S, 1);
+                     npad, mpad, Bw_m.ps, perm);
+  solve_lower(c, Pt, npad, Dinv, Bw_m, Y, mpad, first_big);
+  // S = Y'Y (identity on the padding), factor it; rows of Y above r0 are zero (and were never written)
+  gemm<true, false>(c, mpad, mpad, npad - (int)r0, 1.0, Y.at(r0, 0), Y.at(r0, 0), 0.0, S, 1);
   if (mpad > m) hipLaunchKernelGGL(fix_pad_diag_kernel, dim3(1, np), dim3(64), 0, st, S.p, m, mpad, S.ps);
   if (schur_reg > 0.0) hipLaunchKernelGGL(schur_reg_kernel, dim3(1, np), dim3(256), 0, st, S.p, m, mpad, S.ps, schur_reg);
   cholesky(c, S, mpad, DinvS, stats, n);
@@ -993,13 +1013,19 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
     solve_lower_t(c, S, mpad, DinvS, T2, out, rpad);
   };
   schur_solve(Bp, Lam);
-  gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, Lam, 0.0, Z);
+  // Z = Y Lam: rows above r0 are zeros
+  auto y_times = [&](Mat rhs) {
+    if (r0 > 0 && hipMemset2DAsync(Z.p, (size_t)Z.ps * sizeof(double), 0, (size_t)r0 * rpad * sizeof(double), (size_t)np, st) != hipSuccess)
+      c.rc = fail(AGGF_ERR_HIP, "%s: device memset failed", who);
+    gemm<false, false>(c, npad - (int)r0, rpad, mpad, 1.0, Y.at(r0, 0), rhs, 0.0, Z.at(r0, 0));
+  };
+  y_times(Lam);
   solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
   // refinement on the constraint residual R = A Xt - B:  Xt -= P~^-1 A' S^-1 R
   int64_t rb = ceil_div((int64_t)m * nrhs, 256 * 8);
   const unsigned resid_blocks = (unsigned)(rb < 1 ? 1 : rb > 64 ? 64 : rb);
   for (int it = 0; it < n_refine; ++it) {
-    gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, Xt, 0.0, Lam);
+    gemm<false, false>(c, mpad, rpad, npad - (int)r0, 1.0, Ap.at(0, r0), Xt.at(r0, 0), 0.0, Lam);
     if (it > 0) hipLaunchKernelGGL(zero_scalar_kernel, dim3(np), dim3(1), 0, st, scal + 1, (int64_t)4);
     hipLaunchKernelGGL(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps,
                        it == 0 ? stats + 2 : scal + 1, (int64_t)4);
@@ -1008,16 +1034,16 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
     // mpad * rpad elements, but with its own per-problem stride
     const Mat SR{Bw_r.p, rpad, Bw_r.ps};
     schur_solve(Lam, SR);
-    gemm<false, false>(c, npad, rpad, mpad, 1.0, Y, SR, 0.0, Z);
+    y_times(SR);
     solve_lower_t(c, Pt, npad, Dinv, Z, X2, rpad);
     hipLaunchKernelGGL(axpy_kernel, flat_grid((int64_t)np * l.e_nr), dim3(256), 0, st, Xt.p, X2.p, -1.0,
                        (int64_t)np * (int64_t)l.e_nr);
   }
-  gemm<false, false>(c, mpad, rpad, npad, 1.0, Ap, Xt, 0.0, Lam);
+  gemm<false, false>(c, mpad, rpad, npad - (int)r0, 1.0, Ap.at(0, r0), Xt.at(r0, 0), 0.0, Lam);
   hipLaunchKernelGGL(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps, stats + 1,
                      (int64_t)4);
   hipLaunchKernelGGL(crop_transpose_kernel, flat_grid((int64_t)nrhs * n, np), dim3(256), 0, st, Xt.p, rpad, Xt.ps, n,
-                     nrhs, X);
+                     nrhs, X, perm);
   AGGF_LAUNCH_OK();
   return c.rc;
 }
@@ -1136,12 +1162,15 @@ extern "C" int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, c
 }
 
 extern "C" int aggf_eq_qp_solve_batched_shift(const double* G, int32_t n, double l2, const double* l2_diag,
-                                              const double* A, const double* AtA, int32_t m, const double* B,
-                                              int32_t nrhs, double schur_reg, int32_t n_refine, int32_t n_problems,
-                                              double* X, double* stats, void* ws, size_t ws_bytes, void* stream_v) {
+                                              const double* A, const double* AtA, const int32_t* perm,
+                                              int32_t a_first_col, int32_t m, const double* B, int32_t nrhs,
+                                              double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
+                                              double* stats, void* ws, size_t ws_bytes, void* stream_v) {
   if (!AtA) return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve_batched_shift: NULL pointer");
+  if (a_first_col != 0 && !perm)
+    return fail(AGGF_ERR_ARG, "aggf_eq_qp_solve_batched_shift: a_first_col refers to the order perm gives");
   return eq_qp_solve_impl(G, n, l2, l2_diag, A, m, B, nrhs, schur_reg, n_refine, n_problems, X, stats, ws, ws_bytes,
-                          stream_v, "aggf_eq_qp_solve_batched_shift", AtA);
+                          stream_v, "aggf_eq_qp_solve_batched_shift", AtA, perm, a_first_col);
 }
 
 // ---- Gram algebra for cross-validation (project_forces_grid_cv with Gram reuse) ---------------

@@ -279,9 +279,35 @@ def _fused_setup(coords, forces, coord_map: LinearMap, constraints: Constraints,
         keep = ((lo[:, :, None] < c + reach) & (hi[:, :, None] > c - reach)).reshape(n_cg, n_ch * n_basis)
     cols_of = [np.nonzero(keep[site])[0].astype(np.int32) for site in range(n_cg)]
     n_act = [n_id + len(cols) for cols in cols_of]
-    return types.SimpleNamespace(geo=geo, fdt=fdt, drop_last=drop_last, n_basis=n_basis, width=width,
+    # Which of a site's variables can a constraint row touch at all?  Row (s, c) of A is Mg[c, g(f)] w_s(f): only
+    # columns whose group lies in the support of the group-summed coordinate map -- for a slice map one group per cg
+    # site, i.e. n_cg (1 + n_basis) variables of thousands.  The batched solve takes them LAST (_solve_order).
+    hit = np.any(geo.Mg != 0.0, axis=0)  # (G,)
+    touched = [np.concatenate([hit[:n_id], hit[cols // n_basis] if len(cols) else np.zeros(0, dtype=bool)])
+               for cols in cols_of]
+    return types.SimpleNamespace(touched=touched, geo=geo, fdt=fdt, drop_last=drop_last, n_basis=n_basis, width=width,
                                  centers_h=centers_h, centers=centers, n_id=n_id, n_ch=n_ch, n_feat=n_feat, Fg=Fg,
                                  Mg=Mg, M2=M2, n_cg=n_cg, cols_of=cols_of, n_act=n_act)
+
+
+def _solve_order(sites: List[int], n_act: List[int], touched: List[np.ndarray], nb_max: int, device):
+    """(perm (len(sites), nb_max) int32 on the device, a_first_col) for aggf_eq_qp_solve_batched_shift: per site the
+    variables no constraint row touches first, then the batch's padding variables, then the touched ones;
+    ``a_first_col`` = the number of leading variables untouched in EVERY site of the batch.  (None, 0) when that saves
+    less than one 256-row block of the forward solve."""
+    import os
+
+    import torch
+
+    first = nb_max - max(int(touched[i].sum()) for i in sites)
+    if first < 256 or os.environ.get("AGGF_FEAT_ORDER", "1") == "0":  # (the switch: A/B measurements)
+        return None, 0
+    perm = np.empty((len(sites), nb_max), dtype=np.int32)
+    for j, i in enumerate(sites):
+        t = touched[i]
+        idx = np.arange(n_act[i], dtype=np.int32)
+        perm[j] = np.concatenate([idx[~t], np.arange(n_act[i], nb_max, dtype=np.int32), idx[t]])
+    return torch.from_numpy(perm).to(device), int(first)
 
 
 def fit_id_gb(
@@ -411,8 +437,9 @@ def fit_id_gb(
                 main_stream.wait_stream(st)
         phase.__exit__(None, None, None)
         all_reduce_sum_sym_(Gs, comm)
+        perm, first = _solve_order(sites, n_act, su.touched, nb_max, geo.dev) if use_ata else (None, 0)
         X, stats = K.eq_qp_solve_batched(Gs, float(l2_regularization), None, As, bs, schur_reg=1e-12, n_refine=3,
-                                         AtA=AtAs if use_ata else None)
+                                         AtA=AtAs if use_ata else None, perm=perm, a_first_col=first)
         st_all = stats.cpu().numpy()
         X_host = X[:, 0, :].cpu().numpy()
         for j, site in enumerate(sites):
@@ -528,6 +555,7 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
     S = int(n_constraint_frames)
     per_batch = _sites_per_batch(n_cg, n_max, S * n_cg, dev)
     batches = _solve_batches(n_act, per_batch) if per_batch > 1 else [[i] for i in range(n_cg)]
+    orders = [_solve_order(b, n_act, su.touched, max(n_act[i] for i in b), dev) for b in batches]
     scores: List[List[Optional[float]]] = []
     for l2 in l2_values:
         row: List[Optional[float]] = []
@@ -538,7 +566,7 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
             sel = torch.as_tensor(flat, device=dev)
             Pg_sel, cg_sel = geo.Pg[sel].contiguous(), geo.cg[sel].contiguous()
             total_q, ok = 0.0, True
-            for sites in batches:
+            for sites, (perm, first) in zip(batches, orders):
                 nb_max = max(n_act[i] for i in sites)
                 Gs = torch.zeros((len(sites), nb_max, nb_max), dtype=torch.float64, device=dev)
                 As = torch.empty((len(sites), S * n_cg, nb_max), dtype=torch.float64, device=dev)
@@ -558,7 +586,8 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
                     K.gb_constraint_rows(su.Mg, gauss, S, n_id, n_ch, n_basis, site, out_A=As[j], out_b=bs[j],
                                          cols=cols_dev[site])
                     K.gb_constraint_gram(su.M2, gauss, S, n_id, n_ch, n_basis, AtAs[j], cols=cols_dev[site])
-                X, stats = K.eq_qp_solve_batched(Gs, float(l2), None, As, bs, schur_reg=1e-12, n_refine=3, AtA=AtAs)
+                X, stats = K.eq_qp_solve_batched(Gs, float(l2), None, As, bs, schur_reg=1e-12, n_refine=3, AtA=AtAs,
+                                                 perm=perm, a_first_col=first)
                 st_all = stats.cpu().numpy()
                 bad = [(sites[j], st_all[j]) for j in range(len(sites))
                        if st_all[j][0] != 0 or not np.isfinite(st_all[j][1])]

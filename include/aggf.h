@@ -150,11 +150,17 @@ int aggf_eq_qp_solve_batched(const double* G, int32_t n, double l2, const double
 
 /* aggf_eq_qp_solve_batched with the positive shift A'A of every problem formed by the CALLER (AtA: n x n per
  * problem, lower triangle read) -- for constraint rows whose structure makes it cheap (aggf_gb_constraint_gram:
- * S multiply-adds per entry instead of m = S*n_cg).  Same workspace, same results up to the rounding of A'A. */
+ * S multiply-adds per entry instead of m = S*n_cg).  Same workspace, same results up to the rounding of A'A.
+ * perm (n int32 per problem, or NULL): the factorisation takes the variables in the order perm[0], perm[1], ...
+ * (G, l2_diag, A, AtA and X stay in the caller's order).  a_first_col (needs perm; 0 = unknown): in that order the
+ * columns of A before a_first_col are zero in EVERY problem -- sparse constraint rows with the variables they touch
+ * moved to the end; the forward solve L^-1 A', the Schur complement and the products with A then start at the 256-row
+ * block that holds a_first_col (the fused featurised fit with a slice coordinate map: 576 of ~2100-3000 rows). */
 int aggf_eq_qp_solve_batched_shift(const double* G, int32_t n, double l2, const double* l2_diag,
-                                   const double* A, const double* AtA, int32_t m, const double* B, int32_t nrhs,
-                                   double schur_reg, int32_t n_refine, int32_t n_problems, double* X,
-                                   double* stats, void* ws, size_t ws_bytes, void* stream);
+                                   const double* A, const double* AtA, const int32_t* perm, int32_t a_first_col,
+                                   int32_t m, const double* B, int32_t nrhs, double schur_reg, int32_t n_refine,
+                                   int32_t n_problems, double* X, double* stats, void* ws, size_t ws_bytes,
+                                   void* stream);
 
 /* The same problem when every row of A is a unit vector with the 1 at pin_idx[i] (all distinct) and B is the
  * identity -- the constraint rows of a slice coordinate map, `coord_map.standard_matrix @ con_mat` of

@@ -222,6 +222,32 @@ def test_gb_constraint_gram_matches_the_product_of_the_rows(gdt):
     assert rel(X1.cpu().numpy(), X0.cpu().numpy()) < 1e-10
     with pytest.raises(ValueError):
         K.eq_qp_solve_batched(Gs, 0.5, None, As, bs, AtA=AtA[:, :-1])
+    # sparse constraint rows: the variables they touch taken last, the forward solve restricted to the rows below
+    p, n, m, nt = 3, 700, 40, 150
+    R = rng.standard_normal((p, 900, n))
+    Gs = torch.from_numpy(np.einsum("ptn,ptm->pnm", R, R)).cuda()
+    A_h = np.zeros((p, m, n))
+    perm_h = np.empty((p, n), dtype=np.int32)
+    for q in range(p):
+        t = np.sort(rng.choice(n, size=nt - 7 * q, replace=False))  # a different number per problem
+        A_h[q][:, t] = rng.standard_normal((m, len(t)))
+        mask = np.zeros(n, dtype=bool)
+        mask[t] = True
+        perm_h[q] = np.concatenate([np.nonzero(~mask)[0], np.nonzero(mask)[0]])
+    As = torch.from_numpy(A_h).cuda()
+    bs = torch.from_numpy(rng.standard_normal((p, m, 2))).cuda()
+    AtA = torch.tril(As.transpose(1, 2) @ As).contiguous()
+    X0, st0 = K.eq_qp_solve_batched(Gs, 0.3, None, As, bs, schur_reg=1e-12, n_refine=2, AtA=AtA)
+    perm = torch.from_numpy(perm_h).cuda()
+    for first in (0, n - nt, 300):  # 0: permutation only; n - nt: blocks 0..1 skipped; 300: block 0 skipped
+        X1, st1 = K.eq_qp_solve_batched(Gs, 0.3, None, As, bs, schur_reg=1e-12, n_refine=2, AtA=AtA, perm=perm,
+                                        a_first_col=first)
+        assert float(st1[:, 0].abs().max()) == 0.0 and float(st1[:, 1].max()) < 1e-10
+        assert rel(X1.cpu().numpy(), X0.cpu().numpy()) < 1e-9, first
+    with pytest.raises(ValueError):
+        K.eq_qp_solve_batched(Gs, 0.3, None, As, bs, perm=perm)  # needs AtA
+    with pytest.raises(ValueError):
+        K.eq_qp_solve_batched(Gs, 0.3, None, As, bs, AtA=AtA, perm=perm[:, :-1].contiguous())
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
