@@ -236,6 +236,13 @@ __global__ __launch_bounds__(256) void gb_regmat_cols_kernel(const TF* __restric
 // CLAMap application of the [id | gb] feature-linear map (featlinearmap.py:512-520,
 // map/core.py:428-430): out[t,c,:] = sum_f coef[c,f] * (feat_c[t]' F[t] + div_c[t])[f,:]
 // -- the divergence enters WITHOUT kbt, exactly as in the reference's trans_f.
+// One wave per (block of GB_FR frames, site); lanes stride over id columns and channels.  A lane's coefficients of a
+// channel are read ONCE for the GB_FR frames (per frame they were 43 KB of L1/L2 reads per (frame, site) at BASELINE
+// config 4 -- 55 GB per application, the kernel's bound: 16 ms), and a channel none of whose columns the fit kept
+// costs neither the distance nor the expf.  Per frame the terms are added in the same order as one frame at a time.
+constexpr int GB_FR = 4;
+constexpr int GB_CB = 8;  // coefficients of a channel held in registers (basis functions beyond: read in the loop)
+
 template <typename TF, typename TG>
 __global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg, const TG* __restrict__ Pg,
                                                        const TG* __restrict__ cg, int64_t T, int32_t G,
@@ -244,48 +251,88 @@ __global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg
                                                        const double* __restrict__ coef, int32_t n_feat,
                                                        double* __restrict__ out) {
   typedef typename GbProd<TF, TG>::type TP;
-  // one wave per (frame, site); lanes stride over id columns and channels
   const int lane = threadIdx.x & 63;
   const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
   const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
-  for (int64_t i = wid; i < T * n_cg; i += nw) {
-    const int64_t t = i / n_cg;
-    const int site = (int)(i - t * n_cg);
+  const int64_t n_blk = (T + GB_FR - 1) / GB_FR;
+  for (int64_t i = wid; i < n_blk * n_cg; i += nw) {
+    const int64_t blk = i / n_cg;  // consecutive waves: the same frames, the sites one after the other
+    const int site = (int)(i - blk * n_cg);
+    const int64_t t0 = blk * GB_FR;
+    const int nf = T - t0 < GB_FR ? (int)(T - t0) : GB_FR;
     const double* cf = coef + (int64_t)site * n_feat;
-    double a0 = 0, a1 = 0, a2 = 0;
+    double acc[GB_FR][3];
+#pragma unroll
+    for (int f = 0; f < GB_FR; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.0;
     for (int g = lane; g < n_id; g += 64) {
-      const TF* f = Fg + (t * G + g) * 3;
       const double c = cf[g];
-      a0 += c * (double)f[0];
-      a1 += c * (double)f[1];
-      a2 += c * (double)f[2];
-    }
-    for (int ch = lane; ch < n_ch; ch += 64) {
-      TG r, u[3];
-      gb_geometry(Pg, cg, t, G, ch, n_cg, site, r, u);
-      const TF* f = Fg + (t * G + ch) * 3;
-      const TG m = (TG)sizes[ch];
-      for (int k = 0; k < gp.n_basis; ++k) {
-        const double c = cf[n_id + ch * gp.n_basis + k];
-        if (c == 0.0) continue;  // columns the fit left out (identically zero over the training frames): no expf
-        TG g, dg;
-        gb_gauss(gp, r, k, g, dg);
-        const TG s = m * dg;
-        a0 += c * ((double)((TP)g * (TP)f[0]) + (double)(s * u[0]));
-        a1 += c * ((double)((TP)g * (TP)f[1]) + (double)(s * u[1]));
-        a2 += c * ((double)((TP)g * (TP)f[2]) + (double)(s * u[2]));
+#pragma unroll
+      for (int f = 0; f < GB_FR; ++f) {
+        if (f < nf) {
+          const TF* fv = Fg + ((t0 + f) * G + g) * 3;
+          acc[f][0] += c * (double)fv[0];
+          acc[f][1] += c * (double)fv[1];
+          acc[f][2] += c * (double)fv[2];
+        }
       }
     }
+    for (int ch = lane; ch < n_ch; ch += 64) {
+      const double* cc = cf + n_id + (int64_t)ch * gp.n_basis;
+      double cb[GB_CB];  // the loads are issued together: one memory latency per channel, not one per basis function
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      a0 += __shfl_down(a0, off, 64);
-      a1 += __shfl_down(a1, off, 64);
-      a2 += __shfl_down(a2, off, 64);
+      for (int k = 0; k < GB_CB; ++k) cb[k] = k < gp.n_basis ? cc[k] : 0.0;
+      bool any = false;
+#pragma unroll
+      for (int k = 0; k < GB_CB; ++k) any |= cb[k] != 0.0;
+      for (int k = GB_CB; k < gp.n_basis; ++k) any |= cc[k] != 0.0;
+      if (!any) continue;  // no column of this channel was kept by the fit (identically zero over the training frames)
+      TG r[GB_FR], u[GB_FR][3];
+      TP fr[GB_FR][3];
+#pragma unroll
+      for (int f = 0; f < GB_FR; ++f) {
+        if (f < nf) {
+          gb_geometry(Pg, cg, t0 + f, G, ch, n_cg, site, r[f], u[f]);
+          const TF* fv = Fg + ((t0 + f) * G + ch) * 3;
+          fr[f][0] = (TP)fv[0];
+          fr[f][1] = (TP)fv[1];
+          fr[f][2] = (TP)fv[2];
+        }
+      }
+      const TG m = (TG)sizes[ch];
+      auto add_basis = [&](int k, double c) {
+        if (c == 0.0) return;  // a column the fit left out: no expf
+#pragma unroll
+        for (int f = 0; f < GB_FR; ++f) {
+          if (f < nf) {
+            TG g, dg;
+            gb_gauss(gp, r[f], k, g, dg);
+            const TG s = m * dg;
+            acc[f][0] += c * ((double)((TP)g * fr[f][0]) + (double)(s * u[f][0]));
+            acc[f][1] += c * ((double)((TP)g * fr[f][1]) + (double)(s * u[f][1]));
+            acc[f][2] += c * ((double)((TP)g * fr[f][2]) + (double)(s * u[f][2]));
+          }
+        }
+      };
+#pragma unroll
+      for (int k = 0; k < GB_CB; ++k)
+        if (k < gp.n_basis) add_basis(k, cb[k]);
+      for (int k = GB_CB; k < gp.n_basis; ++k) add_basis(k, cc[k]);
     }
-    if (lane == 0) {
-      out[i * 3 + 0] = a0;
-      out[i * 3 + 1] = a1;
-      out[i * 3 + 2] = a2;
+#pragma unroll
+    for (int f = 0; f < GB_FR; ++f) {
+      double a0 = acc[f][0], a1 = acc[f][1], a2 = acc[f][2];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off, 64);
+        a1 += __shfl_down(a1, off, 64);
+        a2 += __shfl_down(a2, off, 64);
+      }
+      if (lane == 0 && f < nf) {
+        double* o = out + ((t0 + f) * n_cg + site) * 3;
+        o[0] = a0;
+        o[1] = a1;
+        o[2] = a2;
+      }
     }
   }
 }
@@ -403,7 +450,7 @@ extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const void* Pg, const 
     return fail(AGGF_ERR_ARG, "aggf_gb_apply: bad shape");
   int rc = check_gb(centers, n_basis, width);
   if (rc) return rc;
-  const dim3 grid = feat_grid(T * n_cg * 64);
+  const dim3 grid = feat_grid(((T + GB_FR - 1) / GB_FR) * n_cg * 64);
   const int out_dtype = AGGF_F64;
   AGGF_GB_DISPATCH("aggf_gb_apply",
                    hipLaunchKernelGGL((gb_apply_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
