@@ -377,6 +377,11 @@ def fit_id_gb(
     per_batch = _sites_per_batch(n_cg, n_max, m_rows, geo.dev) if len(n_sel) == 1 else 1
     per_batch = agree_on_min(per_batch, comm, geo.dev)  # shapes and count of the collectives below depend on it
     shared_lead = None  # leading (id x id) Gram block, identical for all sites
+    # every site's kept-column list in ONE upload (a pageable copy inside the site loop waits for its stream to drain:
+    # 64 host stalls per fit)
+    col_off = np.concatenate([[0], np.cumsum([len(c) for c in cols_of])]).astype(np.int64)
+    cols_all = torch.from_numpy(np.concatenate(cols_of) if n_ch else np.zeros(0, dtype=np.int32)).to(geo.dev)
+    cols_dev = [cols_all[int(col_off[i]):int(col_off[i + 1])] for i in range(n_cg)]
     batches = (_solve_batches(n_act, per_batch, int(os.environ.get("AGGF_FEAT_BATCH_MIN", _BATCH_MIN_SITES)),
                               float(os.environ.get("AGGF_FEAT_BATCH_RATIO", _BATCH_SIZE_RATIO)))
                if per_batch > 1 else [[i] for i in range(n_cg)])
@@ -397,7 +402,7 @@ def fit_id_gb(
         for j, site in enumerate(sites):
           with torch.cuda.stream(streams[j % n_str]):
             R3 = R3s[j % n_str]
-            cols = torch.from_numpy(cols_of[site]).to(geo.dev)
+            cols = cols_dev[site]
             na = n_act[site]
             K.gb_regmat_cols(Fg, geo.Pg, geo.cg, site, geo.sizes, n_id, cols, centers, width, CLIP, kbt, R3)
             # float64 products: with float32 products the Gram's rounding noise (~1e-7 of its largest entry)
