@@ -197,7 +197,8 @@ def _score_folds(grid, fold_grams, counts, prob, kwargs) -> Dict[str, Dict[Any, 
 
 
 _NOISED_REUSE_FIXED_ARGS: Final = frozenset(
-    {"coord_map", "constrained_inds", "method", "var", "kbt", "seed", "l2_regularization", "solver_args", "gram_dtype"}
+    {"coord_map", "constrained_inds", "method", "var", "kbt", "seed", "l2_regularization", "solver_args", "gram_dtype",
+     "comm"}
 )
 
 
@@ -296,15 +297,24 @@ def project_forces_grid_cv(
     if reuse_gram and _noised_reuse_applicable(list(cv_arg_dict.keys()), kwargs):
         from .qp.gauss import cv_joptgauss_fold_grams
 
+        from .distributed import agree_on_min
+
         f_dev, c_dev = K.as_device(forces), K.as_device(coords)
+        comm = kwargs.get("comm")
         made = None
-        if not K.has_nan(f_dev) and not K.has_nan(c_dev):
+        clean = not K.has_nan(f_dev) and not K.has_nan(c_dev)
+        if agree_on_min(int(clean), comm, f_dev.device):  # (a NaN on any rank sends every rank to the loop)
             made = cv_joptgauss_fold_grams(c_dev, f_dev, kwargs["coord_map"], kwargs["var"], kwargs["kbt"],
                                            kwargs.get("constrained_inds"), kwargs.get("seed"), folds,
-                                           kwargs.get("gram_dtype"), noise=cv_noise)
-        del f_dev, c_dev
+                                           kwargs.get("gram_dtype"), noise=cv_noise, comm=comm)
         if made is not None:
-            return _score_folds(grid, made[0], [float(len(f)) for f in folds], made[1], kwargs)
+            import torch
+
+            counts = torch.tensor([float(len(f)) for f in folds], dtype=torch.float64, device=f_dev.device)
+            all_reduce_sum_(counts, comm)
+            del f_dev, c_dev
+            return _score_folds(grid, made[0], counts.tolist(), made[1], kwargs)
+        del f_dev, c_dev
     feat_cv = _feat_reuse(grid, list(cv_arg_dict.keys()), kwargs) if reuse_gram else None
     if feat_cv is not None and not K.has_nan(K.as_device(forces)) and not K.has_nan(K.as_device(coords)):
         done = _grid_cv_feat_reuse(feat_cv, grid, coords, forces, folds, kwargs, method_rng)

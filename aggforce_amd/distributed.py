@@ -33,6 +33,15 @@ def world_size(comm) -> int:
     return dist.get_world_size(group)
 
 
+def rank_of(comm) -> int:
+    group = resolve_comm(comm)
+    if group is None:
+        return 0
+    import torch.distributed as dist
+
+    return dist.get_rank(group)
+
+
 def all_reduce_sum_(t: torch.Tensor, comm) -> torch.Tensor:
     """In-place sum over the ranks of ``comm`` (no-op without a communicator)."""
     group = resolve_comm(comm)

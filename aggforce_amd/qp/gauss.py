@@ -109,25 +109,32 @@ def _joptgauss_without_extended_arrays(traj, augmenter, kbt, constraints, kwargs
 
 
 def cv_joptgauss_fold_grams(coords, forces, coord_map: LinearMap, var: float, kbt: float, constraints, seed, folds,
-                            gram_dtype=None, noise=None):
+                            gram_dtype=None, noise=None, comm=None):
     """Per-fold Gram matrices of joptgauss_map's extended system for ``project_forces_grid_cv``'s one-pass form, or
     None when the layout does not allow the in-place fit (see ``_joptgauss_without_extended_arrays``).
 
     ONE noise realisation is drawn for every frame (the reference's loop draws afresh for every fit and every
     application: the same distribution, and here every grid point and fold sees common random numbers), fold by
     fold on the gathered frames of the fold, and fold k's matrix is ``Tm' Gram([F | Fa] on fold k) Tm`` with the
-    constraint groups summed -- exactly the matrix a fit on those frames alone would form.  Returns (fold_grams
-    (k, n, n), LinearProblem of the extended system)."""
+    constraint groups summed -- exactly the matrix a fit on those frames alone would form.  ``comm``: the frames are
+    sharded over ranks and every rank splits ITS frames into the folds (global fold k = the union of the ranks' fold
+    k, as in the linear one-pass form); the matrices are all-reduced, each rank draws its own noise (seed offset by
+    the rank).  Returns (fold_grams (k, n, n), LinearProblem of the extended system)."""
     import torch
 
+    from ..distributed import agree_on_min, all_reduce_sum_sym_, rank_of
     from .qplinear import LinearProblem
 
     f_dev, c_dev = K.as_device(forces), K.as_device(coords)
     n_real, n_aug = f_dev.shape[1], coord_map.n_cg_sites
+    if seed is not None and comm is not None:
+        seed = int(seed) + 7919 * rank_of(comm)
     augmenter = CondNormal(var=var, premap=coord_map, seed=seed)
-    if (f_dev.shape[0] == 0 or n_real % 128 or n_aug % 128
-            or (gram_dtype is not None and K.torch_dtype(gram_dtype) != f_dev.dtype)
-            or torch.promote_types(c_dev.dtype, K.torch_dtype(augmenter.dtype)) != f_dev.dtype):
+    ok = not (f_dev.shape[0] == 0 or n_real % 128 or n_aug % 128
+              or (gram_dtype is not None and K.torch_dtype(gram_dtype) != f_dev.dtype)
+              or torch.promote_types(c_dev.dtype, K.torch_dtype(augmenter.dtype)) != f_dev.dtype
+              or not f_dev.is_contiguous() or any(len(idx) == 0 for idx in folds))
+    if not agree_on_min(int(ok), comm, f_dev.device):  # every rank takes the same path
         return None
     aug_cmap = LinearMap(mapping=[[i] for i in range(n_real, n_real + n_aug)], n_fg_sites=n_real + n_aug)
     prob = LinearProblem(aug_cmap, constraints, f_dev.device)
@@ -139,14 +146,15 @@ def cv_joptgauss_fold_grams(coords, forces, coord_map: LinearMap, var: float, kb
             augmenter.inject_noise(np.asarray(noise)[np.asarray(idx)])
         y, fak, cols = augmenter.noise_sites(ck, kbt)  # (every call advances the augmenter's stream: independent draws)
         del y, ck
-        if not K.gram_pair_ok(fk, fak):
-            return None
+        assert K.gram_pair_ok(fk, fak)  # (implied by the layout test above)
         G = K.augmented_gram(K.gram_pair(fk, fak), n_real, cols)
         if prob.grp_ptr is not None:
             G = K.sym_group_reduce(G, prob.grp_ptr, prob.grp_atoms, prob.n_red)
         grams.append(G)
         del fk, fak
-    return torch.stack(grams), prob
+    out = torch.stack(grams)
+    all_reduce_sum_sym_(out, comm)
+    return out, prob
 
 
 # ---- staged maps: deterministic linear pre-map, then a noising step --------------------------

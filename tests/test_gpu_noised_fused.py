@@ -190,3 +190,59 @@ def test_noised_grid_cv_one_pass(name):
     for key in loop["scores"]:
         assert loop["n_runs"][key] == 4
         assert abs(fast["scores"][key] - loop["scores"][key]) < 0.05 * abs(loop["scores"][key]), key
+
+
+def _noised_cv_rank_worker(rank, world, port, out_dir):
+    """Two processes on one GPU (gloo): each rank holds half of the frames, splits them into folds locally and draws
+    the noise of ITS frames; global fold k is the union of the ranks' fold k."""
+    import os
+    import sys
+
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aggforce_amd import LinearMap as LM
+    from aggforce_amd import joptgauss_map as jm
+    from aggforce_amd.agg import project_forces_grid_cv as cv
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    coords, forces, cmat, cons, _, eps, _ = case("dense_f64_constraints")
+    half = slice(rank * 450, (rank + 1) * 450)
+    res = cv({"l2_regularization": [0.0, 2.0]}, coords[half], forces[half], n_folds=3, rng=np.random.default_rng(50 + rank),
+             cv_noise=eps[0][half], coord_map=LM(cmat), constrained_inds=cons, method=jm, var=VAR, kbt=KBT, comm=True)
+    out = [(res["scores"][k], res["sds"][k], res["n_runs"][k]) for k in res["scores"]]
+    np.save(os.path.join(out_dir, f"ncv{rank}.npy"), np.array(out, dtype=np.float64))
+    dist.destroy_process_group()
+
+
+def test_noised_grid_cv_two_ranks_match_one_process_on_union_folds(tmp_path):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    from aggforce_amd import agg
+    from aggforce_amd.agg import mean, process_cvargs, sample_sd
+    from aggforce_amd.qp.gauss import cv_joptgauss_fold_grams
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_noised_cv_rank_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "ncv0.npy"), np.load(tmp_path / "ncv1.npy")
+    assert np.array_equal(r0, r1)  # both ranks hold the same all-reduced matrices and solve the same problems
+    coords, forces, cmat, cons, _, eps, _ = case("dense_f64_constraints")
+    local = []
+    for rank in range(2):
+        fr = np.arange(450)
+        np.random.default_rng(50 + rank).shuffle(fr)
+        local.append([f + 450 * rank for f in np.array_split(fr, 3)])
+    folds = [np.concatenate([local[0][k], local[1][k]]) for k in range(3)]
+    grams, prob = cv_joptgauss_fold_grams(coords, forces, LinearMap(cmat), VAR, KBT, cons, None, folds, noise=eps[0])
+    grid = process_cvargs({"l2_regularization": [0.0, 2.0]})
+    one = agg._score_folds(grid, grams, [float(len(f)) for f in folds], prob, {})
+    for row, (label, _) in zip(r0, grid):
+        assert row[2] == one["n_runs"][label] == 3
+        assert abs(row[0] - one["scores"][label]) < 1e-7 * abs(one["scores"][label])
+        assert abs(row[1] - one["sds"][label]) < 1e-5 * abs(one["sds"][label])
+    assert mean([1.0, 3.0]) == 2.0 and sample_sd([1.0, 3.0]) > 0  # (the helpers the rows were built with)

@@ -280,7 +280,7 @@ def test_grid_cv_noised_reuse_applicability():
     assert not _noised_reuse_applicable(["var"], base)
     assert not _noised_reuse_applicable(["l2_regularization"], dict(base, constrained_inds="auto"))
     assert not _noised_reuse_applicable(["l2_regularization"], dict(base, method=stagedjoptgauss_map))
-    assert not _noised_reuse_applicable(["l2_regularization"], dict(base, comm=object()))
+    assert _noised_reuse_applicable(["l2_regularization"], dict(base, comm=object()))  # per-rank folds, all-reduced
     assert not _noised_reuse_applicable(["l2_regularization"], dict(base, noise=[None]))
     del base["var"]
     assert not _noised_reuse_applicable(["l2_regularization"], base)
