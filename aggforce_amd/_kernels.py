@@ -758,6 +758,36 @@ def gb_apply(Fg, Pg, cg, sizes, n_id: int, n_ch: int, centers, width: float, cli
     return out
 
 
+def gb_compact_coefficients(coef: np.ndarray, n_id: int, device):
+    """(coef_id (n_cg, n_id), col_ptr, col_idx, col_val) on the device for :func:`gb_apply_cols`: the non-zero
+    Gaussian coefficients of every site as compressed rows."""
+    coef = np.asarray(coef, dtype=np.float64)
+    gauss = coef[:, n_id:]
+    rows, cols = np.nonzero(gauss)
+    ptr_h = np.zeros(coef.shape[0] + 1, dtype=np.int32)
+    np.cumsum(np.bincount(rows, minlength=coef.shape[0]), out=ptr_h[1:])
+    to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(device)
+    return (to(coef[:, :n_id]) if n_id else None, to(ptr_h), to(cols.astype(np.int32)), to(gauss[rows, cols]))
+
+
+def gb_apply_cols(Fg, Pg, cg, sizes, n_id: int, centers, width: float, clip: float, compact):
+    """gb_apply from the compact coefficient list of :func:`gb_compact_coefficients`; see aggf_gb_apply_cols."""
+    coef_id, col_ptr, col_idx, col_val = compact
+    T, G, _ = Fg.shape
+    n_cg = cg.shape[1]
+    out = torch.empty((T, n_cg, 3), dtype=torch.float64, device=Fg.device)
+    if T == 0:
+        return out
+    with _timed("gb_apply"):
+        check(
+            lib().aggf_gb_apply_cols(ptr(Fg), dtype_code(Fg.dtype), ptr(Pg), ptr(cg), _gb_dtype(Pg, cg, centers), T, G,
+                                     n_cg, ptr(sizes), n_id, ptr(coef_id), ptr(col_ptr), ptr(col_idx), ptr(col_val),
+                                     ptr(centers), centers.numel(), float(width), float(clip), ptr(out), stream_ptr()),
+            "aggf_gb_apply_cols",
+        )
+    return out
+
+
 # ------------------------------------------------------------------ K3c / K4b / K4c per-frame contractions
 
 

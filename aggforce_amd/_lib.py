@@ -61,6 +61,7 @@ PROTOTYPES = {
     "aggf_group_reduce": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _vp, _i32, C.c_int, C.c_int, _vp, _vp]),
     "aggf_gb_channels": (C.c_int, [_vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _i32, _vp, _i32, _dbl, _dbl, _vp, _vp, _vp]),
     "aggf_gb_regmat": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _dbl, _i32, _vp, C.c_int, _vp]),
+    "aggf_gb_apply_cols": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _i32, _dbl, _dbl, _vp, _vp]),
     "aggf_gb_apply": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _i64, _i32, _i32, _vp, _i32, _i32, _vp, _i32, _dbl, _dbl, _vp, _i32, _vp, _vp]),
     "aggf_trjdot_frames": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _i32, _i32, _vp, _vp, C.c_int, _vp]),
     "aggf_feat_contract": (C.c_int, [_vp, C.c_int, _vp, _vp, C.c_int, _dbl, _i64, _i32, _i32, _i32, _vp, C.c_int, _vp]),

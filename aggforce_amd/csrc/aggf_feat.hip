@@ -67,6 +67,10 @@ template <typename TG>
 __device__ __forceinline__ void gb_geometry(const TG* __restrict__ Pg, const TG* __restrict__ cg,
                                             int64_t t, int32_t G, int32_t ch, int32_t n_cg, int32_t site,
                                             TG& r, TG u[3]) {
+  // no fused multiply-add here: whether dx*dx + dy*dy + dz*dz contracts is otherwise decided per kernel the function is
+  // inlined into, and the kernels that evaluate a feature (regression matrix, constraint rows, the two application
+  // kernels) must agree on it to the last bit -- as the reference's NumPy/JAX float32 arithmetic does
+#pragma clang fp contract(off)
   const TG* p = Pg + (t * G + ch) * 3;
   const TG* c = cg + (t * n_cg + site) * 3;
   const TG dx = p[0] - c[0], dy = p[1] - c[1], dz = p[2] - c[2];
@@ -78,6 +82,7 @@ __device__ __forceinline__ void gb_geometry(const TG* __restrict__ Pg, const TG*
 
 template <typename TG>
 __device__ __forceinline__ void gb_gauss(const GbParams<TG>& gp, TG r, int k, TG& g, TG& dg) {
+#pragma clang fp contract(off)
   const TG arg = (r - gp.centers[k]) / gp.width;
   const TG raw = gb_exp(-(arg * arg));
   g = gb_max(raw, gp.clip) - gp.clip;
@@ -337,6 +342,84 @@ __global__ __launch_bounds__(256) void gb_apply_kernel(const TF* __restrict__ Fg
   }
 }
 
+// The same map from a COMPACT coefficient list: the fit keeps ~a third of the Gaussian columns (2.1 of 8 basis
+// functions per channel at BASELINE config 4) and different ones for every channel, so in gb_apply_kernel -- lane =
+// channel -- nearly every basis function is executed by the wave for the few lanes that need it.  Here lane = one kept
+// column (ch, k) of the site: no idle lanes; the distance of a channel is recomputed for each of its kept columns
+// (cheaper than the expf it replaces).  col_ptr[n_cg + 1] / col_idx (ch * n_basis + k) / col_val: the non-zero
+// Gaussian coefficients per site; coef_id (n_cg, n_id): the id block, dense.
+template <typename TF, typename TG>
+__global__ __launch_bounds__(256) void gb_apply_cols_kernel(const TF* __restrict__ Fg, const TG* __restrict__ Pg,
+                                                            const TG* __restrict__ cg, int64_t T, int32_t G,
+                                                            int32_t n_cg, const float* __restrict__ sizes,
+                                                            int32_t n_id, const double* __restrict__ coef_id,
+                                                            const int32_t* __restrict__ col_ptr,
+                                                            const int32_t* __restrict__ col_idx,
+                                                            const double* __restrict__ col_val, GbParams<TG> gp,
+                                                            double* __restrict__ out) {
+  typedef typename GbProd<TF, TG>::type TP;
+  const int lane = threadIdx.x & 63;
+  const int64_t wid = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+  const int64_t nw = ((int64_t)gridDim.x * blockDim.x) >> 6;
+  const int64_t n_blk = (T + GB_FR - 1) / GB_FR;
+  for (int64_t i = wid; i < n_blk * n_cg; i += nw) {
+    const int64_t blk = i / n_cg;
+    const int site = (int)(i - blk * n_cg);
+    const int64_t t0 = blk * GB_FR;
+    const int nf = T - t0 < GB_FR ? (int)(T - t0) : GB_FR;
+    double acc[GB_FR][3];
+#pragma unroll
+    for (int f = 0; f < GB_FR; ++f) acc[f][0] = acc[f][1] = acc[f][2] = 0.0;
+    for (int g = lane; g < n_id; g += 64) {
+      const double c = coef_id[(int64_t)site * n_id + g];
+#pragma unroll
+      for (int f = 0; f < GB_FR; ++f) {
+        if (f < nf) {
+          const TF* fv = Fg + ((t0 + f) * G + g) * 3;
+          acc[f][0] += c * (double)fv[0];
+          acc[f][1] += c * (double)fv[1];
+          acc[f][2] += c * (double)fv[2];
+        }
+      }
+    }
+    for (int e = col_ptr[site] + lane; e < col_ptr[site + 1]; e += 64) {
+      const int full = col_idx[e];
+      const int ch = full / gp.n_basis, k = full - ch * gp.n_basis;
+      const double c = col_val[e];
+      const TG m = (TG)sizes[ch];
+#pragma unroll
+      for (int f = 0; f < GB_FR; ++f) {
+        if (f < nf) {
+          TG r, u[3], g, dg;
+          gb_geometry(Pg, cg, t0 + f, G, ch, n_cg, site, r, u);
+          gb_gauss(gp, r, k, g, dg);
+          const TF* fv = Fg + ((t0 + f) * G + ch) * 3;
+          const TG sd = m * dg;
+          acc[f][0] += c * ((double)((TP)g * (TP)fv[0]) + (double)(sd * u[0]));
+          acc[f][1] += c * ((double)((TP)g * (TP)fv[1]) + (double)(sd * u[1]));
+          acc[f][2] += c * ((double)((TP)g * (TP)fv[2]) + (double)(sd * u[2]));
+        }
+      }
+    }
+#pragma unroll
+    for (int f = 0; f < GB_FR; ++f) {
+      double a0 = acc[f][0], a1 = acc[f][1], a2 = acc[f][2];
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        a0 += __shfl_down(a0, off, 64);
+        a1 += __shfl_down(a1, off, 64);
+        a2 += __shfl_down(a2, off, 64);
+      }
+      if (lane == 0 && f < nf) {
+        double* o = out + ((t0 + f) * n_cg + site) * 3;
+        o[0] = a0;
+        o[1] = a1;
+        o[2] = a2;
+      }
+    }
+  }
+}
+
 static inline dim3 feat_grid(int64_t n) {
   int64_t g = ceil_div(n, 256);
   if (g > 16384) g = 16384;
@@ -456,6 +539,27 @@ extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const void* Pg, const 
                    hipLaunchKernelGGL((gb_apply_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
                                       (const TG*)Pg, (const TG*)cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat,
                                       out));
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_gb_apply_cols(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
+                                  int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, const double* coef_id,
+                                  const int32_t* col_ptr, const int32_t* col_idx, const double* col_val,
+                                  const void* centers, int32_t n_basis, double width, double clip, double* out,
+                                  void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!Fg || !Pg || !cg || !sizes || !col_ptr || !out || (n_id > 0 && !coef_id))
+    return fail(AGGF_ERR_ARG, "aggf_gb_apply_cols: NULL pointer");
+  if (T <= 0 || G <= 0 || n_cg <= 0 || n_id < 0 || n_id > G) return fail(AGGF_ERR_ARG, "aggf_gb_apply_cols: bad shape");
+  int rc = check_gb(centers, n_basis, width);
+  if (rc) return rc;
+  const dim3 grid = feat_grid(((T + GB_FR - 1) / GB_FR) * n_cg * 64);
+  const int out_dtype = AGGF_F64;
+  AGGF_GB_DISPATCH("aggf_gb_apply_cols",
+                   hipLaunchKernelGGL((gb_apply_cols_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                                      (const TG*)Pg, (const TG*)cg, T, G, n_cg, sizes, n_id, coef_id, col_ptr, col_idx,
+                                      col_val, gp, out));
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

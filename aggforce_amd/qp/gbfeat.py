@@ -465,12 +465,30 @@ def fit_id_gb(
     fit_info = {"kept_columns": n_act, "n_feat": n_feat, "sites_per_batch": per_batch,
                 "solve_batches": [(len(b), max(n_act[i] for i in b)) for b in batches],
                 "kept_gauss_columns": cols_of, "feature_dtype": str(fdt)}
-    coef_dev = torch.from_numpy(np.stack(coefs)).to(geo.dev)
+    coef_h = np.stack(coefs)
+    # the application reads the coefficients as a compact list per site when most Gaussian columns were left out of the
+    # fit (the cut-off basis: a lane per kept column instead of a lane per channel), as the dense matrix otherwise;
+    # the list is the fit's own kept-column list -- no search for the non-zeros
+    sparse = n_ch > 0 and sum(len(c) for c in cols_of) < 0.5 * n_cg * n_ch * n_basis
+    compact = {}
+
+    def compact_on(dev):
+        to = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)
+        ptr_h = np.concatenate([[0], np.cumsum([len(c) for c in cols_of])]).astype(np.int32)
+        vals = np.concatenate([coef_h[site, n_id + cols_of[site]] for site in range(n_cg)])
+        return (to(coef_h[:, :n_id]) if n_id else None, to(ptr_h), to(np.concatenate(cols_of)), to(vals))
 
     def apply_f(points, copoints):
         g2 = _Geometry(copoints, coord_map, constraints, drop_last, fdt)
-        out = K.gb_apply(g2.group_forces(points), g2.Pg, g2.cg, g2.sizes, n_id, n_ch, centers, width, CLIP,
-                         coef_dev.to(g2.dev))
+        key = str(g2.dev)
+        if key not in compact:
+            compact[key] = compact_on(g2.dev) if sparse else torch.from_numpy(coef_h).to(g2.dev)
+        if sparse:
+            out = K.gb_apply_cols(g2.group_forces(points), g2.Pg, g2.cg, g2.sizes, n_id, centers.to(g2.dev), width, CLIP,
+                                  compact[key])
+        else:
+            out = K.gb_apply(g2.group_forces(points), g2.Pg, g2.cg, g2.sizes, n_id, n_ch, centers.to(g2.dev), width, CLIP,
+                             compact[key])
         return K.like_input(out, points)
 
     from .featlinearmap import _feat_linear_mapping

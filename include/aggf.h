@@ -341,6 +341,15 @@ int aggf_gb_apply(const void* Fg, int f_dtype, const void* Pg, const void* cg, i
                   int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, int32_t n_ch,
                   const void* centers, int32_t n_basis, double width, double clip,
                   const double* coef, int32_t n_feat, double* out, void* stream);
+/* The same application from the NON-ZERO Gaussian coefficients only (a fit with a cut-off basis leaves most of them
+ * exactly zero, and different ones for every channel): site c owns entries col_ptr[c] .. col_ptr[c+1]-1 of
+ * col_idx (= ch*n_basis + k) / col_val; coef_id (n_cg, n_id) is the id block, dense (NULL if n_id == 0).
+ * One lane per kept column instead of one per channel: no idle lanes. */
+int aggf_gb_apply_cols(const void* Fg, int f_dtype, const void* Pg, const void* cg, int g_dtype, int64_t T,
+                       int32_t G, int32_t n_cg, const float* sizes, int32_t n_id, const double* coef_id,
+                       const int32_t* col_ptr, const int32_t* col_idx, const double* col_val,
+                       const void* centers, int32_t n_basis, double width, double clip, double* out,
+                       void* stream);
 
 /* ---------------------------------------------------------------------------
  * K3c  trjdot with a per-frame (3-D) factor.

@@ -296,3 +296,35 @@ def test_featurised_grid_cv_one_pass_matches_the_loop(with_id):
         assert abs(fast["sds"][key] - loop["sds"][key]) < 1e-3 * abs(loop["sds"][key]) + 1e-6 * abs(loop["scores"][key]), key
     vals = [loop["scores"][k] for k in loop["scores"]]
     assert len(set(np.round(vals, 6))) == 3  # the grid points really differ
+
+
+@pytest.mark.parametrize("fdt", [np.float32, np.float64])
+@pytest.mark.parametrize("n_id_on", [True, False])
+def test_gb_apply_from_compact_coefficients_matches_dense(fdt, n_id_on):
+    """aggf_gb_apply_cols (one lane per non-zero Gaussian coefficient) against aggf_gb_apply (one lane per channel,
+    zeros skipped) on the same coefficients: ragged frame count, sites with no Gaussian coefficient at all, more basis
+    functions than the dense kernel holds in registers."""
+    from aggforce_amd import _kernels as K
+    from aggforce_amd.qp.gbfeat import CLIP, _Geometry, gb_centers
+
+    rng = np.random.default_rng(77)
+    T, N, n_cg, nb = 203, 90, 6, 11
+    coords = (9 * rng.random((T, N, 3)) + 1).astype(np.float32)
+    forces = (20 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    cons = {frozenset([3 * i, 3 * i + 1]) for i in range(20)}
+    cmap = LinearMap([[7 * i, 7 * i + 3] for i in range(n_cg)], n_fg_sites=N)
+    geo = _Geometry(coords, cmap, cons, True, fdt)
+    Fg = geo.group_forces(forces)
+    n_id = geo.G if n_id_on else 0
+    n_ch = geo.n_ch
+    centers = torch.from_numpy(gb_centers(8.0, 0.0, nb, 0.5, fdt)).cuda()
+    coef = rng.standard_normal((n_cg, n_id + n_ch * nb)) * (rng.random((n_cg, n_id + n_ch * nb)) < 0.2)
+    coef[3, n_id:] = 0.0  # a site whose Gaussian block is empty
+    dense = K.gb_apply(Fg, geo.Pg, geo.cg, geo.sizes, n_id, n_ch, centers, 1.0, CLIP, torch.from_numpy(coef).cuda())
+    compact = K.gb_compact_coefficients(coef, n_id, geo.dev)
+    assert int(compact[1][-1]) == np.count_nonzero(coef[:, n_id:])
+    got = K.gb_apply_cols(Fg, geo.Pg, geo.cg, geo.sizes, n_id, centers, 1.0, CLIP, compact)
+    assert got.shape == (T, n_cg, 3)
+    # the two kernels form bit-identical terms (the feature helpers forbid fused multiply-add contraction, which would
+    # otherwise be the compiler's choice per kernel: 2e-7 apart in float32); what is left is the order of the float64 sums
+    assert rel(got.cpu().numpy(), dense.cpu().numpy()) < 1e-12
