@@ -83,10 +83,24 @@ class CondNormal(Augmenter):
         import torch
 
         tdt = K.torch_dtype(self.dtype)
+        # Inside one project_forces call (K.upload_cache) the fit and the application of a noised map ask for the mean
+        # of the SAME coordinates: the second pass over them (a strided gather, 1.8 ms at BASELINE config 5) is saved.
+        # The consumers only read the mean.
+        cache = K._cache_stack[-1] if K._cache_stack else None
+        anchor = self.premap._standard_matrix if self.premap is not None else None  # (M may be a fresh cast of it)
+        key = ("condnormal_mean", src.data_ptr(), tuple(src.shape), str(src.dtype), id(anchor), str(tdt))
+        if cache is not None:
+            hit = cache.get(key)
+            if hit is not None and hit[0] is src and hit[1] is anchor:
+                return hit[2]
         if self.premap is not None and self.premap._onehot_index() is not None:
             idx = torch.from_numpy(self.premap._onehot_index()).to(src.device)
-            return K.slice_gather(src, idx, tdt)
-        return K.linearmap_apply(src, m_dev)
+            mean = K.slice_gather(src, idx, tdt)
+        else:
+            mean = K.linearmap_apply(src, m_dev)
+        if cache is not None:
+            cache[key] = (src, anchor, mean)  # (the entry keeps both alive: the ids in the key cannot be reused)
+        return mean
 
     # ---- Augmenter interface ----------------------------------------------------------
     def augment_trajectory(self, coords, forces, kbt: float) -> Tuple:
