@@ -151,3 +151,52 @@ def test_random_pinned_solve_and_noised_fit_sweeps():
         assert rel(mapped.forces, orc.linearmap_apply(ff, o["force_map"])) < tol
         assert rel(mapped.coords, fc[:, N:, :]) < 1e-5
     print("noised-fit cases ok")
+
+
+def test_random_batched_solve_with_sparse_rows_sweep():
+    """aggf_eq_qp_solve_batched_shift on random batches: caller-formed A'A, a permutation that takes the variables the
+    (sparse) constraint rows touch last, and the restricted forward solve -- against the oracle's KKT solve, problem by
+    problem.  Sizes straddle the 64 / 256 block edges; redundant rows (rank-deficient A) as the featurised fit has them."""
+    import torch
+
+    from aggforce_amd import _kernels as K
+    from oracle import aggforce_oracle as orc
+
+    def rel(a, b):
+        a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+        return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
+
+    rng = np.random.default_rng(404)
+    worst = 0.0
+    for case in range(14):
+        p = int(rng.integers(1, 5))
+        n = int(rng.choice([130, 256, 300, 511, 513, 640, 900]))
+        nt = int(rng.integers(8, max(9, n // 3)))          # variables the rows may touch
+        m = int(rng.integers(2, 2 * nt))                   # more rows than touched variables: redundant rows
+        l2 = float(rng.choice([0.5, 3.0, 40.0]))
+        Gs, As, bs, perms = [], [], [], []
+        for q in range(p):
+            R = rng.standard_normal((n + 50, n)) * rng.uniform(0.5, 20, size=n)
+            Gs.append(R.T @ R)
+            t = np.sort(rng.choice(n, size=nt - int(rng.integers(0, 4)), replace=False))
+            A = np.zeros((m, n))
+            basis = rng.standard_normal((min(m, max(1, len(t) // 2)), len(t)))    # rank <= len(t) / 2
+            A[:, t] = rng.standard_normal((m, basis.shape[0])) @ basis
+            x_feas = rng.standard_normal(n)
+            As.append(A)
+            bs.append((A @ x_feas)[:, None])                                       # consistent right-hand side
+            mask = np.zeros(n, dtype=bool)
+            mask[t] = True
+            perms.append(np.concatenate([np.nonzero(~mask)[0], np.nonzero(mask)[0]]).astype(np.int32))
+        G_d, A_d, b_d = (torch.from_numpy(np.stack(x)).cuda() for x in (Gs, As, bs))
+        AtA = torch.tril(A_d.transpose(1, 2) @ A_d).contiguous()
+        perm = torch.from_numpy(np.stack(perms)).cuda()
+        X, st = K.eq_qp_solve_batched(G_d, l2, None, A_d, b_d, schur_reg=1e-12, n_refine=3, AtA=AtA, perm=perm,
+                                      a_first_col=n - nt)
+        st = st.cpu().numpy()
+        assert np.all(st[:, 0] == 0) and np.all(st[:, 1] < 1e-8), (case, st)
+        for q in range(p):
+            xo = orc.eq_qp_solve(Gs[q] + l2 * np.eye(n), None, As[q], bs[q])[:, 0]
+            worst = max(worst, rel(X[q, 0].cpu().numpy(), xo))
+    assert worst < 1e-7, worst
+    print(f"14 batched sparse-row solve cases ok (worst rel {worst:.1e})")
