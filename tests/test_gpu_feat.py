@@ -328,3 +328,38 @@ def test_gb_apply_from_compact_coefficients_matches_dense(fdt, n_id_on):
     # the two kernels form bit-identical terms (the feature helpers forbid fused multiply-add contraction, which would
     # otherwise be the compiler's choice per kernel: 2e-7 apart in float32); what is left is the order of the float64 sums
     assert rel(got.cpu().numpy(), dense.cpu().numpy()) < 1e-12
+
+
+def test_featurised_grid_cv_falls_back_to_the_loop_when_the_matrices_do_not_fit(monkeypatch):
+    """The one-pass form keeps (folds, n, n) per site for the whole grid; when that does not fit the device it declines
+    BEFORE drawing from the method's generator, and the loop -- fed by the untouched generator -- gives exactly what
+    reuse_gram=False gives."""
+    from aggforce_amd import agg
+    from aggforce_amd.qp import gbfeat
+
+    coords, forces, cons, cmat = system(T=120, seed=5)
+    cmap = LinearMap(cmat)
+    feat = Multifeaturize([id_feat, Curry(gb_feat, outer=8.0, inner=0.0, n_basis=4, width=1.0)])
+    grid = {"l2_regularization": [1.0, 10.0]}
+
+    def go(reuse):
+        return agg.project_forces_grid_cv(grid, coords, forces, n_folds=3, rng=np.random.default_rng(3), reuse_gram=reuse,
+                                          method_rng=np.random.default_rng(9), coord_map=cmap, constrained_inds=cons,
+                                          method=qp_feat_linear_map, featurizer=feat, kbt=KBT, n_constraint_frames=5)
+
+    declined = {"n": 0}
+    real = agg._grid_cv_feat_reuse
+
+    def watched(*a, **k):
+        out = real(*a, **k)
+        declined["n"] += out is None
+        return out
+
+    monkeypatch.setattr(agg, "_grid_cv_feat_reuse", watched)
+    monkeypatch.setattr(gbfeat.K, "device_memory", lambda dev=None: (1 << 16, 1 << 16))
+    tight = go(True)
+    assert declined["n"] == 1
+    monkeypatch.undo()
+    loop = go(False)
+    for key in loop["scores"]:
+        assert tight["scores"][key] == loop["scores"][key] and tight["n_runs"][key] == loop["n_runs"][key] == 3
