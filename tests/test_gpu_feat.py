@@ -363,3 +363,43 @@ def test_featurised_grid_cv_falls_back_to_the_loop_when_the_matrices_do_not_fit(
     loop = go(False)
     for key in loop["scores"]:
         assert tight["scores"][key] == loop["scores"][key] and tight["n_runs"][key] == loop["n_runs"][key] == 3
+
+
+def test_fused_fit_is_independent_of_the_solve_order_and_batching(monkeypatch):
+    """The batched solve of the fused fit may take the variables the sparse constraint rows touch last
+    (gbfeat._solve_order: aggf_eq_qp_solve_batched_shift with perm / a_first_col), form A'A from the rows' structure
+    and group the sites by size: each of these is an exact reformulation.  A system large enough for all three to be
+    active (slice map, ~1000 kept columns per site) against the same fit with them switched off."""
+    from aggforce_amd.qp import gbfeat
+
+    rng = np.random.default_rng(13)
+    T, N, n_cg = 400, 330, 8
+    grid = np.stack(np.meshgrid(*[np.arange(7)] * 3, indexing="ij"), -1).reshape(-1, 3)[:N] * 1.6
+    coords = (grid[None] + 0.25 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    forces = (25 * rng.standard_normal((T, N, 3))).astype(np.float32)
+    cons = {frozenset([3 * i, 3 * i + 1]) for i in range(N // 3)}
+    cmap = LinearMap([[3 * (i * (N // n_cg) // 3)] for i in range(n_cg)], n_fg_sites=N)
+    feat = Multifeaturize([id_feat, Curry(gb_feat, outer=9.0, inner=0.0, n_basis=6, width=1.0)])
+    traj = Trajectory(coords=coords, forces=forces)
+    frames = [rng.choice(T, size=12, replace=False) for _ in range(n_cg)]
+    seen = {}
+    real_order = gbfeat._solve_order
+
+    def spy(*a, **k):
+        out = real_order(*a, **k)
+        seen["first"] = out[1]
+        return out
+
+    monkeypatch.setattr(gbfeat, "_solve_order", spy)
+    monkeypatch.setattr(gbfeat, "_BATCH_MIN_SITES", 4)
+    a = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=frames, l2_regularization=5.0)
+    info = a.force_map.tags["fit_info"]
+    assert seen["first"] >= 256 and min(info["kept_columns"]) > 500  # the restricted forward solve really ran
+    monkeypatch.setenv("AGGF_FEAT_ORDER", "0")
+    monkeypatch.setenv("AGGF_FEAT_ATA", "0")
+    monkeypatch.setenv("AGGF_FEAT_BATCH_MIN", "64")
+    b = qp_feat_linear_map(traj, cmap, feat, KBT, constraints=cons, frame_indices=frames, l2_regularization=5.0)
+    assert len(b.force_map.tags["fit_info"]["solve_batches"]) == 1
+    ca, cb = np.stack(a.force_map.tags["coef_list"]), np.stack(b.force_map.tags["coef_list"])
+    assert rel(ca, cb) < 1e-9, rel(ca, cb)
+    assert rel(a(traj).forces, b(traj).forces) < 1e-9
