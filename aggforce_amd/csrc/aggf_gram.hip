@@ -47,7 +47,9 @@ struct GramCfg<float> {
 constexpr int PK_FAST = 4;
 constexpr int PK_ELEMS = 3;  // output elements per thread
 
-template <typename TIn, typename TC>
+// NT: non-temporal loads and stores -- the overlapped pipeline packs the next chunk while the tile kernel lives on
+// the panels it shares through the L2
+template <typename TIn, typename TC, bool NT = false>
 __global__ __launch_bounds__(256) void pack_groups_kernel(
     const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
     const int32_t* __restrict__ grp_atoms, int32_t n_red, int32_t n_pad, TC* __restrict__ out) {
@@ -81,7 +83,7 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(
       TC a = 0;
 #pragma unroll
       for (int j = 0; j < PK_FAST; ++j)
-        if (off[q][j] >= 0) a += (TC)src[off[q][j]];
+        if (off[q][j] >= 0) a += (TC)(NT ? __builtin_nontemporal_load(src + off[q][j]) : src[off[q][j]]);
       acc[q] = a;
     }
     if (big) {
@@ -93,7 +95,9 @@ __global__ __launch_bounds__(256) void pack_groups_kernel(
     }
 #pragma unroll
     for (int q = 0; q < PK_ELEMS; ++q)
-      if (eo[q] >= 0) dst[eo[q]] = acc[q];
+      if (eo[q] >= 0) {
+        if (NT) __builtin_nontemporal_store(acc[q], dst + eo[q]); else dst[eo[q]] = acc[q];
+      }
   }
 }
 
@@ -2176,6 +2180,28 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   return AGGF_OK;
 }
 
+// side stream + events of the overlapped pack pipeline (gram_typed), created once per host thread and device
+struct PackPipe {
+  hipStream_t side = nullptr;
+  hipEvent_t packed[2] = {nullptr, nullptr}, consumed[2] = {nullptr, nullptr};
+  bool ok = false, tried = false;
+};
+static PackPipe* pack_pipe() {
+  static thread_local PackPipe pipes[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+  PackPipe& pp = pipes[dev];
+  if (!pp.tried) {
+    pp.tried = true;
+    bool ok = hipStreamCreateWithFlags(&pp.side, hipStreamNonBlocking) == hipSuccess;
+    for (int k = 0; k < 2 && ok; ++k)
+      ok = hipEventCreateWithFlags(&pp.packed[k], hipEventDisableTiming) == hipSuccess &&
+           hipEventCreateWithFlags(&pp.consumed[k], hipEventDisableTiming) == hipSuccess;
+    pp.ok = ok;
+  }
+  return pp.ok ? &pp : nullptr;
+}
+
 template <typename TIn, typename TC>
 static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_ptr,
                       const int32_t* grp_atoms, int32_t n_red, double* G, int accumulate,
@@ -2269,18 +2295,81 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   }
   TC* pack = reinterpret_cast<TC*>(ws + round_up((int64_t)p.slab_bytes, 256));
   const TIn* F = reinterpret_cast<const TIn*>(Fv);
-  int acc = accumulate;
-  for (int64_t t0 = 0; t0 < T; t0 += p.chunk_frames) {
-    const int64_t rows = (T - t0 < p.chunk_frames) ? T - t0 : p.chunk_frames;
+  // The pack pass is HBM-bound, the tile kernel MFMA-bound: the chunk is split into two half-size buffers and chunk
+  // i + 1 is packed on a side stream while chunk i is multiplied; a trajectory that fits one chunk is still cut into
+  // PACK_MIN_CHUNKS pieces for the same reason.  The pack beside the tile kernel is a SMALL grid of long-lived
+  // workgroups with non-temporal accesses (one per CU; AGGF_GRAM_PACK_WGS): a full-size grid's workgroups take turns
+  // with the tile kernel's for the CUs and break up the cohorts that share panels in the L2.  C3 with bond pairs,
+  // Gram stage (tools/pack_ab.sh): serial 404-407 ms; overlapped with the full grid 562-581; with 32 / 64 / 128 / 192 /
+  // 256 / 384 / 512 workgroups 1017 / 633 / 430 / 396 / 397 / 399 / 409 -- 35 ms of pack, 8 of them hidden.
+  // AGGF_GRAM_PACK=serial: one buffer, one stream; =chunked: the overlapped form's chunks on one stream (measurements).
+  static const char* pack_env = getenv("AGGF_GRAM_PACK");
+  constexpr int PACK_MIN_CHUNKS = 8;
+  // a chunk must be worth its launches and event waits: >= 8192 frames and >= 4e11 flop (~6 ms of tile kernel)
+  int64_t PACK_MIN_FRAMES = (int64_t)(4e11 / (3.0 * (double)p.n_pad * (double)p.n_pad)) + 1;
+  if (PACK_MIN_FRAMES < 8192) PACK_MIN_FRAMES = 8192;
+  const size_t row_elems = (size_t)p.n_pad * 3;
+  int64_t cf = p.chunk_frames;
+  bool overlap = !(pack_env && pack_env[0] == 's') && T >= 2 * PACK_MIN_FRAMES && p.chunk_frames / 2 >= PACK_MIN_FRAMES;
+  const bool same_stream = pack_env && pack_env[0] == 'c';  // (measurement: the overlapped form's chunks, one stream)
+  PackPipe* pipe = overlap ? pack_pipe() : nullptr;
+  if (overlap && !pipe) overlap = false;  // no side stream: the serial form
+  if (overlap) {
+    cf = p.chunk_frames / 2;                              // two buffers in the space of one
+    const int64_t want = ceil_div(T, (int64_t)PACK_MIN_CHUNKS);
+    if (cf > want) cf = want;
+    if (cf < PACK_MIN_FRAMES) cf = PACK_MIN_FRAMES;
+    if (cf > p.chunk_frames / 2) cf = p.chunk_frames / 2;
+    cf = (cf / 8) * 8;                                    // whole stages (both dtypes)
+    if (cf < 8) overlap = false;
+  }
+  if (!overlap) cf = p.chunk_frames;
+  TC* bufs[2] = {pack, overlap ? pack + (size_t)cf * row_elems : pack};
+  auto launch_pack = [&](int64_t t0, int64_t rows, TC* dst, hipStream_t st) {
     const unsigned gx = (unsigned)ceil_div((int64_t)p.n_pad * 3, 256 * PK_ELEMS);
     int64_t gy = ceil_div((int64_t)16 * device_cu_count(), gx);  // ~16 workgroups per CU in all
+    if (st != stream) {
+      // beside the tile kernel: a FEW long-lived workgroups that trickle the chunk through (a full-size grid's
+      // workgroups take turns with the tile kernel's for the CUs and break up the cohorts that share panels in the L2)
+      static const char* wg_env = getenv("AGGF_GRAM_PACK_WGS");
+      const int64_t budget = wg_env && atoi(wg_env) > 0 ? atoi(wg_env) : device_cu_count();  // one per CU
+      gy = ceil_div(budget, (int64_t)gx);
+    }
     if (gy > rows) gy = rows;
-    hipLaunchKernelGGL((pack_groups_kernel<TIn, TC>), dim3(gx, (unsigned)gy), dim3(256), 0, stream,
-                       F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad,
-                       pack);
-    AGGF_LAUNCH_OK();
-    int rc = launch_gram<TC>(pack, rows, (int64_t)p.n_pad * 3, p, slabs, tile_table, G, n_red, acc, stream);
+    if (st != stream)
+      hipLaunchKernelGGL((pack_groups_kernel<TIn, TC, true>), dim3(gx, (unsigned)gy), dim3(256), 0, st,
+                         F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad, dst);
+    else
+      hipLaunchKernelGGL((pack_groups_kernel<TIn, TC>), dim3(gx, (unsigned)gy), dim3(256), 0, st,
+                         F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad, dst);
+  };
+  int acc = accumulate;
+  if (overlap) {
+    // side stream: starts behind everything already queued on `stream` (the caller's data), ends before the last
+    // tile kernel starts (that kernel waits for its pack), so the caller's stream order covers the whole call
+    AGGF_HIP_OK(hipEventRecord(pipe->consumed[0], stream));
+    AGGF_HIP_OK(hipStreamWaitEvent(pipe->side, pipe->consumed[0], 0));
+  }
+  int64_t i = 0;
+  for (int64_t t0 = 0; t0 < T; t0 += cf, ++i) {
+    const int64_t rows = (T - t0 < cf) ? T - t0 : cf;
+    const int b = (int)(i & 1);
+    if (overlap && same_stream) {
+      launch_pack(t0, rows, bufs[b], stream);
+      AGGF_LAUNCH_OK();
+    } else if (overlap) {
+      if (i >= 2) AGGF_HIP_OK(hipStreamWaitEvent(pipe->side, pipe->consumed[b], 0));  // the kernel that read this buffer
+      launch_pack(t0, rows, bufs[b], pipe->side);
+      AGGF_LAUNCH_OK();
+      AGGF_HIP_OK(hipEventRecord(pipe->packed[b], pipe->side));
+      AGGF_HIP_OK(hipStreamWaitEvent(stream, pipe->packed[b], 0));
+    } else {
+      launch_pack(t0, rows, bufs[b], stream);
+      AGGF_LAUNCH_OK();
+    }
+    int rc = launch_gram<TC>(bufs[b], rows, (int64_t)p.n_pad * 3, p, slabs, tile_table, G, n_red, acc, stream);
     if (rc) return rc;
+    if (overlap && !same_stream) AGGF_HIP_OK(hipEventRecord(pipe->consumed[b], stream));
     acc = 1;
   }
   return AGGF_OK;
