@@ -11,9 +11,10 @@ import sys
 tag, bench_args = sys.argv[1], (sys.argv[2] if len(sys.argv) > 2 else "")
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 src, dst = os.path.join(root, "gpurun_out"), os.path.join(root, "profiles")
-stats = glob.glob(os.path.join(src, f"{tag}_trace", "**", "*kernel_stats.csv"), recursive=True)
+# (gpurun_out/ keeps the files of earlier runs of the same tag: the newest one is this run's)
+stats = sorted(glob.glob(os.path.join(src, f"{tag}_trace", "**", "*kernel_stats.csv"), recursive=True), key=os.path.getmtime)
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, f"{tag}_kernel_stats.csv"))
+    shutil.copy(stats[-1], os.path.join(dst, f"{tag}_kernel_stats.csv"))
 summary = json.load(open(os.path.join(src, f"{tag}_summary.json")))
 summary["commands"] = {
     "trace": f"rocprofv3 --kernel-trace --stats -- python3 bench.py --no-cpu-baseline {bench_args}",
