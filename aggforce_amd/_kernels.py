@@ -433,16 +433,25 @@ def take_flag(device) -> torch.Tensor:
     pool = _flag_pool.setdefault(str(device), [])
     if not pool:
         block = torch.zeros(64, dtype=torch.int32, device=device)
+        # The fill runs on whatever stream is current (in a fresh process: the side stream of the coordinate gather,
+        # behind a multi-millisecond kernel) while the flags are then used on any stream: wait for it here, once per
+        # 64 flags, so that no later kernel's mark can be wiped by -- or read before -- the fill.
+        torch.cuda.current_stream(block.device).synchronize()
         pool.extend(block[i:i + 1] for i in range(64))
     return pool.pop()
 
 
 def read_flag(flag: torch.Tensor) -> bool:
-    """Host value of a flag from :func:`take_flag` (synchronises); the flag goes back to the pool, zeroed."""
+    """Host value of a flag from :func:`take_flag` (synchronises); the flag goes back to the pool, zeroed.  A flag is
+    handed back exactly once: a second hand-back would let two later kernels share it."""
+    pool = _flag_pool.setdefault(str(flag.device), [])
+    if any(f.data_ptr() == flag.data_ptr() for f in pool):
+        raise RuntimeError("read_flag: this flag is already back in the pool")
     v = bool(flag.item())
     if v:
         flag.zero_()
-    _flag_pool.setdefault(str(flag.device), []).append(flag)
+        torch.cuda.current_stream(flag.device).synchronize()  # the next user may sit on another stream
+    pool.append(flag)
     return v
 
 
@@ -617,6 +626,57 @@ def condnormal_sites(mean: torch.Tensor, var: float, kbt: float, noise: Optional
                                           dtype_code(mean.dtype), float(var), float(kbt), ptr(y), ptr(fa),
                                           dtype_code(out_dtype), stream_ptr()), "aggf_condnormal_sites")
     return y, fa
+
+
+def residual_over_var(gen: torch.Tensor, mean: torch.Tensor, var: float, out_dtype: torch.dtype, want_pos: bool = True,
+                      want_neg: bool = True):
+    """(r, -r) with r = (gen - mean) / var, elementwise, in ``out_dtype`` (aggf_residual_over_var): the log-gradients
+    of a scalar-covariance conditional normal.  An output that is not wanted is None."""
+    assert gen.shape == mean.shape and gen.is_contiguous() and mean.is_contiguous()
+    pos = torch.empty(gen.shape, dtype=out_dtype, device=gen.device) if want_pos else None
+    neg = torch.empty(gen.shape, dtype=out_dtype, device=gen.device) if want_neg else None
+    if gen.numel():
+        with _timed("augment"):
+            check(lib().aggf_residual_over_var(ptr(gen), dtype_code(gen.dtype), ptr(mean), dtype_code(mean.dtype),
+                                               gen.numel(), float(var), ptr(pos), ptr(neg), dtype_code(out_dtype),
+                                               stream_ptr()), "aggf_residual_over_var")
+    return pos, neg
+
+
+def frames_matmul(x: torch.Tensor, b: torch.Tensor, sub: Optional[torch.Tensor] = None,
+                  add: Optional[torch.Tensor] = None, alpha: float = 1.0) -> torch.Tensor:
+    """``add + alpha (x - sub) @ b.T`` on flattened frames: x, sub (T, K), b (J, K), add (T, J), one dtype
+    (aggf_frames_matmul)."""
+    T, Kd = x.shape
+    J = b.shape[0]
+    assert b.shape[1] == Kd and b.dtype == x.dtype and x.is_contiguous() and b.is_contiguous()
+    assert sub is None or (sub.shape == x.shape and sub.dtype == x.dtype and sub.is_contiguous())
+    assert add is None or (tuple(add.shape) == (T, J) and add.dtype == x.dtype and add.is_contiguous())
+    out = torch.empty((T, J), dtype=x.dtype, device=x.device)
+    if T:
+        with _timed("augment"):
+            check(lib().aggf_frames_matmul(ptr(x), ptr(sub), T, Kd, ptr(b), J, ptr(add), float(alpha),
+                                           dtype_code(x.dtype), ptr(out), stream_ptr()), "aggf_frames_matmul")
+    return out
+
+
+def augment_concat(coords: torch.Tensor, forces: torch.Tensor, gen: torch.Tensor, corr: torch.Tensor,
+                   lgrad: torch.Tensor, kbt: float):
+    """([coords ; gen], [forces + kbt corr ; kbt lgrad]) in the promoted dtype (aggf_augment_concat): the
+    concatenation step of the general Augmenter protocol (trajectory/core.py:384-390)."""
+    T, N, _ = coords.shape
+    n_aug = gen.shape[1]
+    assert forces.shape == coords.shape and forces.dtype == coords.dtype
+    assert gen.dtype == corr.dtype == lgrad.dtype and corr.shape == coords.shape and lgrad.shape == gen.shape
+    out_dtype = torch.promote_types(coords.dtype, gen.dtype)
+    oc = torch.empty((T, N + n_aug, 3), dtype=out_dtype, device=coords.device)
+    of = torch.empty((T, N + n_aug, 3), dtype=out_dtype, device=coords.device)
+    if T:
+        with _timed("augment"):
+            check(lib().aggf_augment_concat(ptr(coords), ptr(forces), dtype_code(coords.dtype), ptr(gen), ptr(corr),
+                                            ptr(lgrad), dtype_code(gen.dtype), T, N, n_aug, float(kbt), ptr(oc),
+                                            ptr(of), stream_ptr()), "aggf_augment_concat")
+    return oc, of
 
 
 def gram_pair_ok(a: torch.Tensor, b: torch.Tensor) -> bool:

@@ -53,6 +53,9 @@ PROTOTYPES = {
     "aggf_sym_unpack_upper": (C.c_int, [_vp, C.c_int32, C.c_int32, _vp, _vp]),
     "aggf_condnormal_augment": (C.c_int, [_vp, _vp, _i64, _i32, C.c_int, _vp, _vp, _vp, _i32, C.c_int, _vp, _vp, _u64, _i64, _dbl, _dbl, _vp, _vp, _vp]),
     "aggf_condnormal_sites": (C.c_int, [_vp, _vp, _u64, _i64, _i64, _i32, C.c_int, _dbl, _dbl, _vp, _vp, C.c_int, _vp]),
+    "aggf_residual_over_var": (C.c_int, [_vp, C.c_int, _vp, C.c_int, _i64, _dbl, _vp, _vp, C.c_int, _vp]),
+    "aggf_frames_matmul": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _i32, _vp, _dbl, C.c_int, _vp, _vp]),
+    "aggf_augment_concat": (C.c_int, [_vp, _vp, C.c_int, _vp, _vp, _vp, C.c_int, _i64, _i32, _i32, _dbl, _vp, _vp, _vp]),
     "aggf_gram_pair_workspace_bytes": (_sz, [_i64, _i32, _i32, C.c_int]),
     "aggf_gram_pair": (C.c_int, [_vp, _i32, _vp, _i32, _i64, C.c_int, _vp, C.c_int, _vp, _sz, _vp]),
     "aggf_augmented_gram_workspace_bytes": (_sz, [_i32, _i32]),

@@ -196,6 +196,102 @@ static int augment_typed(const void* coords, const void* forces, int64_t T, int3
   return AGGF_OK;
 }
 
+
+// ---- pieces of the GENERAL Augmenter protocol (trajectory/core.py:382-390 with any sample / log_gradient) ----------
+// r = (gen - mean) / var and -r in one pass: the two log-gradients of a scalar-covariance conditional normal
+// (jaxgausstraj.py:251-284 in closed form; simplegausstraj.py:100-113).  Either output may be NULL.
+template <typename TG, typename TM, typename TO>
+__global__ __launch_bounds__(256) void residual_over_var_kernel(const TG* __restrict__ gen, const TM* __restrict__ mean,
+                                                                int64_t count, TO var, TO* __restrict__ out_pos,
+                                                                TO* __restrict__ out_neg) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x) {
+    const TO r = ((TO)gen[i] - (TO)mean[i]) / var;
+    if (out_pos) out_pos[i] = r;
+    if (out_neg) out_neg[i] = -r;
+  }
+}
+
+// out[t, j] = add[t, j] + alpha * sum_k (X[t, k] - S[t, k]) B[j, k]    (add, S optional)
+// The flattened (n_frames, 3 n) products of a FULL covariance matrix: y = mean + eps L' and Sigma^-1 (y - mean)
+// (jaxgausstraj.py:77-96, 291-329).  MFMA 16x16x4: workgroup = 64 frames x 64 outputs, 4 waves, wave = 16 frames x 64
+// outputs; K in chunks of 32 staged through LDS (coalesced along k, zero filled outside the matrix).
+template <typename T>
+__global__ __launch_bounds__(256) void frames_matmul_kernel(const T* __restrict__ X, const T* __restrict__ S, int64_t nT,
+                                                            int32_t K, const T* __restrict__ B, int32_t J,
+                                                            const T* __restrict__ add, T alpha, T* __restrict__ out) {
+  constexpr int KC = 32, LD = KC + 1;
+  __shared__ T sX[64 * LD];
+  __shared__ T sB[64 * LD];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t t0 = (int64_t)blockIdx.x * 64;
+  const int j0 = blockIdx.y * 64;
+  typename Mfma<T>::acc_t acc[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) acc[c] = acc_zero<T>();
+  for (int k0 = 0; k0 < K; k0 += KC) {
+    for (int e = tid; e < 64 * KC; e += 256) {
+      const int r = e / KC, k = e - r * KC;
+      const int64_t t = t0 + r;
+      T x = 0, b = 0;
+      if (k0 + k < K) {
+        if (t < nT) {
+          x = X[t * K + k0 + k];
+          if (S) x -= S[t * K + k0 + k];
+        }
+        if (j0 + r < J) b = B[(int64_t)(j0 + r) * K + k0 + k];
+      }
+      sX[r * LD + k] = x;
+      sB[r * LD + k] = b;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < KC; kk += 4) {
+      const T a = sX[(wave * 16 + (lane & 15)) * LD + kk + (lane >> 4)];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const T b = sB[(c * 16 + (lane & 15)) * LD + kk + (lane >> 4)];
+        acc[c] = Mfma<T>::mma(a, b, acc[c]);
+      }
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int c = 0; c < 4; ++c)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t t = t0 + wave * 16 + Mfma<T>::row(lane, r);
+      const int j = j0 + c * 16 + (lane & 15);
+      if (t < nT && j < J) {
+        const T base = add ? add[t * J + j] : (T)0;
+        out[t * J + j] = base + alpha * acc[c][r];
+      }
+    }
+}
+
+// [x ; y] and [F + kbt corr ; kbt lgrad] written side by side (trajectory/core.py:384-390): the concatenation of the
+// general Augmenter protocol, with the two scaled sums fused into the copy.  One thread = one output element.
+template <typename TX, typename TY, typename TO>
+__global__ __launch_bounds__(256) void augment_concat_kernel(const TX* __restrict__ coords, const TX* __restrict__ forces,
+                                                             const TY* __restrict__ gen, const TY* __restrict__ corr,
+                                                             const TY* __restrict__ lgrad, int64_t nT, int32_t N,
+                                                             int32_t n_aug, TO kbt, TO* __restrict__ out_c,
+                                                             TO* __restrict__ out_f) {
+  const int64_t row_in = (int64_t)N * 3, row_aug = (int64_t)n_aug * 3, row_out = row_in + row_aug;
+  const int64_t total = nT * row_out;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = e / row_out, c = e - t * row_out;
+    if (c < row_in) {
+      const int64_t i = t * row_in + c;
+      out_c[e] = (TO)coords[i];
+      out_f[e] = (TO)forces[i] + kbt * (TO)corr[i];
+    } else {
+      const int64_t i = t * row_aug + (c - row_in);
+      out_c[e] = (TO)gen[i];
+      out_f[e] = kbt * (TO)lgrad[i];
+    }
+  }
+}
+
 }  // namespace aggf
 
 using namespace aggf;
@@ -275,6 +371,77 @@ extern "C" int aggf_sym_group_reduce(const double* G, int32_t n, const int32_t* 
   int64_t g = ceil_div((int64_t)n_red * n_red, 256);
   if (g > 65535) g = 65535;
   hipLaunchKernelGGL(sym_group_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, G, n, grp_ptr, grp_atoms, n_red, G_red);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_residual_over_var(const void* gen, int gen_dtype, const void* mean, int mean_dtype, int64_t count,
+                                      double var, void* out_pos, void* out_neg, int out_dtype, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!gen || !mean || (!out_pos && !out_neg)) return fail(AGGF_ERR_ARG, "aggf_residual_over_var: NULL pointer");
+  if (count < 0) return fail(AGGF_ERR_ARG, "aggf_residual_over_var: negative count");
+  if (!(var > 0.0)) return fail(AGGF_ERR_ARG, "aggf_residual_over_var: var must be positive");
+  if (count == 0) return AGGF_OK;
+  int64_t g = ceil_div(count, 256);
+  if (g > 16384) g = 16384;
+  const dim3 grid((unsigned)g), block(256);
+#define AGGF_ROV(TG, TM, TO)                                                                                         \
+  hipLaunchKernelGGL((residual_over_var_kernel<TG, TM, TO>), grid, block, 0, stream, (const TG*)gen, (const TM*)mean, \
+                     count, (TO)var, (TO*)out_pos, (TO*)out_neg)
+  if (gen_dtype == AGGF_F32 && mean_dtype == AGGF_F32 && out_dtype == AGGF_F32) AGGF_ROV(float, float, float);
+  else if (gen_dtype == AGGF_F32 && mean_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_ROV(float, float, double);
+  else if (gen_dtype == AGGF_F64 && mean_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_ROV(double, double, double);
+  else if (gen_dtype == AGGF_F32 && mean_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_ROV(float, double, double);
+  else if (gen_dtype == AGGF_F64 && mean_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_ROV(double, float, double);
+  else return fail(AGGF_ERR_ARG, "aggf_residual_over_var: bad dtype (out must hold the promotion of the inputs)");
+#undef AGGF_ROV
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_frames_matmul(const void* X, const void* S, int64_t T, int32_t K, const void* B, int32_t J,
+                                  const void* add, double alpha, int dtype, void* out, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!X || !B || !out) return fail(AGGF_ERR_ARG, "aggf_frames_matmul: NULL pointer");
+  if (T < 0 || K <= 0 || J <= 0) return fail(AGGF_ERR_ARG, "aggf_frames_matmul: bad shape");
+  if (out == X || out == S) return fail(AGGF_ERR_ARG, "aggf_frames_matmul: out must not alias X or S");
+  if (T == 0) return AGGF_OK;
+  const int64_t gx = ceil_div(T, 64), gy = ceil_div(J, 64);
+  if (gx > 0x7fffffffLL || gy > 65535) return fail(AGGF_ERR_ARG, "aggf_frames_matmul: grid too large");
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+  if (dtype == AGGF_F32)
+    hipLaunchKernelGGL((frames_matmul_kernel<float>), grid, block, 0, stream, (const float*)X, (const float*)S, T, K,
+                       (const float*)B, J, (const float*)add, (float)alpha, (float*)out);
+  else if (dtype == AGGF_F64)
+    hipLaunchKernelGGL((frames_matmul_kernel<double>), grid, block, 0, stream, (const double*)X, (const double*)S, T, K,
+                       (const double*)B, J, (const double*)add, alpha, (double*)out);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_frames_matmul: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_augment_concat(const void* coords, const void* forces, int traj_dtype, const void* gen,
+                                   const void* corr, const void* lgrad, int aug_dtype, int64_t T, int32_t N,
+                                   int32_t n_aug, double kbt, void* out_coords, void* out_forces, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!coords || !forces || !gen || !corr || !lgrad || !out_coords || !out_forces)
+    return fail(AGGF_ERR_ARG, "aggf_augment_concat: NULL pointer");
+  if (T < 0 || N <= 0 || n_aug <= 0) return fail(AGGF_ERR_ARG, "aggf_augment_concat: bad shape");
+  if (T == 0) return AGGF_OK;
+  int64_t g = ceil_div(T * ((int64_t)N + n_aug) * 3, 256);
+  if (g > 32768) g = 32768;
+  const dim3 grid((unsigned)g), block(256);
+#define AGGF_CAT(TX, TY, TO)                                                                                       \
+  hipLaunchKernelGGL((augment_concat_kernel<TX, TY, TO>), grid, block, 0, stream, (const TX*)coords,               \
+                     (const TX*)forces, (const TY*)gen, (const TY*)corr, (const TY*)lgrad, T, N, n_aug, (TO)kbt,   \
+                     (TO*)out_coords, (TO*)out_forces)
+  if (traj_dtype == AGGF_F32 && aug_dtype == AGGF_F32) AGGF_CAT(float, float, float);
+  else if (traj_dtype == AGGF_F64 && aug_dtype == AGGF_F32) AGGF_CAT(double, float, double);
+  else if (traj_dtype == AGGF_F32 && aug_dtype == AGGF_F64) AGGF_CAT(float, double, double);
+  else if (traj_dtype == AGGF_F64 && aug_dtype == AGGF_F64) AGGF_CAT(double, double, double);
+  else return fail(AGGF_ERR_ARG, "aggf_augment_concat: bad dtype");
+#undef AGGF_CAT
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

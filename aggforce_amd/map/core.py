@@ -35,9 +35,15 @@ class _PendingMap:
         main.wait_stream(self._stream)
         self._out.record_stream(main)
 
+    def _take_flag_value(self) -> bool:
+        """Reads the flag and hands it back to the pool -- once: ``result()`` raising and the caller's ``discard()``
+        in a ``finally`` used to return the same flag twice, and two later kernels then shared it."""
+        flag, self._flag = self._flag, None
+        return False if flag is None else K.read_flag(flag)
+
     def result(self):
         self._join()
-        if K.read_flag(self._flag):
+        if self._take_flag_value():
             raise ValueError(
                 "NaN handling is on and results seem to depend on NaN "
                 "positions in input array. Check input and standard_matrix."
@@ -46,7 +52,7 @@ class _PendingMap:
 
     def discard(self) -> None:
         self._join()
-        K.read_flag(self._flag)
+        self._take_flag_value()
 
 
 class LinearMap:

@@ -115,7 +115,8 @@ class AugmentedTMap(TMap):
                 or not isinstance(sub.coord_map, LinearMap) or isinstance(t, AugmentedTrajectory)):
             return None
         n_real = t.forces.shape[1]
-        premap = getattr(self.augmenter, "premap", None)
+        premap_map = getattr(self.augmenter, "premap_map", None)
+        premap = premap_map(n_real) if premap_map is not None else None
         if premap is None or premap.n_fg_sites != n_real:
             return None
         n_aug = premap.n_cg_sites

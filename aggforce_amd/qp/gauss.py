@@ -81,23 +81,35 @@ def _joptgauss_without_extended_arrays(traj, augmenter, kbt, constraints, kwargs
     extra = set(kwargs) - {"l2_regularization", "solver_args", "gram_dtype", "comm"}
     if extra or not isinstance(traj, Trajectory) or isinstance(traj, AugmentedTrajectory):
         return None
-    forces = K.as_device(traj.forces)
-    n_real, n_aug = forces.shape[1], augmenter.premap.n_cg_sites
-    gram_dtype = kwargs.get("gram_dtype")
-    if (forces.shape[0] == 0 or n_real % 128 or n_aug % 128
-            or (gram_dtype is not None and K.torch_dtype(gram_dtype) != forces.dtype)):
-        return None
-    coords = K.as_device(traj.coords)
     import torch
 
-    if (torch.promote_types(coords.dtype, K.torch_dtype(augmenter.dtype)) != forces.dtype
-            or not forces.is_contiguous() or forces.data_ptr() % 16):
+    from ..distributed import agree_on_min
+
+    comm = kwargs.get("comm")
+    forces = K.as_device(traj.forces)
+    coords = K.as_device(traj.coords)
+    n_real, n_aug = forces.shape[1], augmenter.premap_map(forces.shape[1]).n_cg_sites
+    gram_dtype = kwargs.get("gram_dtype")
+    # A shard without frames contributes a zero matrix (only under ``comm``: alone it is the general path's error).
+    empty = forces.shape[0] == 0
+    ok = not ((empty and comm is None) or n_real % 128 or n_aug % 128
+              or (gram_dtype is not None and K.torch_dtype(gram_dtype) != forces.dtype)
+              or torch.promote_types(coords.dtype, K.torch_dtype(augmenter.dtype)) != forces.dtype
+              or (not empty and (not forces.is_contiguous() or forces.data_ptr() % 16)))
+    # The choice rests on rank-local facts (contiguity, alignment, dtypes, an empty shard), and the two paths
+    # all-reduce DIFFERENT matrices (Gx of [F | Fa] here, the Gram of [F - Fa C | Fa] in qp_linear_map): every rank
+    # must take the same one, as cv_joptgauss_fold_grams does.
+    if not agree_on_min(int(ok), comm, forces.device):
         return None
-    y, fa, cols = augmenter.noise_sites(coords, kbt)
-    assert K.gram_pair_ok(forces, fa)
-    del y
-    Gx = K.gram_pair(forces, fa)
-    all_reduce_sum_sym_(Gx, kwargs.get("comm"))  # linear in Gx: the transform commutes with the sum over ranks
+    if empty:
+        cols = augmenter.correction_columns(n_real, forces.device)
+        Gx = torch.zeros((n_real + n_aug, n_real + n_aug), dtype=torch.float64, device=forces.device)
+    else:
+        y, fa, cols = augmenter.noise_sites(coords, kbt)
+        assert K.gram_pair_ok(forces, fa)
+        del y
+        Gx = K.gram_pair(forces, fa)
+    all_reduce_sum_sym_(Gx, comm)  # linear in Gx: the transform commutes with the sum over ranks
     G = K.augmented_gram(Gx, n_real, cols)
     del Gx
     aug_cmap = LinearMap(mapping=[[i] for i in range(n_real, n_real + n_aug)], n_fg_sites=n_real + n_aug)

@@ -44,6 +44,24 @@ def _concat_sites(parts):
     return np.concatenate(parts, axis=1)
 
 
+def _augment_concat(coords, forces, aug_coords, real_corr, aug_lgrad, kbt):
+    """([x ; y], [F + kbt d/dx ; kbt d/dy]) of the general Augmenter protocol (reference trajectory/core.py:384-390) in
+    one pass (``aggf_augment_concat``: the two scaled sums ride along with the concatenating copy)."""
+    from .. import _kernels as K
+
+    c = K.as_device(coords)
+    f = K.as_device(forces, c.dtype)
+    y = K.as_device(aug_coords)
+    adt = y.dtype
+    for other in (real_corr, aug_lgrad):
+        if K.as_device(other).dtype != adt:
+            import torch
+
+            adt = torch.float64
+    oc, of = K.augment_concat(c, f, K.as_device(y, adt), K.as_device(real_corr, adt), K.as_device(aug_lgrad, adt), kbt)
+    return K.like_input(oc, coords), K.like_input(of, coords)
+
+
 def _need_slice(index) -> None:
     if not isinstance(index, slice):
         raise ValueError("Only slices are allowed for indexing.")
@@ -164,9 +182,7 @@ class AugmentedTrajectory(Trajectory):
             return fused(coords, forces, self.kbt)
         aug_coords = self.augmenter.sample(coords)
         real_corr, aug_lgrad = self.augmenter.log_gradient(coords, aug_coords)
-        aug_forces = self.kbt * aug_lgrad
-        real_forces = forces + self.kbt * real_corr
-        return _concat_sites([coords, aug_coords]), _concat_sites([real_forces, aug_forces])
+        return _augment_concat(coords, forces, aug_coords, real_corr, aug_lgrad, self.kbt)
 
     @property
     def real_coords(self):

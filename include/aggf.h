@@ -275,6 +275,27 @@ int aggf_augmented_gram(const double* Gx, int32_t N, int32_t n2, const int32_t* 
 int aggf_sym_group_reduce(const double* G, int32_t n, const int32_t* grp_ptr, const int32_t* grp_atoms,
                           int32_t n_red, double* G_red, void* stream);
 
+/* The GENERAL Augmenter protocol (any sample / log_gradient pair; trajectory/core.py:382-390, trajectory/augment.py)
+ * and the parts of JCondNormal's interface that the fused calls above do not cover (trajectory/jaxgausstraj.py):
+ *   aggf_residual_over_var  r = (gen - mean) / var into out_pos and -r into out_neg (either may be NULL): the two
+ *                           log-gradients of a scalar-covariance conditional normal (jaxgausstraj.py:251-284 in closed
+ *                           form, simplegausstraj.py:100-113); out_dtype = NumPy promotion of the two input dtypes
+ *                           (or float64);
+ *   aggf_frames_matmul      out[t, j] = add[t, j] + alpha sum_k (X[t, k] - S[t, k]) B[j, k] on flattened frames
+ *                           (T, K) -> (T, J), B (J, K) row-major, S and add optional (NULL), one dtype throughout:
+ *                           the products of a FULL (3 n x 3 n) covariance -- y = mean + eps L' with L its Cholesky
+ *                           factor (jaxgausstraj.py:291-329) and Sigma^-1 (y - mean) (jaxgausstraj.py:77-96);
+ *   aggf_augment_concat     out_coords = [coords ; gen], out_forces = [forces + kbt corr ; kbt lgrad], (T, N + n_aug,
+ *                           3) each in the NumPy promotion of traj_dtype and aug_dtype (trajectory/core.py:384-390);
+ *                           gen, lgrad: (T, n_aug, 3), corr: (T, N, 3), all three in aug_dtype. */
+int aggf_residual_over_var(const void* gen, int gen_dtype, const void* mean, int mean_dtype, int64_t count, double var,
+                           void* out_pos, void* out_neg, int out_dtype, void* stream);
+int aggf_frames_matmul(const void* X, const void* S, int64_t T, int32_t K, const void* B, int32_t J, const void* add,
+                       double alpha, int dtype, void* out, void* stream);
+int aggf_augment_concat(const void* coords, const void* forces, int traj_dtype, const void* gen, const void* corr,
+                        const void* lgrad, int aug_dtype, int64_t T, int32_t N, int32_t n_aug, double kbt,
+                        void* out_coords, void* out_forces, void* stream);
+
 /* ---------------------------------------------------------------------------
  * K4  Gaussian-basis distance featuriser (gb_feat) and the featurised regression
  *     matrix, without the one-hot (T, N, n_feat) feature tensor.

@@ -495,6 +495,28 @@ def condnormal_sample(source, premap_matrix, var, noise, dtype=np.float32):
     return (trjdot(source, M) + dtype(np.sqrt(var)) * np.asarray(noise, dtype=dtype)).astype(dtype)
 
 
+def condnormal_full_sample(source, premap_matrix, cov, noise, dtype=np.float64):
+    """JCondNormal.sample with a FULL covariance over the flattened generated coordinates (site-major, xyz innermost):
+    multivariate_normal(mean = premap(flat source), cov), jaxgausstraj.py:232-234,311-316, with the variate written as
+    mean + L eps, L L' = cov (Cholesky: JAX's default ``method``), eps injected.  PARITY UNPINNED (JAX absent)."""
+    source = np.asarray(source, dtype=dtype)
+    mean = trjdot(source, np.asarray(premap_matrix, dtype=dtype))
+    L = np.linalg.cholesky(np.asarray(cov, dtype=np.float64)).astype(dtype)
+    flat = mean.reshape(len(mean), -1) + np.asarray(noise, dtype=dtype).reshape(len(mean), -1) @ L.T
+    return flat.reshape(mean.shape).astype(dtype)
+
+
+def condnormal_full_log_gradient(source, generated, premap_matrix, cov, dtype=np.float64):
+    """grad of logpdf(y; premap(x), cov) with respect to (x, y): jaxgausstraj.py:77-96 in closed form,
+    d/dy = -cov^-1 (y - Mx), d/dx = (M (x) I_3)' cov^-1 (y - Mx).  PARITY UNPINNED (JAX absent)."""
+    source = np.asarray(source, dtype=dtype)
+    generated = np.asarray(generated, dtype=dtype)
+    M = np.asarray(premap_matrix, dtype=dtype)
+    resid = (generated - trjdot(source, M)).reshape(len(source), -1)
+    r = (resid @ np.linalg.inv(np.asarray(cov, dtype=np.float64)).astype(dtype)).reshape(generated.shape)
+    return np.einsum("tcd,cf->tfd", r, M).astype(dtype), (-r).astype(dtype)
+
+
 def augment(coords, forces, premap_matrix, var, kbt, noise, dtype=np.float32):
     """AugmentedTrajectory._augment; trajectory/core.py:382-390."""
     aug_coords = condnormal_sample(coords, premap_matrix, var, noise, dtype)

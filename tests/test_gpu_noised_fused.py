@@ -246,3 +246,51 @@ def test_noised_grid_cv_two_ranks_match_one_process_on_union_folds(tmp_path):
         assert abs(row[0] - one["scores"][label]) < 1e-7 * abs(one["scores"][label])
         assert abs(row[1] - one["sds"][label]) < 1e-5 * abs(one["sds"][label])
     assert mean([1.0, 3.0]) == 2.0 and sample_sd([1.0, 3.0]) > 0  # (the helpers the rows were built with)
+
+
+def _mixed_layout_rank_worker(rank, world, port, out_dir, mode):
+    """rank 1's shard is a strided device view (``noncontig``) or has no frames (``empty``); rank 0's is
+    plain.  The fused / general choice must be taken jointly: the two paths all-reduce different matrices."""
+    import os
+    import sys
+
+    import torch
+    import torch.distributed as dist
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from aggforce_amd import LinearMap as LM
+    from aggforce_amd import Trajectory as TJ
+    from aggforce_amd import joptgauss_map as jm
+
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    coords, forces, cmat, cons, l2, eps, _ = case("dense_f64_constraints")
+    cut = 900 if mode == "empty" else 450
+    sl = slice(0, cut) if rank == 0 else slice(cut, 900)
+    c, f = torch.from_numpy(coords[sl]).cuda(), torch.from_numpy(forces[sl]).cuda()
+    if mode == "noncontig" and rank == 1:
+        wide = torch.zeros((f.shape[0], f.shape[1], 4), dtype=f.dtype, device=f.device)
+        wide[:, :, :3] = f
+        f = wide[:, :, :3]  # same values, strides (4 N, 4, 1): not a layout aggf_gram_pair reads in place
+        assert not f.is_contiguous()
+    tm = jm(TJ(coords=c, forces=f), LM(cmat), var=VAR, kbt=KBT, constraints=cons, noise=[eps[0][sl]],
+            l2_regularization=l2, frame_offset=sl.start, comm=True)
+    np.save(os.path.join(out_dir, f"mixed_{mode}_{rank}.npy"), tm.tmap.force_map.standard_matrix)
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["noncontig", "empty"])
+def test_fused_noised_fit_two_ranks_agree_on_the_path(tmp_path, mode):
+    import socket
+
+    import torch.multiprocessing as mp
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    mp.spawn(_mixed_layout_rank_worker, args=(2, port, str(tmp_path), mode), nprocs=2, join=True)
+    w0, w1 = np.load(tmp_path / f"mixed_{mode}_0.npy"), np.load(tmp_path / f"mixed_{mode}_1.npy")
+    assert np.array_equal(w0, w1)  # replicated solve of one all-reduced matrix
+    coords, forces, cmat, cons, l2, eps, _ = case("dense_f64_constraints")
+    o = orc.joptgauss_force_map(coords, forces, cmat, VAR, KBT, eps[0], cons, l2, dtype=np.float64)
+    assert rel(w0, o["force_map"]) < 2e-5

@@ -223,3 +223,36 @@ def test_exact_featurised_problem_is_ill_posed_when_float32_flips_the_rank():
     assert [s[0] for s in shift] == [0, 0, shift[2][0], 0] and shift[2][0] > 0      # only the midpoint site flips
     assert shift[2][1] > 1e-2                                                         # ... and its optimum moves
     assert max(shift[0][1], shift[1][1], shift[3][1]) < 1e-5                          # the others do not
+
+
+def test_full_covariance_log_gradient_is_the_gradient_of_scipys_logpdf():
+    """``orc.condnormal_full_log_gradient`` (closed form of jaxgausstraj.py:77-96) against central differences of
+    scipy's multivariate-normal log-density: an anchor independent of our algebra (JAX itself is absent)."""
+    from scipy.stats import multivariate_normal
+
+    rng = np.random.default_rng(8)
+    N, n = 5, 2
+    M = rng.standard_normal((n, N))
+    B = rng.standard_normal((3 * n, 3 * n))
+    cov = B @ B.T + 0.5 * np.eye(3 * n)
+    x = rng.standard_normal((1, N, 3))
+    y = orc.trjdot(x, M) + 0.3 * rng.standard_normal((1, n, 3))
+
+    def logp(xx, yy):
+        return multivariate_normal.logpdf(yy.reshape(-1), mean=orc.trjdot(xx, M).reshape(-1), cov=cov)
+
+    d_src, d_gen = orc.condnormal_full_log_gradient(x, y, M, cov)
+    h = 1e-5
+    for arr, grad, wrt in ((x, d_src, 0), (y, d_gen, 1)):
+        num = np.zeros_like(arr)
+        for i in np.ndindex(arr.shape):
+            p, m = arr.copy(), arr.copy()
+            p[i] += h
+            m[i] -= h
+            num[i] = ((logp(p, y) - logp(m, y)) if wrt == 0 else (logp(x, p) - logp(x, m))) / (2 * h)
+        assert np.max(np.abs(num - grad)) < 1e-6 * max(1.0, np.max(np.abs(grad)))
+    # and a sample with injected noise has mean premap(x) and the Cholesky factor applied to the noise
+    eps = rng.standard_normal((1, n, 3))
+    ys = orc.condnormal_full_sample(x, M, cov, eps)
+    L = np.linalg.cholesky(cov)
+    assert np.allclose(ys.reshape(-1), orc.trjdot(x, M).reshape(-1) + L @ eps.reshape(-1))
