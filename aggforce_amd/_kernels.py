@@ -174,76 +174,6 @@ def gram(
     return out
 
 
-def gather_layout(n_fg: int, n_red: int, csr=None):
-    """Host description of the reduced-column layout for :func:`gram_gather` (aggf_gram_gather): ``csr`` =
-    (grp_ptr, grp_atoms) of the constraint groups (``constraints.groups_csr``: column -> member atoms, ascending) or
-    None for one atom per column.  Returns None if some column has more than four members, else a dict with
-    ``col_off`` (n_pad, mm) int32, ``panel_lo`` (n_pad / 128) int32, ``span`` (atoms) and ``mm``."""
-    n_pad = -(-n_red // 128) * 128
-    if csr is None:
-        sizes = np.ones(n_red, dtype=np.int64)
-        ptr = np.arange(n_red + 1, dtype=np.int64)
-        atoms = np.arange(n_red, dtype=np.int64)
-    else:
-        ptr, atoms = np.asarray(csr[0], dtype=np.int64), np.asarray(csr[1], dtype=np.int64)
-        sizes = np.diff(ptr)
-    most = int(sizes.max()) if n_red else 0
-    if most > 4 or most < 1 or int(sizes.min()) < 1:
-        return None
-    mm = 1 if most == 1 else 2 if most == 2 else 4
-    col_off = np.full((n_pad, mm), -1, dtype=np.int32)
-    col = np.repeat(np.arange(n_red), sizes)
-    slot = np.arange(len(atoms)) - np.repeat(ptr[:-1], sizes)
-    col_off[col, slot] = 3 * atoms
-    lo_col = np.minimum.reduceat(atoms, ptr[:-1])
-    hi_col = np.maximum.reduceat(atoms, ptr[:-1]) + 1
-    starts = np.arange(0, n_red, 128)
-    panel_lo = np.minimum.reduceat(lo_col, starts).astype(np.int32)
-    panel_hi = np.maximum.reduceat(hi_col, starts)
-    return {"col_off": col_off, "panel_lo": panel_lo, "span": int((panel_hi - panel_lo).max()), "mm": mm, "n_fg": n_fg}
-
-
-def gram_gather_ok(forces: torch.Tensor, n_red: int, compute_dtype: torch.dtype, layout) -> bool:
-    """Should (and can) aggf_gram_gather take this trajectory / layout?  OPT-IN, AGGF_GRAM_GATHER=1 in the
-    environment: measured on MI355X (tools/gather_bench.py, profiles/r03_gather_vs_packed.txt) the fused kernel
-    reaches 0.30-0.72 of the MFMA peak where the packed copy + panel kernel reach 0.40-0.82 INCLUDING the pack pass
-    (the member sums are redone in every tile column, on the SIMD that issues the MFMAs), so the packed pipeline
-    stays the default; the fused kernel is for trajectories that leave no HBM for the packed
-    chunk (it needs the tile table and the slabs only)."""
-    import os
-
-    if layout is None or os.environ.get("AGGF_GRAM_GATHER", "0") != "1" or not forces.is_contiguous():
-        return False
-    if forces.data_ptr() % 16 or forces.shape[1] != layout["n_fg"]:
-        return False
-    T, N, _ = forces.shape
-    return bool(lib().aggf_gram_gather_supported(T, N, n_red, dtype_code(forces.dtype), dtype_code(compute_dtype),
-                                                 layout["mm"], layout["span"]))
-
-
-def gram_gather(forces: torch.Tensor, layout_dev, layout, n_red: int, compute_dtype: torch.dtype,
-                out: Optional[torch.Tensor] = None, accumulate: bool = False) -> torch.Tensor:
-    """G (n_red, n_red) float64 through the fused tile kernel (aggf_gram_gather): constraint sums, float32 -> float64
-    conversion and padding inside the MFMA operand read, no packed copy.  ``layout_dev`` = (col_off, panel_lo) on
-    the device, ``layout`` the host dict of :func:`gather_layout`."""
-    l = lib()
-    T, N, _ = forces.shape
-    if out is None:
-        out = torch.empty((n_red, n_red), dtype=torch.float64, device=forces.device)
-        accumulate = False
-    cd = dtype_code(compute_dtype)
-    need = l.aggf_gram_gather_workspace_bytes(T, n_red, cd)
-    ws = workspace(need, forces.device, "gram")
-    with _timed("gram"):
-        check(l.aggf_gram_gather(ptr(forces), T, N, dtype_code(forces.dtype), cd, ptr(layout_dev[0]), layout["mm"],
-                                 ptr(layout_dev[1]), layout["span"], n_red, ptr(out), 1 if accumulate else 0, ptr(ws), need,
-                                 stream_ptr()), "aggf_gram_gather")
-    return out
-
-
-# ------------------------------------------------------------------ K2 solve
-
-
 def eq_qp_solve(
     G: torch.Tensor,
     l2: float,
@@ -403,7 +333,10 @@ def linearmap_apply(
     return (out, sumsq) if want_sumsq else out
 
 
-def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype) -> torch.Tensor:
+def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype,
+                 nan_probe: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[t, c, :] = points[t, idx[c], :] (aggf_slice_gather).  ``nan_probe``: zeroed int32 device scalar (from
+    :func:`take_flag`) that is set to 1 if a gathered value is NaN -- the scan rides along with the gather."""
     l = lib()
     T, N, D = points.shape
     n_cg = idx.numel()
@@ -413,7 +346,7 @@ def slice_gather(points: torch.Tensor, idx: torch.Tensor, out_dtype: torch.dtype
     with _timed("gather"):
         check(
             l.aggf_slice_gather(ptr(points), T, N, dtype_code(points.dtype), ptr(idx), n_cg, dtype_code(out_dtype),
-                                ptr(out), stream_ptr()),
+                                ptr(out), ptr(nan_probe), stream_ptr()),
             "aggf_slice_gather",
         )
     return out

@@ -30,9 +30,6 @@ PROTOTYPES = {
     "aggf_device_info": (C.c_int, [C.POINTER(_i32), C.POINTER(_sz), C.POINTER(_sz)]),
     "aggf_gram_workspace_bytes": (_sz, [_i64, _i32, _i32, C.c_int, C.c_int, C.c_int]),
     "aggf_gram": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _vp, _vp, _i32, _vp, C.c_int, _vp, _sz, _vp]),
-    "aggf_gram_gather_supported": (C.c_int, [_i64, _i32, _i32, C.c_int, C.c_int, _i32, _i32]),
-    "aggf_gram_gather_workspace_bytes": (_sz, [_i64, _i32, C.c_int]),
-    "aggf_gram_gather": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _vp, _i32, _vp, _i32, _i32, _vp, C.c_int, _vp, _sz, _vp]),
     "aggf_gram_from_column": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _i32, _i32, _vp, C.c_int, _vp, _sz, _vp]),
     "aggf_eq_qp_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "aggf_eq_qp_solve": (C.c_int, [_vp, _i32, _dbl, _vp, _vp, _i32, _vp, _i32, _dbl, _i32, _vp, _vp, _vp, _sz, _vp]),
@@ -44,7 +41,7 @@ PROTOTYPES = {
     "aggf_expand_map": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _vp]),
     "aggf_linearmap_apply_workspace_bytes": (_sz, [_i64, _i32, _i32]),
     "aggf_linearmap_apply": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, C.c_int, _dbl, _vp, _vp, _vp, _vp, _sz, _vp]),
-    "aggf_slice_gather": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, _vp, _vp]),
+    "aggf_slice_gather": (C.c_int, [_vp, _i64, _i32, C.c_int, _vp, _i32, C.c_int, _vp, _vp, _vp]),
     "aggf_has_nan": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
     "aggf_not_close": (C.c_int, [_vp, _vp, _i64, C.c_int, _dbl, _dbl, _vp, _vp]),
     "aggf_sumsq_workspace_bytes": (_sz, []),

@@ -13,7 +13,8 @@ import numpy as np
 
 from . import _kernels as K
 from .constraints import Constraints, guess_pairwise_constraints
-from .distributed import all_reduce_sum_, all_reduce_sum_sym_
+from .distributed import (all_reduce_sum_, all_reduce_sum_sym_, cancel_overlap, overlap_with_next_collective,
+                          world_size)
 from .map import LinearMap, SeperableTMap, TMap
 from .qp import qp_linear_map
 from .trajectory import Trajectory
@@ -87,9 +88,30 @@ def project_forces(
     with K.upload_cache():
         t = Trajectory(coords=coords, forces=forces)
         fused_ss = None  # sum of squares of the mapped forces when the apply kernel accumulated it
-        traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
-        pending = None
-        if type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map and isinstance(coord_map, LinearMap):
+        # Frames sharded over ranks: the coordinate gather of a slice map starts when the fit reaches its Gram
+        # all-reduce (link-bound, compute units idle) and runs beside it on the side stream.
+        early = {}
+        hook = None
+        if world_size(kwargs.get("comm")) > 1 and isinstance(coord_map, LinearMap) and method is qp_linear_map:
+            def hook():
+                early["pending"] = coord_map.map_async(t.coords)
+
+            overlap_with_next_collective(hook)
+        try:
+            traj_map: TMap = method(traj=t, coord_map=coord_map, constraints=constrained_inds, **kwargs)
+        except BaseException:
+            if early.get("pending") is not None:
+                early["pending"].discard()
+            raise
+        finally:
+            if hook is not None:
+                cancel_overlap(hook)
+        pending = early.get("pending")
+        if pending is not None and not (type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map):
+            pending.discard()
+            pending = None
+        elif (pending is None and type(traj_map) is SeperableTMap and traj_map.coord_map is coord_map
+              and isinstance(coord_map, LinearMap)):
             # a slice map's gather (HBM-bound) goes to a side stream underneath the force apply (MFMA-bound):
             # c3 869 ms/step against 874-878 one after the other; started before the fit it slows the
             # Gram kernel by as much as it saves (872-876), underneath the solve it doubles the solve (874-876)

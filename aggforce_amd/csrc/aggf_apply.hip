@@ -35,7 +35,7 @@ __device__ unsigned long long aggf_apply_prof[5];
 #endif
 
 template <typename TIn, typename TC, bool NANREP, int AP_THREADS, int AP_TC, int AP_WF = 4>
-__global__ __launch_bounds__(AP_THREADS, (AP_TC >= 256 && AP_THREADS == 512) ? 2 : (AP_THREADS >= 1024 || AP_WF < 4) ? 4 : 2) void apply_kernel(
+__global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg,
     int32_t ncb, TC nan_fill, int p_vec_ok, int m_vec_ok, TC* __restrict__ out,
     double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
@@ -309,19 +309,42 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
   if (threadIdx.x == 0) out[0] = sh[0];
 }
 
+// K3b: one-hot (slice) maps -- out[t, c, :] = P[t, idx[c], :] (map/core.py:219-240 on a map whose rows are unit
+// vectors).  A thread owns ONE element position e = 3 c + d of the output row for a strided set of frames: its source
+// offset 3 idx[c] + d is looked up once, outside the frame loop (the first version divided a 64-bit element index per
+// element), and the loop body is UF independent 4/8-byte loads followed by UF stores -- consecutive threads read the
+// three components of one atom, then the next selected atom, and write consecutive elements.  Loads and stores are
+// non-temporal: every byte is used once, and the kernel runs on a side stream beside K1 / K3, whose panels live in
+// the L2.  Fused NaN scan of the gathered values (the slice map's NaN policy: a NaN at a SELECTED site is the case
+// in which the reference's NaN -> 0 / NaN -> -1 products differ, map/core.py:226-236).
+constexpr int SG_UF = 8;
+
 template <typename TIn, typename TO>
 __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict__ P, int64_t T,
                                                            int32_t N, const int32_t* __restrict__ idx,
-                                                           int32_t n_cg, TO* __restrict__ out) {
-  const int64_t row_out = (int64_t)n_cg * 3;
-  const int64_t total = T * row_out;
-  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-       i += (int64_t)gridDim.x * blockDim.x) {
-    const int64_t t = i / row_out;
-    const int e = (int)(i - t * row_out);
-    const int c = e / 3, d = e - 3 * c;
-    out[i] = (TO)P[(t * N + idx[c]) * 3 + d];
+                                                           int32_t n_cg, TO* __restrict__ out,
+                                                           int32_t* __restrict__ nan_seen) {
+  const int row_out = n_cg * 3;
+  const int e = blockIdx.y * 256 + threadIdx.x;
+  const bool valid = e < row_out;
+  const int c = valid ? e / 3 : 0;
+  const int64_t off = (int64_t)idx[c] * 3 + (e - 3 * c);
+  const int64_t row_in = (int64_t)N * 3;
+  bool saw_nan = false;
+  for (int64_t t0 = (int64_t)blockIdx.x * SG_UF; t0 < T; t0 += (int64_t)gridDim.x * SG_UF) {
+    TIn v[SG_UF];
+#pragma unroll
+    for (int u = 0; u < SG_UF; ++u) {
+      v[u] = (TIn)0;
+      if (valid && t0 + u < T) v[u] = __builtin_nontemporal_load(P + (t0 + u) * row_in + off);
+    }
+#pragma unroll
+    for (int u = 0; u < SG_UF; ++u) {
+      saw_nan |= (v[u] != v[u]);
+      if (valid && t0 + u < T) __builtin_nontemporal_store((TO)v[u], out + (t0 + u) * row_out + e);
+    }
   }
+  if (nan_seen && __any(saw_nan) && (threadIdx.x & 63) == 0) atomicOr(nan_seen, 1);
 }
 
 // ---------------------------------------------------------------------------
@@ -583,32 +606,17 @@ template <typename TIn, typename TC>
 static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
                        int nan_mode, double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
                        void* ws, size_t ws_bytes, hipStream_t stream) {
-  // 64 frames x 128 sites with 16 waves (4 per SIMD; c3: 102.4 ms, 8 waves: 104.5 ms) when n_cg > 64,
-  // else 64 x 64 with 4 waves.  AGGF_APPLY_TILE = "wide" | "big" (8 waves) | "small" overrides (benchmarks).
-  static const char* force = getenv("AGGF_APPLY_TILE");
+  // 64 frames x 128 sites with 16 waves (4 per SIMD) when n_cg > 64, else 64 x 64 with 4 waves.  Measured and dropped
+  // (profiles/r04_pruned_variants.patch): 8 waves on 64 x 128 (104.5 against 102.4 ms at c3), 32 x 128 with two
+  // workgroups per CU (103 ms), 64 x 256 at 4 waves per SIMD (spills: 282 ms), 32 x 256 at 2 waves per SIMD (P read
+  // once, 232 registers: 109.8 against 108.4 ms).
   // few sites: the streaming kernel (frames of a stage must fit AS_NV 16-byte loads per thread; P 16-byte aligned)
-  if (!force && n_cg <= 16 && (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) <= (int64_t)AS_NV * AS_THREADS * 16 &&
+  if (n_cg <= 16 && (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) <= (int64_t)AS_NV * AS_THREADS * 16 &&
       (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) >= 16 && (((uintptr_t)P & 15) == 0) && T >= 64)
     return apply_small_launch<TIn, TC>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
-  // (32 frames x 128 sites with 8 waves -- two independent workgroups per CU -- measured the same 103 ms)
-  const int tile = force ? (force[0] == 'h' ? 4 : force[0] == 'a' ? 3 : force[0] == 'w' ? 2 : force[0] == 'b' ? 1 : 0) : (n_cg > 64 ? 2 : 0);
-  // "huge": 32 frames x 256 sites with 8 waves at TWO waves per SIMD (the 12 accumulator tiles of a wave + staging =
-  // ~170 registers), one workgroup per CU: P is read once for n_cg <= 256, 7 operand reads per 12 MFMAs
-  // (64 frames x 256 sites needs 270 registers: 928 spilled at the 256 of two waves per SIMD)
-  if (tile == 4)
-    return apply_launch<TIn, TC, 512, 256, 2>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
-                                              ws_bytes, stream);
-  // "all": one workgroup over 256 sites, so that P is read once for n_cg <= 256.  Measured at C3:
-  // see DESIGN section 8 -- 96 accumulator registers + staging at 4 waves per SIMD.
-  if (tile == 3)
-    return apply_launch<TIn, TC, 1024, 256>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
-                                            ws_bytes, stream);
-  if (tile == 2)
+  if (n_cg > 64)
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);
-  if (tile == 1)
-    return apply_launch<TIn, TC, 512, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
-                                           ws_bytes, stream);
   return apply_launch<TIn, TC, 256, 64>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                         ws_bytes, stream);
 }
@@ -647,22 +655,28 @@ extern "C" int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_
 
 extern "C" int aggf_slice_gather(const void* P, int64_t T, int32_t N, int in_dtype,
                                  const int32_t* idx, int32_t n_cg, int out_dtype, void* out,
-                                 void* stream_v) {
+                                 int32_t* nan_seen, void* stream_v) {
   hipStream_t stream = (hipStream_t)stream_v;
   if (!P || !idx || !out) return fail(AGGF_ERR_ARG, "aggf_slice_gather: NULL pointer");
   if (T <= 0 || N <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_slice_gather: empty problem");
-  const int64_t total = T * (int64_t)n_cg * 3;
-  int64_t g = ceil_div(total, 256);
-  if (g > 8192) g = 8192;
-  const dim3 grid((unsigned)g), block(256);
+  const int64_t gy = ceil_div((int64_t)n_cg * 3, 256);
+  if (gy > 65535) return fail(AGGF_ERR_ARG, "aggf_slice_gather: too many sites");
+  // enough workgroups to keep the memory system busy on their own (8 frames in flight per thread), few enough that
+  // the kernel stays a guest beside a compute kernel on another stream; AGGF_GATHER_WGS overrides (benchmarks)
+  static const char* force = getenv("AGGF_GATHER_WGS");
+  int64_t gx = force ? atoll(force) : 4 * (int64_t)device_cu_count() / gy;
+  const int64_t need = ceil_div(T, SG_UF);
+  if (gx > need) gx = need;
+  if (gx < 1) gx = 1;
+  const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out);
+    hipLaunchKernelGGL((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out, nan_seen);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out);
+    hipLaunchKernelGGL((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out, nan_seen);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out);
+    hipLaunchKernelGGL((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out, nan_seen);
   else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out);
+    hipLaunchKernelGGL((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out, nan_seen);
   else
     return fail(AGGF_ERR_ARG, "aggf_slice_gather: unsupported dtype combination");
   AGGF_LAUNCH_OK();

@@ -148,225 +148,8 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
 
 // Factor one 64x64 diagonal block: A_kk = L L' (lower), and Linv = L^-1.
 // info[0]: 1-based global index of the first non-positive pivot (0 = ok).
-//
-// ONE wave, the block in registers: lane i holds row i (64 doubles); the loops are fully unrolled,
-// so every register index is static.  Column j: pivot by v_readlane from lane j, the scaled column
-// goes through a 64-entry LDS buffer and comes back as uniform-address (broadcast) reads for the
-// rank-1 update -- one LDS round trip per column and no multi-wave barrier (the 256-thread LDS
-// version spent ~1.2 us per column, 80 us per block, 5.4 ms of a 12 ms solve at n = 4096; reading
-// the column with v_readlane instead costs two SGPR hazards per element).  The inverse is a forward
-// substitution with lane c holding column c of L^-1 and L[i][k] broadcast from LDS.
-__device__ __forceinline__ double lane_bcast(double v, int src_lane) {
-  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
-  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
-  return __hiloint2double(hi, lo);
-}
-
-__global__ __launch_bounds__(64) void potrf_diag_kernel(double* __restrict__ Akk, int64_t lda,
-                                                        double* __restrict__ Linv,
-                                                        double* __restrict__ info, int pivot_base,
-                                                        int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
-  __shared__ double a[NB][NB + 1];
-  __shared__ double colbuf[2][NB];
-  const int lane = threadIdx.x;
-  Akk += blockIdx.x * a_ps;    // blockIdx.x = problem of a batched solve
-  Linv += blockIdx.x * linv_ps;
-  info += blockIdx.x * info_ps;
-  for (int row = 0; row < NB; ++row) a[row][lane] = (lane <= row) ? Akk[(int64_t)row * lda + lane] : 0.0;
-  __syncthreads();
-  double r[NB];
-#pragma unroll
-  for (int k = 0; k < NB; ++k) r[k] = a[lane][k];
-  double rinv = 0.0;  // lane j keeps 1 / L[j][j]
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double d = lane_bcast(r[j], j);
-    if (!(d > 0.0)) {
-      if (lane == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + j + 1);
-      d = 1.0;
-    }
-    // 1/sqrt(d): hardware estimate + two Newton steps (the IEEE divide + sqrt sequence is ~4x longer
-    // and sits on the 64-step dependency chain)
-    double rs = __builtin_amdgcn_rsq(d);
-    double e = fma(-d * rs, rs, 1.0);
-    rs = fma(rs * e, fma(e, 0.375, 0.5), rs);
-    e = fma(-d * rs, rs, 1.0);
-    rs = fma(rs * 0.5, e, rs);
-    r[j] = (lane == j) ? d * rs : r[j] * rs;  // column j of L (rows above the diagonal: unused values)
-    if (lane == j) rinv = rs;
-    colbuf[j & 1][lane] = r[j];
-    __syncthreads();  // one wave: orders the LDS write before the broadcast reads
-#pragma unroll
-    for (int k = j + 1; k < NB; ++k)
-      r[k] = fma(-r[j], colbuf[j & 1][k], r[k]);  // A[i][k] -= L[i][j] L[k][j]; only rows i >= k are ever read
-  }
-  __syncthreads();
-#pragma unroll
-  for (int k = 0; k < NB; ++k) a[lane][k] = (k <= lane) ? r[k] : 0.0;
-  __syncthreads();
-  for (int row = 0; row < NB; ++row)
-    if (lane <= row) Akk[(int64_t)row * lda + lane] = a[row][lane];
-  // X = L^-1 by forward substitution; x[k] of lane c is X[k][c] (zero for k < c by construction)
-  double x[NB];
-#pragma unroll
-  for (int i = 0; i < NB; ++i) {
-    double sum = (lane == i) ? 1.0 : 0.0;
-#pragma unroll
-    for (int k = 0; k < i; ++k) sum = fma(-a[i][k], x[k], sum);
-    x[i] = sum * lane_bcast(rinv, i);
-    Linv[i * NB + lane] = x[i];
-  }
-}
-
-// The same factorisation and inverse, blocked 16 x 16 inside the 64 x 64 block and spread over 4 waves (default;
-// AGGF_POTRF=wave selects the one-wave kernel above): 35.5 against 40.3 us per block (rocprofv3, n = 1024).  A 16 x 16
-// diagonal sub-block is factored AND inverted inside 16 lanes (v_readlane broadcasts), the panel below it is a
-// product with that inverse (independent entries; a row-wise triangular solve is a chain of 136 FMAs), the trailing
-// update is one (i, j) entry per thread, and the rest of the inverse comes from three levels of 16 x 16 block
-// products.  In-kernel cycle counts of one block: load 6.2 k, the four diagonal sub-blocks 45.7 k (the 16-lane serial
-// part: ~40 cycles per readlane + FMA pair), panels 5.7 k, trailing updates 14.5 k, inverse levels 12.7 k, stores
-// 4.5 k -- the next step would be the diagonal sub-blocks on all 64 lanes of the wave through an LDS column buffer.
-constexpr int PB = 16;
-constexpr int POTRF_LDS = 2 * NB * (NB + 1) * (int)sizeof(double);
-__global__ __launch_bounds__(256) void potrf_diag_blocked_kernel(double* __restrict__ Akk, int64_t lda,
-                                                                double* __restrict__ Linv,
-                                                                double* __restrict__ info, int pivot_base,
-                                                                int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
-  extern __shared__ __attribute__((aligned(16))) char potrf_smem[];
-  double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem);                       // A, then L (lower)
-  double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem) + NB;                  // L^-1
-  const int tid = threadIdx.x;
-  Akk += blockIdx.x * a_ps;  // blockIdx.x = problem of a batched solve
-  Linv += blockIdx.x * linv_ps;
-  info += blockIdx.x * info_ps;
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e - r * NB;
-    a[r][c] = (c <= r) ? Akk[(int64_t)r * lda + c] : 0.0;
-    x[r][c] = 0.0;
-  }
-  __syncthreads();
-  for (int kb = 0; kb < NB / PB; ++kb) {
-    const int k0 = kb * PB;
-    // 1. diagonal sub-block and its inverse: lanes 0..15 of wave 0, the 16 columns in registers
-    if (tid < PB) {
-      double r[PB];  // row tid of the sub-block
-#pragma unroll
-      for (int c = 0; c < PB; ++c) r[c] = a[k0 + tid][k0 + c];
-      double rinv = 0.0;  // lane j keeps 1 / L[j][j]
-#pragma unroll
-      for (int j = 0; j < PB; ++j) {
-        double d = lane_bcast(r[j], j);
-        if (!(d > 0.0)) {
-          if (tid == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + k0 + j + 1);
-          d = 1.0;
-        }
-        // 1/sqrt(d): hardware estimate + two Newton steps
-        double rs = __builtin_amdgcn_rsq(d);
-        double e = fma(-d * rs, rs, 1.0);
-        rs = fma(rs * e, fma(e, 0.375, 0.5), rs);
-        e = fma(-d * rs, rs, 1.0);
-        rs = fma(rs * 0.5, e, rs);
-        r[j] = (tid == j) ? d * rs : r[j] * rs;  // column j of L (rows above the diagonal: unused values)
-        if (tid == j) rinv = rs;
-#pragma unroll
-        for (int k = j + 1; k < PB; ++k) r[k] = fma(-r[j], lane_bcast(r[j], k), r[k]);  // only rows i >= k are ever read
-      }
-#pragma unroll
-      for (int c = 0; c < PB; ++c) a[k0 + tid][k0 + c] = (c <= tid) ? r[c] : 0.0;
-      // inverse, lane = column c: right-looking forward substitution, L[i][k] broadcast from the lane that holds row i
-      double sv[PB];
-#pragma unroll
-      for (int i = 0; i < PB; ++i) sv[i] = (i == tid) ? 1.0 : 0.0;
-#pragma unroll
-      for (int k = 0; k < PB; ++k) {
-        const double xk = sv[k] * lane_bcast(rinv, k);
-        x[k0 + k][k0 + tid] = xk;
-#pragma unroll
-        for (int i = k + 1; i < PB; ++i) sv[i] = fma(-lane_bcast(r[k], i), xk, sv[i]);
-      }
-    }
-    __syncthreads();
-    const int nt = NB - k0 - PB;  // rows below the sub-block
-    // 2. panel below: P = A_panel inv(L_kk)', P[i][j] = sum_{m <= j} A[i][m] X[j][m]: independent entries (the
-    //    row-wise triangular solve is a chain of 136 FMAs with an LDS read in front of each)
-    {
-      double pv[3];
-      int np = 0;
-      for (int e = tid; e < nt * PB; e += 256) {
-        const int ii = e / PB, j = e - ii * PB, i = k0 + PB + ii;
-        double sacc = 0.0;
-#pragma unroll
-        for (int m = 0; m < PB; ++m) sacc = fma(a[i][k0 + m], x[k0 + j][k0 + m], sacc);  // X is lower: zeros for m > j
-        pv[np++] = sacc;
-      }
-      __syncthreads();
-      np = 0;
-      for (int e = tid; e < nt * PB; e += 256) {
-        const int ii = e / PB, j = e - ii * PB;
-        a[k0 + PB + ii][k0 + j] = pv[np++];
-      }
-    }
-    __syncthreads();
-    // 3. trailing block -= P P' (lower part), one entry per thread and pass
-    for (int e = tid; e < nt * nt; e += 256) {
-      const int ii = e / nt, jj = e - ii * nt;
-      if (jj <= ii) {
-        const int i = k0 + PB + ii, j = k0 + PB + jj;
-        double sacc = a[i][j];
-#pragma unroll
-        for (int m = 0; m < PB; ++m) sacc = fma(-a[i][k0 + m], a[j][k0 + m], sacc);
-        a[i][j] = sacc;
-      }
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e - r * NB;
-    if (c <= r) Akk[(int64_t)r * lda + c] = a[r][c];
-  }
-  // sub-blocks of the inverse below the diagonal, by distance d from it:
-  //   X(bi,bj) = -X(bi,bi) * sum_{k = bj}^{bi-1} L(bi,k) X(k,bj)
-  for (int d = 1; d < NB / PB; ++d) {
-    const int nblk = NB / PB - d;
-    // (a) W = sum_k L(bi,k) X(k,bj), parked in X(bi,bj)
-    for (int e = tid; e < nblk * PB * PB; e += 256) {
-      const int bj = e / (PB * PB), rc = e - bj * PB * PB, r = rc / PB, c = rc - r * PB, bi = bj + d;
-      double w = 0.0;
-      for (int kb = bj; kb < bi; ++kb) {
-#pragma unroll
-        for (int m = 0; m < PB; ++m) w = fma(a[bi * PB + r][kb * PB + m], x[kb * PB + m][bj * PB + c], w);
-      }
-      x[bi * PB + r][bj * PB + c] = w;
-    }
-    __syncthreads();
-    // (b) X(bi,bj) = -X(bi,bi) W: read the column of W, barrier, write in place
-    double out[3];
-    int n_out = 0;
-    for (int e = tid; e < nblk * PB * PB; e += 256) {
-      const int bj = e / (PB * PB), rc = e - bj * PB * PB, r = rc / PB, c = rc - r * PB, bi = bj + d;
-      double w = 0.0;
-#pragma unroll
-      for (int m = 0; m < PB; ++m) w = fma(-x[bi * PB + r][bi * PB + m], x[bi * PB + m][bj * PB + c], w);  // X(bi,bi) lower
-      out[n_out++] = w;
-    }
-    __syncthreads();
-    n_out = 0;
-    for (int e = tid; e < nblk * PB * PB; e += 256) {
-      const int bj = e / (PB * PB), rc = e - bj * PB * PB, r = rc / PB, c = rc - r * PB, bi = bj + d;
-      x[bi * PB + r][bj * PB + c] = out[n_out++];
-    }
-    __syncthreads();
-  }
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e - r * NB;
-    Linv[r * NB + c] = x[r][c];
-  }
-}
-
-// Third version of the diagonal-block kernel (default since round 3; AGGF_POTRF=blocked / wave select the older ones).
-// In-kernel cycle counts of the blocked version above: the four 16 x 16 diagonal sub-blocks 45.7 k of 89 k cycles (16
-// lanes, a v_readlane + FMA pair every ~40 cycles), the block products (panels, trailing updates, inverse levels) 33 k
-// as scalar FMAs with two LDS reads each.  Here
+// (Rounds 1-2 had a one-wave register version -- 35.5 us per block -- and a 256-thread version whose block products
+// were scalar FMAs -- 40.3 us: profiles/r04_pruned_variants.patch.)  Here
 //  * a 16 x 16 sub-block is factored AND inverted by all 256 threads, thread (i, c) owning entry (i, c) of the block and
 //    of the running inverse Z (Z starts as the identity and receives the same row operations): per column one 16-entry
 //    column buffer + one 16-entry Z-row buffer in LDS and ONE barrier; every thread recomputes the pivot's 1/sqrt itself;
@@ -374,6 +157,7 @@ __global__ __launch_bounds__(256) void potrf_diag_blocked_kernel(double* __restr
 //    16 x 16 output tile per wave and pass.  The second product of an inverse level, X(bi,bi) W, takes W from the
 //    accumulator registers of the first: the contraction index is walked in the order the D layout holds it
 //    (k = (lane >> 4) + 4 r), so no LDS round trip is needed.
+constexpr int PB = 16;
 __device__ __forceinline__ double rsqrt_newton(double d) {
   double rs = __builtin_amdgcn_rsq(d);
   double e = fma(-d * rs, rs, 1.0);
@@ -805,33 +589,16 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
     for (int k = k0; k < kend && !c.rc; ++k) {
       const Mat Akk = P.at((int64_t)k * NB, (int64_t)k * NB);
       const Mat Dk{Dinv.p + (int64_t)k * NB * NB, NB, Dinv.ps};
-      static const char* potrf_env = getenv("AGGF_POTRF");
-      if (potrf_env && potrf_env[0] == 'w') {
-        hipLaunchKernelGGL(potrf_diag_kernel, dim3(c.nprob), dim3(64), 0, c.stream, Akk.p, (int64_t)npad, Dk.p,
-                           info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
-      } else if (!(potrf_env && potrf_env[0] == 'b')) {
-        static thread_local PerDeviceOnce attr_once3;
-        bool& attr_done3 = *attr_once3.flag();
-        if (!attr_done3) {
-          if (hipFuncSetAttribute((const void*)potrf_diag_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  POTRF3_LDS) != hipSuccess)
-            c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
-          attr_done3 = true;
-        }
-        hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, (int64_t)npad,
-                           Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
-      } else {
-        static thread_local PerDeviceOnce attr_once;
-        bool& attr_done = *attr_once.flag();
-        if (!attr_done) {
-          if (hipFuncSetAttribute((const void*)potrf_diag_blocked_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  POTRF_LDS) != hipSuccess)
-            c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
-          attr_done = true;
-        }
-        hipLaunchKernelGGL(potrf_diag_blocked_kernel, dim3(c.nprob), dim3(256), POTRF_LDS, c.stream, Akk.p,
-                           (int64_t)npad, Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
+      static thread_local PerDeviceOnce attr_once3;
+      bool& attr_done3 = *attr_once3.flag();
+      if (!attr_done3) {
+        if (hipFuncSetAttribute((const void*)potrf_diag_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                POTRF3_LDS) != hipSuccess)
+          c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
+        attr_done3 = true;
       }
+      hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, (int64_t)npad,
+                         Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
       if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
       const int rem = npad - (k + 1) * NB + extra_rows;
       if (rem <= 0) break;

@@ -50,8 +50,47 @@ def all_reduce_sum_(t: torch.Tensor, comm) -> torch.Tensor:
     import torch.distributed as dist
 
     if dist.get_world_size(group) > 1:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+        _run_overlap_hooks()
+        with _stage(t):
+            dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
+
+
+# Work that does not depend on the reduced matrix and may run BESIDE the collective: project_forces registers the
+# slice-map gather of the coordinates here (HBM-bound, a side stream), so the Gram all-reduce -- link-bound, the
+# compute units idle -- hides behind it instead of standing alone between K1 and K2.  Each hook runs once, in front of
+# the first multi-rank collective after it was registered.
+_overlap_hooks: list = []
+
+
+def overlap_with_next_collective(thunk) -> None:
+    _overlap_hooks.append(thunk)
+
+
+def cancel_overlap(thunk) -> bool:
+    """Remove a hook that no collective has consumed; True if it was still waiting."""
+    if thunk in _overlap_hooks:
+        _overlap_hooks.remove(thunk)
+        return True
+    return False
+
+
+def _run_overlap_hooks() -> None:
+    while _overlap_hooks:
+        _overlap_hooks.pop(0)()
+
+
+def _stage(t: torch.Tensor):
+    """HIP-event bracket "allreduce" (pack + collective + unpack) on the launching stream, when bench.py's stage
+    timers are on and the payload lives on the device; torch.distributed makes that stream wait for the collective, so
+    the closing event sees its end."""
+    import contextlib
+
+    if not t.is_cuda:
+        return contextlib.nullcontext()
+    from . import _kernels as K
+
+    return K._timed("allreduce")
 
 
 def all_reduce_sum_sym_(G: torch.Tensor, comm) -> torch.Tensor:
@@ -75,9 +114,11 @@ def all_reduce_sum_sym_(G: torch.Tensor, comm) -> torch.Tensor:
         return all_reduce_sum_(G, comm)
     from . import _kernels as K
 
-    packed = K.sym_pack_upper(G)
-    dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
-    return K.sym_unpack_upper(packed, G)
+    _run_overlap_hooks()
+    with _stage(G):
+        packed = K.sym_pack_upper(G)
+        dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
+        return K.sym_unpack_upper(packed, G)
 
 
 def all_reduce_minmax_(lo: torch.Tensor, hi: torch.Tensor, comm) -> None:

@@ -223,8 +223,9 @@ class LinearMap:
             if hit is None or hit[0] is not self._standard_matrix:
                 hit = (self._standard_matrix, torch.from_numpy(idx).to(p.device))
                 self._dev_cache[key] = hit
-            out = K.slice_gather(p, hit[1], out_t)
-            if K.has_nan(out):
+            probe = K.take_flag(p.device)
+            out = K.slice_gather(p, hit[1], out_t, nan_probe=probe)
+            if K.read_flag(probe):
                 raise ValueError(
                     "NaN handling is on and results seem to depend on NaN "
                     "positions in input array. Check input and standard_matrix."
@@ -294,8 +295,8 @@ class LinearMap:
         side = K.side_stream(p.device)
         side.wait_stream(main)
         with torch.cuda.stream(side):
-            out = K.slice_gather(p, hit[1], out_t)
-            flag = K.nan_flag(out)
+            flag = K.take_flag(p.device)
+            out = K.slice_gather(p, hit[1], out_t, nan_probe=flag)
         p.record_stream(side)
         return _PendingMap(out, flag, side, points)
 

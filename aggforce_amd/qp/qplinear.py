@@ -144,7 +144,6 @@ class LinearProblem:
             self.grp_atoms = torch.from_numpy(self._csr[1]).to(device)
         self.sizes = torch.from_numpy(np.bincount(self.goa, minlength=self.n_red).astype(np.float64)).to(device)
         self._goa_d = None
-        self._gather = None  # (host layout, device arrays) of aggf_gram_gather, built on first use
         # a slice coordinate map (the map object caches its row -> atom index): A = M C has unit rows at the reduced
         # variables of the mapped atoms -- the pinned variables of aggf_eq_qp_solve_pinned; A itself is not formed
         self.pins = None
@@ -179,18 +178,6 @@ class LinearProblem:
         cdt = forces.dtype if gram_dtype is None else K.torch_dtype(gram_dtype)
         if forces.dtype == torch.float64:
             cdt = torch.float64
-        in_place = self.grp_ptr is None and self.n_fg % 128 == 0 and forces.dtype == cdt
-        if not in_place and self.n_red > 128:
-            # constraint groups, float32 -> float64, ragged site counts: the tile kernel that sums / converts / pads
-            # in its operand read (no packed copy of the trajectory), where the layout allows it
-            if self._gather is None:
-                lay = K.gather_layout(self.n_fg, self.n_red, self._csr)
-                dev = None if lay is None else (torch.from_numpy(lay["col_off"]).to(self.device),
-                                                torch.from_numpy(lay["panel_lo"]).to(self.device))
-                self._gather = (lay, dev)
-            lay, dev = self._gather
-            if K.gram_gather_ok(forces, self.n_red, cdt, lay):
-                return K.gram_gather(forces, dev, lay, self.n_red, cdt, out=out, accumulate=accumulate)
         return K.gram(forces, self.grp_ptr, self.grp_atoms, self.n_red, cdt, out=out, accumulate=accumulate)
 
     def solve(self, G, l2_regularization: float = 0.0):

@@ -516,6 +516,7 @@ def main():
                     "flops_per_launch": flops}
             if gram_note:
                 roof["launches"] = gram_note
+        per_step = {k: v["ms"] / args.steps for k, v in stages.items()}
         line = {
             "metric": "frames/sec through project_forces (Gram+solve), 1e6x4096-atom traj, 1/2/4/8 GPU",
             "value": T_total * args.steps / elapsed,
@@ -537,7 +538,13 @@ def main():
                 "variant": args.variant,
                 "n_red": n_gram,
                 "frames_per_gpu": T_local,
-                "stage_ms_per_step": {k: v["ms"] / args.steps for k, v in stages.items()},
+                "stage_ms_per_step": per_step,
+                # the terms of the strong-scaling model, read off this run instead of projected: what divides by the
+                # number of GPUs (gram, apply, gather, ...), what does not (the replicated solve + the host time between
+                # the stages: wall minus every stage of the main stream) and the collective (pack + all-reduce + unpack)
+                "allreduce_ms_per_step": per_step.get("allreduce", 0.0 if comm is None else None),
+                "replicated_ms_per_step": per_step.get("solve", 0.0) + max(0.0, 1e3 * elapsed / args.steps - sum(
+                    v for k, v in per_step.items() if k != "gather")),
                 "constraint_residual": cons_resid,
                 "residual": out["residual"],
                 "collective": ("REHEARSAL: gloo, all ranks on cuda:0 -- not a measurement" if args.rehearse_on_one_gpu

@@ -72,26 +72,6 @@ int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dty
               const int32_t* grp_ptr, const int32_t* grp_atoms, int32_t n_red, double* G,
               int accumulate, void* ws, size_t ws_bytes, void* stream);
 
-/* The same Gram matrix with the constraint-group sums (`@ con_mat`), the float32 -> float64 conversion and the
- * padding to whole 128-column tiles done INSIDE the tile kernel -- the raw frame rows travel HBM -> LDS as they lie
- * and the MFMA operand read adds up the members of a column -- instead of through aggf_gram's packed copy of the
- * trajectory.  The column layout is described by the caller (it is map-sized host logic, qplinear.py:147-164):
- *   col_off   (round_up(n_red, 128) x max_members) int32, device: col_off[c * max_members + j] = 3 * (atom of the
- *             j-th member of reduced column c) in the order `@ con_mat` adds them, -1 where there is none (all -1
- *             for the padding columns c >= n_red); max_members is 1, 2 or 4;
- *   panel_lo  (round_up(n_red, 128) / 128) int32, device: first atom of the window of each 128-column panel;
- *   span_atoms  every member atom of panel p lies in [panel_lo[p], panel_lo[p] + span_atoms).
- * aggf_gram_gather_supported: 1 if this (shape, dtypes, max_members, span_atoms) can take the kernel (more than 128
- * reduced columns, T * 3N * sizeof(in) a multiple of 16, two LDS stages of the window in 80 KB), else 0 -- then use
- * aggf_gram.  F must be 16-byte aligned.  Results equal aggf_gram's to rounding (same products, same member order;
- * the split over frame ranges may differ).  Workspace: aggf_gram_gather_workspace_bytes (tile table + slabs only). */
-int aggf_gram_gather_supported(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
-                               int32_t max_members, int32_t span_atoms);
-size_t aggf_gram_gather_workspace_bytes(int64_t T, int32_t n_red, int compute_dtype);
-int aggf_gram_gather(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype, const int32_t* col_off,
-                     int32_t max_members, const int32_t* panel_lo, int32_t span_atoms, int32_t n_red, double* G,
-                     int accumulate, void* ws, size_t ws_bytes, void* stream);
-
 /* The same Gram matrix when the caller already holds its leading first_col x first_col block
  * (first_col a multiple of 128): only the 128 x 128 tiles that reach column first_col or beyond
  * are computed and written (both triangles); G[0:first_col, 0:first_col] is left untouched.
@@ -206,9 +186,12 @@ int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype, cons
                          double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, void* stream);
 
 /* K3b  one-hot rows (slice maps): out[t,c,:] = P[t, idx[c], :], converted to
- * out_dtype.  Same call site as K3 when every row of M is a unit vector. */
+ * out_dtype.  Same call site as K3 when every row of M is a unit vector.  0 <= idx[c] < N (not
+ * checked on the device).  nan_seen (may be NULL; zeroed by the caller): set to 1 when a GATHERED
+ * value is NaN -- for a slice map exactly the case in which the reference's NaN -> 0 and NaN -> -1
+ * products differ (map/core.py:226-236). */
 int aggf_slice_gather(const void* P, int64_t T, int32_t N, int in_dtype, const int32_t* idx,
-                      int32_t n_cg, int out_dtype, void* out, void* stream);
+                      int32_t n_cg, int out_dtype, void* out, int32_t* nan_seen, void* stream);
 
 /* flag[0] = 1 if any element of x is NaN (map/core.py:13-16 _has_nans); flag must be
  * zeroed by the caller. */

@@ -39,9 +39,15 @@ def test_bench_two_ranks_rehearsal_on_one_gpu():
     assert "REHEARSAL" in cfg["collective"] and cfg["frames_per_gpu"] == 2048
     assert cfg["constraint_residual"] < 1e-8
     assert "cpu_baseline" not in line                               # rank 0 at N = 1 only
+    # the strong-scaling terms are measured, not projected: a HIP-event "allreduce" stage (pack + collective + unpack)
+    # and the replicated part (solve + host time between the stages)
+    assert cfg["stage_ms_per_step"]["allreduce"] > 0 and cfg["allreduce_ms_per_step"] == cfg["stage_ms_per_step"]["allreduce"]
+    assert cfg["replicated_ms_per_step"] >= cfg["stage_ms_per_step"]["solve"] > 0
+    assert cfg["replicated_ms_per_step"] < line["ms_per_step"]
     # the same workload in one process: same residual (the Gram matrix is summed over the shards)
     one = run_bench("--workload", "tiny", "--steps", "2", "--warmup", "1", "--no-cpu-baseline")
-    assert one["n_gpus"] == 1 and one["config"]["backend"] is None
+    assert one["n_gpus"] == 1 and one["config"]["backend"] is None and one["config"]["allreduce_ms_per_step"] == 0.0
+    assert "allreduce" not in one["config"]["stage_ms_per_step"]
     assert abs(one["config"]["residual"] / cfg["residual"] - 1.0) < 1e-9
 
 

@@ -68,41 +68,21 @@ def test_batched_solve_redundant_rows_and_identity_rhs():
         K.eq_qp_solve_batched(torch.from_numpy(G2).cuda(), 0.0, None, torch.from_numpy(A2[:2]).cuda(), None)
 
 
-_POTRF_SCRIPT = r"""
-import sys, numpy as np, torch
-sys.path.insert(0, sys.argv[1])
-from aggforce_amd import _kernels as K
-rng = np.random.default_rng(3)
-out = {}
-for n, m in ((64, 3), (200, 17), (1000, 64)):
-    R = rng.standard_normal((3 * n, n))
-    G = torch.from_numpy(R.T @ R).cuda()
-    A = torch.from_numpy(rng.standard_normal((m, n))).cuda()
-    b = torch.from_numpy(np.eye(m)).cuda()
-    X, stats = K.eq_qp_solve(G, 1e-3, None, A, b, schur_reg=1e-12, n_refine=3)
-    out[f"x{n}"] = X.cpu().numpy()
-np.savez(sys.argv[2], **out)
-"""
-
-
-def test_diagonal_block_kernels_agree(tmp_path):
-    """The 64 x 64 diagonal-block factorisation has two implementations (default: blocked 16 x 16 over four waves;
-    AGGF_POTRF=wave: one wave, the block in registers): the solves they feed agree to rounding."""
-    import os
-    import subprocess
-    import sys
-
-    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    script = tmp_path / "potrf.py"
-    script.write_text(_POTRF_SCRIPT)
-    res = {}
-    for tag, env in (("blocked", dict(os.environ)), ("wave", dict(os.environ, AGGF_POTRF="wave"))):
-        env.pop("AGGF_POTRF", None) if tag == "blocked" else None
-        path = tmp_path / f"{tag}.npz"
-        run = subprocess.run([sys.executable, str(script), root, str(path)], env=env, capture_output=True, text=True,
-                             timeout=300)
-        assert run.returncode == 0, run.stdout[-1000:] + run.stderr[-2000:]
-        res[tag] = np.load(path)
-    for key in res["blocked"].files:
-        a, b = res["blocked"][key], res["wave"][key]
-        assert np.max(np.abs(a - b)) <= 1e-11 * np.max(np.abs(b)), key
+def test_general_solve_matches_oracle_across_block_counts():
+    """The blocked factorisation behind K2 (64-wide diagonal blocks, 256-wide outer panels, inverted diagonal blocks)
+    at sizes with 1, 4 and 16 diagonal blocks and ragged padding, against the oracle's exact equality-QP solve."""
+    rng = np.random.default_rng(3)
+    for n, m in ((64, 3), (200, 17), (1000, 64)):
+        R = rng.standard_normal((3 * n, n))
+        Gh = R.T @ R
+        Ah = rng.standard_normal((m, n))
+        X, stats = K.eq_qp_solve(torch.from_numpy(Gh).cuda(), 1e-3, None, torch.from_numpy(Ah).cuda(),
+                                 torch.from_numpy(np.eye(m)).cuda(), schur_reg=1e-12, n_refine=3)
+        X = X.cpu().numpy()
+        assert stats.cpu().numpy()[0] == 0
+        assert np.max(np.abs(Ah @ X.T - np.eye(m))) < 1e-9
+        for i in (0, m - 1):
+            e = np.zeros(m)
+            e[i] = 1.0
+            ref = orc.eq_qp_solve(Gh + 1e-3 * np.eye(n), None, Ah, e)
+            assert np.max(np.abs(X[i] - ref)) < 1e-7 * max(1.0, np.max(np.abs(ref))), (n, m, i)
