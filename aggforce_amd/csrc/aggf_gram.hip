@@ -164,6 +164,12 @@ __device__ __forceinline__ void wait_vmcnt_dyn(int n) {
   static_assert(MAXN <= 8, "extend the dispatch");
 }
 
+// AGGF_SMALL_ABL (tools/small_ablate.hip only; the library is built without it): the single-tile kernel with one of its
+// three co-limiting phases removed -- 1 = no MFMA phase (operand reads and MFMAs), 2 = no global loads after the first
+// stage (the fetched registers are re-parked), 3 = no group sums (the panel keeps its first contents).
+#ifndef AGGF_SMALL_ABL
+#define AGGF_SMALL_ABL 0
+#endif
 #ifdef AGGF_SMALL_PROF
 // tools/small_probe.hip: shader cycles per wave of the small-system kernel spent in park (incl. the wait for the
 // fetched frames) / group sums / MFMA / the three barriers, and the stage count
@@ -745,9 +751,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     AGGF_SP_T(q2);
     __syncthreads();
     AGGF_SP_T(q3);
-    if (s + 1 < n_it) fetch(s + 1);
+    if (s + 1 < n_it && (AGGF_SMALL_ABL != 2 || s == 0)) fetch(s + 1);
     AGGF_SP_T(q3b);
-    reduce_groups();
+    if (AGGF_SMALL_ABL != 3 || s == 0) reduce_groups();
     AGGF_SP_T(q4);
     __syncthreads();
     AGGF_SP_T(q5);
@@ -757,7 +763,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
       for (int d = 0; d < 3; ++d)
 #pragma unroll
         for (int k = 0; k < SM_MAXBLK; ++k)
-          if (b_i[k] >= 0) {
+          if (b_i[k] >= 0 && AGGF_SMALL_ABL != 1) {
             // (one LDS round trip per MFMA.  Tried: all operands of a group read first -- 20 more VGPRs, spills,
             // 5.8 -> 9.0 ms; one item ahead -- 10 spills, 6.5 ms; a compile-time block count with straight-line code --
             // the scheduler hoists every read: 79-108 spilled VGPRs.  The staged frames take the registers.)

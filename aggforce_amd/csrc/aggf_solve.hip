@@ -19,9 +19,11 @@ constexpr int NB = 64;          // Cholesky panel width == GEMM tile edge
 constexpr int GK = 16;          // GEMM K chunk
 constexpr int GS = GK + 2;      // LDS row stride of GEMM operand tiles (elements)
 
-// C[M x N] = alpha * op(A) op(B) + beta * C  (and the same values to C2 if non-null).
-// Row-major; M % 64 == 0, N % 64 == 0, K % 16 == 0.  op(A) is M x K, op(B) is K x N.
-// lower_only: skip tiles strictly above the block diagonal (square trailing updates).
+// C[M x N] = alpha * op(A) op(B) + beta * C.
+// Row-major; M % 64 == 0, N % 64 == 0, K % 16 == 0; every operand 16-byte aligned with an even leading dimension (the
+// solver pads every matrix to multiples of 64).  op(A) is M x K, op(B) is K x N.
+// lower_only: skip tiles strictly above the block diagonal and, on diagonal 128-tiles, the 64 x 64 quadrant above it
+// (square trailing updates).
 // blockIdx.z = problem * per_prob + z: operand X is offset by problem * x_p + (z / inner) * x_o +
 // (z % inner) * x_i elements (problem = one of the independent QPs of a batched solve; z = the
 // batched GEMMs of one algorithmic step inside a problem).
@@ -32,16 +34,30 @@ struct GemmBatch {
   int64_t a_p = 0, b_p = 0, c_p = 0;
 };
 
-template <bool TA, bool TB>
-__global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
-                                                        const double* A, int64_t lda,
-                                                        const double* B, int64_t ldb,
-                                                        double beta, double* C, int64_t ldc,
-                                                        double* C2, int64_t ldc2, int lower_only,
-                                                        GemmBatch bt) {
+// Two shapes of one kernel.  TM x TN = 128 x 128 with 8 waves (wave tile 64 x 32: 6 operand reads per 8 MFMAs, two
+// workgroups per CU) for everything that is at least 128 wide -- the trailing updates, the Schur products, the
+// triangular solves with many right-hand sides: the n^3 part; 64 x 64 with 4 waves (wave tile 32 x 32) for the 64-wide
+// panel steps.  (Until round 4 there was only the 64 x 64 shape, fed by 8-BYTE global loads: 0.07-0.35 of the fp64 MFMA
+// peak.)  Operand tiles travel global -> registers -> LDS with 16-byte loads, one stage (16 k) ahead of the MFMAs;
+// the refill and the barrier sit in front of the stage's last MFMA group, whose operands are in registers by then.
+// An operand that is contiguous along k is stored with ds_write_b128; one that is contiguous along the tile's
+// rows/columns (op = transpose) is transposed by the LDS store.  LDS rows are 18 elements apart: the operand reads
+// (lane = (row l & 15, k l >> 4)) touch 32 different bank pairs.
+template <bool TA, bool TB, int TM, int TN, int WM, int WN>
+__global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), 2) void gemm_tile_kernel(int M, int N, int K, double alpha,
+                                                                                 const double* A, int64_t lda,
+                                                                                 const double* B, int64_t ldb,
+                                                                                 double beta, double* C, int64_t ldc,
+                                                                                 int lower_only, GemmBatch bt) {
   using MF = Mfma<double>;
+  typedef double __attribute__((ext_vector_type(2))) d2;
+  constexpr int NWN = TN / WN, NW = (TM / WM) * NWN, THREADS = 64 * NW;
+  constexpr int AM = WM / 16, AN = WN / 16;
+  constexpr int CA = TM * 8 / THREADS, CB = TN * 8 / THREADS;  // 16-byte chunks per thread and stage
+  static_assert(TM * 8 % THREADS == 0 && TN * 8 % THREADS == 0, "chunk split");
   const int bi = blockIdx.y, bj = blockIdx.x;
-  if (lower_only && bj > bi) return;
+  const int64_t i0 = (int64_t)bi * TM, j0 = (int64_t)bj * TN;
+  if (lower_only && j0 > i0 + (TM - 64)) return;  // (tiles are squares here: strictly above the block diagonal)
   if (gridDim.z > 1) {
     const int prob = blockIdx.z / bt.per_prob, z = blockIdx.z % bt.per_prob;
     const int zo = z / bt.inner, zi = z % bt.inner;
@@ -49,62 +65,83 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
     B += prob * bt.b_p + zo * bt.b_o + zi * bt.b_i;
     C += prob * bt.c_p + zo * bt.c_o + zi * bt.c_i;
   }
-  __shared__ __attribute__((aligned(16))) double sA[2][64 * GS];
-  __shared__ __attribute__((aligned(16))) double sB[2][64 * GS];
+  extern __shared__ __attribute__((aligned(16))) char gemm_smem[];
+  double* sA = reinterpret_cast<double*>(gemm_smem);  // [2][TM * GS]
+  double* sB = sA + 2 * TM * GS;                      // [2][TN * GS]
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
-  const int64_t i0 = (int64_t)bi * 64, j0 = (int64_t)bj * 64;
+  const int wm = wave / NWN, wn = wave % NWN;
+  const int m_valid = (int)((M - i0) < TM ? (M - i0) : TM), n_valid = (int)((N - j0) < TN ? (N - j0) : TN);
 
-  double ra[4], rb[4];
+  d2 ra[CA], rb[CB];
   auto load_stage = [&](int k0) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + 256 * q;
+    for (int q = 0; q < CA; ++q) {
+      const int e = tid + THREADS * q;
+      d2 v = {0.0, 0.0};
       if (TA) {  // op(A)[i][k] = A[k][i]: contiguous along i
-        const int k = e >> 6, i = e & 63;
-        ra[q] = A[(int64_t)(k0 + k) * lda + i0 + i];
+        const int k = e / (TM / 2), ic = e % (TM / 2);
+        if (2 * ic < m_valid) v = *reinterpret_cast<const d2*>(A + (int64_t)(k0 + k) * lda + i0 + 2 * ic);
       } else {   // A[i][k]: contiguous along k
-        const int i = e >> 4, k = e & 15;
-        ra[q] = A[(i0 + i) * lda + k0 + k];
+        const int i = e >> 3, kc = e & 7;
+        if (i < m_valid) v = *reinterpret_cast<const d2*>(A + (i0 + i) * lda + k0 + 2 * kc);
       }
+      ra[q] = v;
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const int e = tid + THREADS * q;
+      d2 v = {0.0, 0.0};
       if (TB) {  // op(B)[k][j] = B[j][k]: contiguous along k
-        const int j = e >> 4, k = e & 15;
-        rb[q] = B[(j0 + j) * ldb + k0 + k];
+        const int j = e >> 3, kc = e & 7;
+        if (j < n_valid) v = *reinterpret_cast<const d2*>(B + (j0 + j) * ldb + k0 + 2 * kc);
       } else {   // B[k][j]: contiguous along j
-        const int k = e >> 6, j = e & 63;
-        rb[q] = B[(int64_t)(k0 + k) * ldb + j0 + j];
+        const int k = e / (TN / 2), jc = e % (TN / 2);
+        if (2 * jc < n_valid) v = *reinterpret_cast<const d2*>(B + (int64_t)(k0 + k) * ldb + j0 + 2 * jc);
       }
+      rb[q] = v;
     }
   };
   auto store_stage = [&](int buf) {
+    double* a = sA + buf * TM * GS;
+    double* b = sB + buf * TN * GS;
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int e = tid + 256 * q;
+    for (int q = 0; q < CA; ++q) {
+      const int e = tid + THREADS * q;
       if (TA) {
-        const int k = e >> 6, i = e & 63;
-        sA[buf][i * GS + k] = ra[q];
+        const int k = e / (TM / 2), ic = e % (TM / 2);
+        a[(2 * ic) * GS + k] = ra[q][0];
+        a[(2 * ic + 1) * GS + k] = ra[q][1];
       } else {
-        const int i = e >> 4, k = e & 15;
-        sA[buf][i * GS + k] = ra[q];
+        const int i = e >> 3, kc = e & 7;
+        *reinterpret_cast<d2*>(a + i * GS + 2 * kc) = ra[q];
       }
+    }
+#pragma unroll
+    for (int q = 0; q < CB; ++q) {
+      const int e = tid + THREADS * q;
       if (TB) {
-        const int j = e >> 4, k = e & 15;
-        sB[buf][j * GS + k] = rb[q];
+        const int j = e >> 3, kc = e & 7;
+        *reinterpret_cast<d2*>(b + j * GS + 2 * kc) = rb[q];
       } else {
-        const int k = e >> 6, j = e & 63;
-        sB[buf][j * GS + k] = rb[q];
+        const int k = e / (TN / 2), jc = e % (TN / 2);
+        b[(2 * jc) * GS + k] = rb[q][0];
+        b[(2 * jc + 1) * GS + k] = rb[q][1];
       }
     }
   };
 
-  f64x4 acc[2][2];
+  f64x4 acc[AM][AN];
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < AM; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n) acc[m][n] = acc_zero<double>();
+    for (int n = 0; n < AN; ++n) acc[m][n] = acc_zero<double>();
 
-  const int offA = (wm * 32 + (lane & 15)) * GS + (lane >> 4);
-  const int offB = (wn * 32 + (lane & 15)) * GS + (lane >> 4);
+  // a wave whose tile lies outside the matrix, or in the skipped quadrant of a diagonal tile, still stages and meets the
+  // barriers but does not multiply
+  const bool live = wm * WM < m_valid && wn * WN < n_valid &&
+                    !(lower_only && j0 + wn * WN > i0 + wm * WM + (WM > 64 ? WM : 64) - 1);
+  const int offA = (wm * WM + (lane & 15)) * GS + (lane >> 4);
+  const int offB = (wn * WN + (lane & 15)) * GS + (lane >> 4);
   const int n_stage = K / GK;
   load_stage(0);
   store_stage(0);
@@ -112,37 +149,39 @@ __global__ __launch_bounds__(256, 2) void gemm64_kernel(int K, double alpha,
   for (int s = 0; s < n_stage; ++s) {
     const int cur = s & 1;
     if (s + 1 < n_stage) load_stage((s + 1) * GK);
+    const double* a_s = sA + cur * TM * GS;
+    const double* b_s = sB + cur * TN * GS;
 #pragma unroll
     for (int kk = 0; kk < GK / 4; ++kk) {
-      double a[2], b[2];
+      double a[AM], b[AN];
 #pragma unroll
-      for (int m = 0; m < 2; ++m) a[m] = sA[cur][offA + 16 * m * GS + 4 * kk];
+      for (int m = 0; m < AM; ++m) a[m] = a_s[offA + 16 * m * GS + 4 * kk];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) b[n] = sB[cur][offB + 16 * n * GS + 4 * kk];
+      for (int n = 0; n < AN; ++n) b[n] = b_s[offB + 16 * n * GS + 4 * kk];
       if (kk == GK / 4 - 1) {
-        // LDS refill and barrier in front of the stage's last MFMAs (operands in registers): they run while the
-        // waves meet (as in K3).  Same box, back to back: c4 solve 81.2 -> 78.0 ms, C3 7.46 -> 7.07 ms, c2 1.64 -> 1.55 ms.
         if (s + 1 < n_stage) store_stage(cur ^ 1);
         __syncthreads();
       }
+      if (live) {
 #pragma unroll
-      for (int m = 0; m < 2; ++m)
+        for (int m = 0; m < AM; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) acc[m][n] = MF::mma(a[m], b[n], acc[m][n]);
+          for (int n = 0; n < AN; ++n) acc[m][n] = MF::mma(a[m], b[n], acc[m][n]);
+      }
     }
   }
+  if (!live) return;
 #pragma unroll
-  for (int m = 0; m < 2; ++m)
+  for (int m = 0; m < AM; ++m)
 #pragma unroll
-    for (int n = 0; n < 2; ++n)
+    for (int n = 0; n < AN; ++n)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int64_t row = i0 + wm * 32 + m * 16 + MF::row(lane, r);
-        const int64_t col = j0 + wn * 32 + n * 16 + (lane & 15);
+        const int64_t row = i0 + wm * WM + m * 16 + MF::row(lane, r);
+        const int64_t col = j0 + wn * WN + n * 16 + (lane & 15);
         double v = alpha * acc[m][n][r];
         if (beta != 0.0) v += beta * C[row * ldc + col];
         C[row * ldc + col] = v;
-        if (C2) C2[row * ldc2 + col] = v;
       }
 }
 
@@ -511,8 +550,28 @@ static void gemm(Ctx& c, int M, int N, int K, double alpha, Mat A, Mat B, double
     c.rc = fail(AGGF_ERR_ARG, "batched solve: too many problems for one launch");
     return;
   }
-  hipLaunchKernelGGL((gemm64_kernel<TA, TB>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), 0, c.stream, K, alpha,
-                     A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, (double*)nullptr, (int64_t)0, lower_only, bt);
+  // the 128 x 128 shape when its grid still fills the chip twice over (2 workgroups per CU): the batched solves of the
+  // featurised fit; a single problem (n = 4096: 528 lower tiles at most) keeps the 64 x 64 shape's four times as many
+  // workgroups (same box: c3 solve 5.2 ms with 128-tiles throughout against 4.0)
+  const int64_t wgs128 = (int64_t)ceil_div(M, 128) * ceil_div(N, 128) * gz / (lower_only ? 2 : 1);
+  if (M >= 128 && N >= 128 && wgs128 >= 2 * 2 * (int64_t)device_cu_count()) {
+    constexpr size_t lds = (size_t)2 * (128 + 128) * GS * sizeof(double);  // 73.7 KB: two workgroups per CU
+    static thread_local PerDeviceOnce once;
+    bool& done = *once.flag();
+    if (!done) {
+      if (hipFuncSetAttribute((const void*)gemm_tile_kernel<TA, TB, 128, 128, 64, 32>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+        c.rc = fail(AGGF_ERR_HIP, "gemm LDS attribute failed");
+      done = true;
+    }
+    hipLaunchKernelGGL((gemm_tile_kernel<TA, TB, 128, 128, 64, 32>),
+                       dim3((unsigned)ceil_div(N, 128), (unsigned)ceil_div(M, 128), (unsigned)gz), dim3(512), lds, c.stream, M,
+                       N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, lower_only, bt);
+  } else {
+    constexpr size_t lds = (size_t)2 * (64 + 64) * GS * sizeof(double);
+    hipLaunchKernelGGL((gemm_tile_kernel<TA, TB, 64, 64, 32, 32>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), lds,
+                       c.stream, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, lower_only, bt);
+  }
   if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "gemm launch failed");
 }
 
