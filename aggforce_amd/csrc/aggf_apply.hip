@@ -602,6 +602,237 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
   return AGGF_OK;
 }
 
+// ---------------------------------------------------------------------------
+// K3 for float64 x float64 with many sites (n_cg > 64, N % 16 == 0): the 64-frame x 128-site tile of apply_kernel with
+// the operand tiles travelling HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) through a ring of three stages, as
+// in K1 -- no VGPR round trip, no ds_write, no conversion or NaN-scan VALU work beside the MFMAs (the register-staged
+// kernel spends 7.6 % of its time refilling LDS and holds the clock at ~2.2 GHz; K1 runs at 2.38).
+//
+// K3 contracts over ATOMS, the direction in which a frame row is contiguous, so a stage (16 atoms) is a 384-byte piece
+// of each of the 64 frame rows and a 128-byte piece of each of the 128 map rows.  A DMA instruction fills 1 KiB of LDS
+// contiguously but every lane brings its own global address, so the 16-byte chunks may land in any order:
+//   P tile: row i = 64 doubles (32 slots of 16 bytes, 24 used); chunk c of row i sits in slot (c + i) & 31.  An operand
+//           read (lane = frame l & 15, k' = l >> 4: element 3 (4 kk + k') + d) then touches 32 different bank pairs.
+//           One DMA instruction = 2 rows x 32 slots (the 8 unused slots of a row are masked lanes).
+//   M tile: row j = 16 doubles (8 slots); chunk c of row j sits in slot (c + (j >> 1)) & 7; one DMA instruction = 8 rows.
+// 32 + 16 instructions per stage, 3 per wave (16 waves); stage it + 2 is issued during stage it, two pieces beside the
+// first two MFMA groups and the third behind the stage's barrier, which sits in front of the last group's MFMAs (their
+// operands are in registers by then).  Rows past T / n_cg are masked lanes: their LDS rows keep stale bytes, which only
+// reach outputs that are never stored.  The fused NaN scan looks at the OUTPUT (0 x NaN = NaN reaches every site of that
+// frame and component): nan_seen is conservative -- an infinity meeting a zero coefficient sets it too.
+// Workgroups b and b + 8 (same XCD under round-robin dispatch; speed only) take the two 128-site blocks of one frame
+// block: the second reader of a P tile finds it in that XCD's L2.
+constexpr int AD_TF = 64, AD_TC = 128, AD_KA = 16, AD_NBUF = 3, AD_THREADS = 1024;
+constexpr int AD_P_ELEMS = AD_TF * 64;
+constexpr int AD_M_ELEMS = AD_TC * 16;
+constexpr int AD_BUF = AD_P_ELEMS + AD_M_ELEMS;  // 6144 doubles = 48 KB per stage
+
+__device__ __forceinline__ void ad_wait_vmcnt(int n) {
+  if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
+  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+}
+
+template <int MODE>
+__global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* __restrict__ P, int64_t T, int32_t N,
+                                                                 const double* __restrict__ Mx, int32_t n_cg, int32_t ncb,
+                                                                 int64_t nfb, double* __restrict__ out,
+                                                                 double* __restrict__ sumsq_partials,
+                                                                 int32_t* __restrict__ nan_seen) {
+  using MF = Mfma<double>;
+  extern __shared__ __attribute__((aligned(16))) char smem_raw[];
+  double* smem = reinterpret_cast<double*>(smem_raw);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // block -> (frame block, site block): 8 consecutive frame blocks x ncb site blocks per group of 8 ncb workgroups,
+  // the site blocks of one frame block 8 apart
+  const int64_t b = blockIdx.x;
+  const int64_t grp = b / (8 * ncb);
+  const int rem = (int)(b - grp * 8 * ncb);
+  const int cb = rem >> 3;
+  const int64_t fb = grp * 8 + (rem & 7);
+  if (fb >= nfb) return;  // (the grid is padded to whole groups; uniform: no barrier has been reached)
+  const int64_t t0 = fb * AD_TF;
+  const int c0 = cb * AD_TC;
+  const int64_t rowP = (int64_t)N * 3;
+  const int n_stage = N / AD_KA;
+
+  // this wave's three DMA pieces: P pieces wave and wave + 16 (2 rows each), M piece wave (8 rows)
+  const double* gsrc[3];
+  int lbase[3];
+  bool ok[3];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int pp = wave + 16 * q;
+    const int row = 2 * pp + (lane >> 5), slot = lane & 31;
+    const int chunk = (slot - (row & 15)) & 31;
+    ok[q] = chunk < 24 && t0 + row < T;
+    gsrc[q] = P + (t0 + row) * rowP + chunk * 2;
+    lbase[q] = pp * 128;
+  }
+  {
+    const int row = 8 * wave + (lane >> 3), slot = lane & 7;
+    const int chunk = (slot - (row >> 1)) & 7;
+    ok[2] = c0 + row < n_cg;
+    gsrc[2] = Mx + (int64_t)(c0 + row) * N + chunk * 2;
+    lbase[2] = AD_P_ELEMS + wave * 128;
+  }
+  // pieces with no active lane are skipped by the hardware and do not count in vmcnt: wave-uniform tallies
+  const int act0 = __any(ok[0]) ? 1 : 0, act1 = __any(ok[1]) ? 1 : 0, act2 = __any(ok[2]) ? 1 : 0;
+  const int n_first = __builtin_amdgcn_readfirstlane(act0 + act1);  // issued in front of the stage barrier
+  const int n_all = __builtin_amdgcn_readfirstlane(act0 + act1 + act2);
+  auto issue_piece = [&](int s, int q) {
+    if (ok[q])
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(gsrc[q] + (int64_t)s * (q == 2 ? AD_KA : AD_KA * 3)),
+          (__attribute__((address_space(3))) void*)(smem + (s % AD_NBUF) * AD_BUF + lbase[q]), 16, 0, 0);
+  };
+
+  // MFMA operand offsets (doubles, inside a stage buffer)
+  const int wf = wave & 3, wc = wave >> 2;
+  int offA[4][3], offB[4];
+  {
+    const int row = 16 * wf + (lane & 15), kq = lane >> 4;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const int e = 12 * kk + 3 * kq + d;
+        offA[kk][d] = row * 64 + (((e >> 1) + (row & 15)) & 31) * 2 + (e & 1);
+      }
+    const int j = 32 * wc + (lane & 15);
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const int e = 4 * kk + kq;
+      offB[kk] = AD_P_ELEMS + j * 16 + (((e >> 1) + (j >> 1)) & 7) * 2 + (e & 1);
+    }
+  }
+
+  f64x4 acc[2][3];
+#pragma unroll
+  for (int n = 0; n < 2; ++n)
+#pragma unroll
+    for (int d = 0; d < 3; ++d) acc[n][d] = acc_zero<double>();
+
+#pragma unroll
+  for (int q = 0; q < 3; ++q) issue_piece(0, q);
+  if (n_stage > 1) {
+#pragma unroll
+    for (int q = 0; q < 3; ++q) issue_piece(1, q);
+  }
+  ad_wait_vmcnt(n_stage > 1 ? n_all : 0);
+  __builtin_amdgcn_s_barrier();
+  asm volatile("" ::: "memory");
+
+  // MODE 0: pieces 0, 1 of stage it + 2 beside the first two MFMA groups, piece 2 behind the barrier (in front of the
+  //         last group's MFMAs).  MODE 1: all three pieces behind the barrier.  MODE 2 (shipped): as 1, and waves 8..15
+  //         (the second pair of every SIMD) meet the barrier two groups EARLIER in their own stream -- they run half a
+  //         stage behind waves 0..7, so the two pairs of a SIMD are never in their operand-read / barrier phase together
+  //         (a slot is refilled only behind the barrier after which nobody reads it: three slots still suffice).
+  //         c3, same box, two runs each: MODE 0 107.1 / 106.6 ms, MODE 1 106.0 / 106.5, MODE 2 104.9 / 105.5 (the
+  //         register-staged kernel: 105.4-105.8) -- the staging was never the limiter; what the DMA form buys is the
+  //         single fetch of P: rocprofv3 FETCH_SIZE x 2 = 109.5 GB per launch against 202.3 GB (98.3 GB algorithmic).
+  const int bar_kk = (MODE == 2 && wave >= 8) ? 1 : 3;
+  for (int it = 0; it < n_stage; ++it) {
+    const double* buf = smem + (it % AD_NBUF) * AD_BUF;
+    const bool issue_now = it + 2 < n_stage;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      double a[3], bq[2];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) a[d] = buf[offA[kk][d]];
+#pragma unroll
+      for (int n = 0; n < 2; ++n) bq[n] = buf[offB[kk] + 256 * n];
+      if (MODE == 0 && issue_now && kk < 2) issue_piece(it + 2, kk);
+      if (kk == bar_kk) {
+        // stage it + 1 has landed (this wave's pieces; pieces of stage it + 2 issued above may stay in flight), every
+        // operand of stage it that the early group needs is in registers
+        ad_wait_vmcnt(MODE == 0 && issue_now ? n_first : 0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+        if (issue_now) {
+          if (MODE == 0) {
+            issue_piece(it + 2, 2);
+          } else {
+#pragma unroll
+            for (int q = 0; q < 3; ++q) issue_piece(it + 2, q);
+          }
+        }
+      }
+#pragma unroll
+      for (int n = 0; n < 2; ++n)
+#pragma unroll
+        for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], bq[n], acc[n][d]);
+    }
+  }
+
+  double ss = 0.0;
+  bool saw_nan = false;
+#pragma unroll
+  for (int n = 0; n < 2; ++n) {
+    const int c = c0 + (wc * 2 + n) * 16 + (lane & 15);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t t = t0 + 16 * wf + MF::row(lane, r);
+      if (t < T && c < n_cg) {
+        double* o = out + (t * n_cg + c) * 3;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) {
+          const double v = acc[n][d][r];
+          o[d] = v;
+          saw_nan |= (v != v);
+          ss += v * v;
+        }
+      }
+    }
+  }
+  if (nan_seen && __any(saw_nan) && lane == 0) atomicOr(nan_seen, 1);
+  if (sumsq_partials) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
+    __shared__ double wsum[AD_THREADS / 64];
+    if (lane == 0) wsum[wave] = ss;
+    __syncthreads();
+    if (tid == 0) {
+      double tot = 0.0;
+#pragma unroll
+      for (int w = 0; w < AD_THREADS / 64; ++w) tot += wsum[w];
+      sumsq_partials[fb * ncb + cb] = tot;
+    }
+  }
+}
+
+static int apply_dma_launch(const double* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
+                            double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, hipStream_t stream) {
+  const int ncb = (int)ceil_div(n_cg, AD_TC);
+  const int64_t nfb = ceil_div(T, AD_TF);
+  const int64_t nblocks = round_up(nfb, 8) * ncb;
+  if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "apply grid too large");
+  double* partials = nullptr;
+  if (sumsq) {
+    if (!ws || ws_bytes < (size_t)(nfb * ncb) * sizeof(double))
+      return fail(AGGF_ERR_WORKSPACE, "aggf_linearmap_apply: workspace too small for sumsq");
+    partials = reinterpret_cast<double*>(ws);
+  }
+  constexpr size_t lds = (size_t)AD_NBUF * AD_BUF * sizeof(double);  // 144 KB: one workgroup per CU
+  static thread_local PerDeviceOnce once;
+  bool& done = *once.flag();
+  if (!done) {
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    done = true;
+  }
+  hipLaunchKernelGGL(apply_dma_kernel<2>, dim3((unsigned)nblocks), dim3(AD_THREADS), lds, stream, P, T, N, Mx, n_cg, ncb, nfb,
+                     out, partials, nan_seen);
+  AGGF_LAUNCH_OK();
+  if (sumsq) {
+    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nfb * ncb, sumsq);
+    AGGF_LAUNCH_OK();
+  }
+  return AGGF_OK;
+}
+
 template <typename TIn, typename TC>
 static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg,
                        int nan_mode, double nan_fill, void* out, double* sumsq, int32_t* nan_seen,
@@ -614,9 +845,15 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   if (n_cg <= 16 && (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) <= (int64_t)AS_NV * AS_THREADS * 16 &&
       (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) >= 16 && (((uintptr_t)P & 15) == 0) && T >= 64)
     return apply_small_launch<TIn, TC>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
-  if (n_cg > 64)
+  if (n_cg > 64) {
+    if constexpr (std::is_same<TIn, double>::value && std::is_same<TC, double>::value) {
+      if (nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && N >= 2 * AD_KA)
+        return apply_dma_launch((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws, ws_bytes,
+                                stream);
+    }
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);
+  }
   return apply_launch<TIn, TC, 256, 64>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                         ws_bytes, stream);
 }

@@ -238,7 +238,9 @@ class LinearMap:
         # (rare) are the reference's two extra products formed (map/core.py:226-236)
         probe = K.take_flag(p.device)
         out = K.linearmap_apply(p, m, nan_probe=probe)
-        if not K.read_flag(probe):
+        # (the probe is conservative: the LDS-DMA tile kernel reports NaNs of the OUTPUT, which an infinity meeting a
+        # zero coefficient produces too; the reference's test is on the input, map/core.py:13-16)
+        if not K.read_flag(probe) or not K.has_nan(p):
             return K.like_input(out, points)
         raw = K.linearmap_apply(p, m, nan_fill=0.0)
         pushed = K.linearmap_apply(p, m, nan_fill=-1.0)

@@ -178,7 +178,11 @@ int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
  * sum of squares of `out` is written there (float64; agg.force_smoothness,
  * agg.py:297, is sumsq / (3 T n_cg)), combined in a fixed order.  If nan_seen != NULL,
  * nan_seen[0] is set to 1 when P contains a NaN (the _has_nans scan of map/core.py:13-16
- * fused into the pass that reads P anyway; the caller zeroes it).
+ * fused into the pass that reads P anyway; the caller zeroes it).  The flag is conservative: it
+ * is never left at 0 when P holds a NaN, but the float64 LDS-DMA tile kernel scans its OUTPUT
+ * (0 x NaN = NaN reaches every site of that frame and component), so an infinity of P that meets a
+ * zero coefficient sets it too -- a caller that needs the exact input property follows a set flag
+ * with aggf_has_nan.
  * ------------------------------------------------------------------------- */
 size_t aggf_linearmap_apply_workspace_bytes(int64_t T, int32_t N, int32_t n_cg);
 int aggf_linearmap_apply(const void* P, int64_t T, int32_t N, int in_dtype, const void* M,
