@@ -921,7 +921,18 @@ __global__ __launch_bounds__(256) void pinned_free_list_kernel(const int32_t* __
 __global__ __launch_bounds__(256) void pinned_build_kernel(const double* __restrict__ G, int n, const int32_t* __restrict__ free_idx,
                                                            int nf, const int32_t* __restrict__ pin, int m, int npad, int rpad,
                                                            double l2, const double* __restrict__ l2d,
-                                                           const double* __restrict__ scale, double* __restrict__ Pt) {
+                                                           const double* __restrict__ scale, double* __restrict__ Pt,
+                                                           const double* __restrict__ stats) {
+  // a pin out of range or repeated (stats[0] = -1 from pinned_free_list_kernel): the index lists are not a partition
+  // of 0..n-1 -- touch nothing (the host reports the status); the factorisation then runs on the workspace as it is
+  if (stats[0] < 0.0) {
+    const int64_t tot = (int64_t)(npad + rpad) * npad;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < tot; e += (int64_t)gridDim.x * blockDim.x) {
+      const int i = (int)(e / npad), j = (int)(e - (int64_t)i * npad);
+      Pt[e] = (i == j) ? 1.0 : 0.0;
+    }
+    return;
+  }
   const double inv_s = 1.0 / scale[0];
   const int64_t total = (int64_t)(npad + rpad) * npad;
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
@@ -948,8 +959,12 @@ __global__ __launch_bounds__(256) void pinned_build_kernel(const double* __restr
 __global__ __launch_bounds__(256) void pinned_scatter_kernel(const double* __restrict__ Xt, int rpad,
                                                              const int32_t* __restrict__ free_idx, int nf,
                                                              const int32_t* __restrict__ pin, int m, int n,
-                                                             double* __restrict__ X) {
+                                                             double* __restrict__ X, const double* __restrict__ stats) {
   const int64_t total = (int64_t)m * n;
+  if (stats[0] < 0.0) {  // bad pins: no scatter through them; X = 0
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) X[e] = 0.0;
+    return;
+  }
   for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
     const int c = (int)(e / n), k = (int)(e - (int64_t)c * n);  // k-th entry of row c: free ones first, then the pins
     if (k < nf) X[(int64_t)c * n + free_idx[k]] = Xt[(int64_t)k * rpad + c];
@@ -1126,7 +1141,7 @@ extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, co
   hipLaunchKernelGGL(max_diag_kernel, dim3(1, 1), dim3(256), 0, st, G, n, (int64_t)0, l2, l2_diag, scal, (int64_t)4);
   hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
   hipLaunchKernelGGL(pinned_build_kernel, flat_grid((int64_t)(npad + rpad) * npad), dim3(256), 0, st, G, n, free_idx, nf,
-                     pin_idx, m, npad, rpad, l2, l2_diag, scal, Pt.p);
+                     pin_idx, m, npad, rpad, l2, l2_diag, scal, Pt.p, stats);
   AGGF_LAUNCH_OK();
   // the rows below the matrix leave the factorisation as Y' = B' L^-T: no forward solve of its own
   cholesky(c, Pt, npad, Dinv, stats, 0, rpad);
@@ -1135,7 +1150,7 @@ extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, co
   AGGF_LAUNCH_OK();
   solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
   hipLaunchKernelGGL(pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
-                     n, X);
+                     n, X, stats);
   AGGF_LAUNCH_OK();
   return c.rc;
 }

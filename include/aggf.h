@@ -148,7 +148,8 @@ int aggf_eq_qp_solve_batched_shift(const double* G, int32_t n, double l2, const 
  * x_i[pin_idx[j]] = delta_ij, and the rest follows from ONE factorisation of the free block,
  * x_f = -P_ff^-1 P[f, pin_idx[i]] -- no A'A product, no Schur complement, no refinement.
  * pin_idx: m int32 (device).  X: (m, n).  stats as above ([1] = [2] = 0: the constraints hold exactly;
- * [0] = -1 if pin_idx holds an index twice or outside 0..n-1). */
+ * [0] = -1 if pin_idx holds an index twice or outside 0..n-1: then no element of G or X is addressed through a pin
+ * and X comes back as zeros). */
 size_t aggf_eq_qp_pinned_workspace_bytes(int32_t n, int32_t m);
 int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, const double* l2_diag,
                             const int32_t* pin_idx, int32_t m, double* X, double* stats, void* ws,

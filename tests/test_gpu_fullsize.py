@@ -13,6 +13,8 @@ import torch
 
 pytestmark = pytest.mark.gpu
 
+from conftest import need_hbm  # noqa: E402
+
 from aggforce_amd import LinearMap, Trajectory, joptgauss_map, project_forces  # noqa: E402
 from aggforce_amd import _kernels as K  # noqa: E402
 from aggforce_amd.qp import Multifeaturize, gb_feat, id_feat, qp_feat_linear_map  # noqa: E402
@@ -58,9 +60,7 @@ def test_full_size_c2_matches_oracle():
 
 def test_full_size_c5_properties():
     """configs[4]: joptgauss_map, var 0.01, 5e5 frames x 2048 atoms x 128 beads, float32."""
-    free, _ = torch.cuda.mem_get_info()
-    if free < 60 * 2**30:
-        pytest.skip("needs ~50 GB of free HBM")
+    need_hbm(60)
     T, N, n_cg, var = 500_000, 2048, 128, 0.01
     forces = K.synth_normal(T, N, torch.float32, seed=42100, sigma=30.0)
     coords = K.synth_normal(T, N, torch.float32, seed=42101, sigma=0.3, lattice=1.5)

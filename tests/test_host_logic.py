@@ -451,3 +451,19 @@ def test_solve_batches_group_sites_of_similar_size():
     # equal sizes: one batch; one site: one batch
     assert _solve_batches([500] * 10, 64) == [list(range(10))]
     assert _solve_batches([7], 1) == [[0]]
+
+
+def test_host_sanitizer_build_of_the_c_abi():
+    """`make asan` (sanitizers on the CPU build): the host pass of every HIP source under ASan + UBSan,
+    driven through argument validation, launch planning and workspace arithmetic of all entry points by
+    aggforce_amd/csrc/asan_driver.cpp -- no GPU needed (every launch fails cleanly without a device)."""
+    import shutil
+    import subprocess
+
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not on PATH")
+    csrc = os.path.join(ROOT, "aggforce_amd", "csrc")
+    run = subprocess.run(["make", "-C", csrc, "asan", "-j", "8"], capture_output=True, text=True, timeout=900)
+    tail = (run.stdout + run.stderr)[-3000:]
+    assert run.returncode == 0, tail
+    assert "0 unexpected statuses" in run.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail
