@@ -661,6 +661,57 @@ def sym_group_reduce(G: torch.Tensor, grp_ptr: torch.Tensor, grp_atoms: torch.Te
 # ------------------------------------------------------------------ synthetic data
 
 
+def take_frames(x: torch.Tensor, idx) -> torch.Tensor:
+    """x[idx] along the frame axis as one gather kernel (aggf_take_frames); ``idx``: integer array-like or tensor."""
+    if not isinstance(idx, torch.Tensor):
+        idx = torch.from_numpy(np.ascontiguousarray(np.asarray(idx, dtype=np.int64)))
+    idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
+    n = idx.numel()
+    x = x.contiguous()
+    n_src = x.shape[0]
+    if n and (int(idx.min()) < -n_src or int(idx.max()) >= n_src):
+        raise IndexError(f"frame index out of range for {n_src} frames")
+    if n and int(idx.min()) < 0:
+        idx = torch.where(idx < 0, idx + n_src, idx)
+    out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    if n and n_src:
+        row = int(np.prod(x.shape[1:])) if x.dim() > 1 else 1
+        check(lib().aggf_take_frames(ptr(x), n_src, row, dtype_code(x.dtype), ptr(idx), n, ptr(out), stream_ptr()),
+              "aggf_take_frames")
+    return out
+
+
+def concat_sites(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """[a ; b] along the site axis of two (T, ., 3) arrays, in the promoted dtype (aggf_concat_sites)."""
+    assert a.dim() == 3 and b.dim() == 3 and a.shape[0] == b.shape[0] and a.shape[2] == 3 and b.shape[2] == 3
+    a, b = a.contiguous(), b.contiguous()
+    dt = torch.promote_types(a.dtype, b.dtype)
+    T = a.shape[0]
+    out = torch.empty((T, a.shape[1] + b.shape[1], 3), dtype=dt, device=a.device)
+    if T and a.shape[1] and b.shape[1]:
+        check(lib().aggf_concat_sites(ptr(a), a.shape[1], dtype_code(a.dtype), ptr(b), b.shape[1], dtype_code(b.dtype), T,
+                                      ptr(out), dtype_code(dt), stream_ptr()), "aggf_concat_sites")
+    elif T:
+        out.copy_(a if a.shape[1] else b)
+    return out
+
+
+def scale(x: torch.Tensor, alpha: float) -> torch.Tensor:
+    """alpha * x as a product (aggf_scale): NaN / inf behave as in NumPy's ``alpha * x``."""
+    x = x.contiguous()
+    out = torch.empty_like(x)
+    if x.numel():
+        check(lib().aggf_scale(ptr(x), x.numel(), dtype_code(x.dtype), float(alpha), ptr(out), stream_ptr()), "aggf_scale")
+    return out
+
+
+def scaled(x, alpha):
+    """``alpha * x`` for a trajectory array: device tensors through :func:`scale`, host arrays as they are (NumPy)."""
+    if is_torch(x) and x.is_cuda and x.dtype in (torch.float32, torch.float64):
+        return scale(x, float(alpha))
+    return alpha * x
+
+
 def synth_normal(T: int, N: int, dtype: torch.dtype, seed: int, frame_offset: int = 0, mean: float = 0.0,
                  sigma: float = 1.0, lattice: float = 0.0, device=None) -> torch.Tensor:
     l = lib()

@@ -83,6 +83,9 @@ PROTOTYPES = {
     "aggf_comm_init": (C.c_int, [_vp, _sz, _i32, _i32, C.POINTER(_vp)]),
     "aggf_comm_destroy": (C.c_int, [_vp]),
     "aggf_allreduce_sum": (C.c_int, [_vp, _i64, C.c_int, _vp, _vp]),
+    "aggf_take_frames": (C.c_int, [_vp, _i64, _i64, C.c_int, _vp, _i64, _vp, _vp]),
+    "aggf_concat_sites": (C.c_int, [_vp, _i32, C.c_int, _vp, _i32, C.c_int, _i64, _vp, C.c_int, _vp]),
+    "aggf_scale": (C.c_int, [_vp, _i64, C.c_int, _dbl, _vp, _vp]),
     "aggf_synth_normal": (C.c_int, [_vp, _i64, _i32, C.c_int, _u64, _i64, _dbl, _dbl, _dbl, _vp]),
 }
 

@@ -152,6 +152,8 @@ _GRAM_REUSE_FIXED_ARGS: Final = frozenset(
 
 def _take_frames(arr, idx):
     if hasattr(arr, "detach"):
+        if arr.is_cuda and arr.dtype in (K.torch_dtype(np.float32), K.torch_dtype(np.float64)):
+            return K.take_frames(arr, idx)  # one gather kernel of the library, not an ATen index op
         import torch
 
         return arr[torch.as_tensor(idx, device=arr.device)]

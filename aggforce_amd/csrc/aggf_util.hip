@@ -159,6 +159,51 @@ static dim3 stream_grid(int64_t n) {
   return dim3((unsigned)g);
 }
 
+// ---- frame-sized housekeeping of the Python layer as kernels of the library (the reference does these with NumPy
+// fancy indexing, np.concatenate and scalar products on (n_frames, n_sites, 3) arrays): ------------------------------
+// out[i, :] = src[idx[i], :] for whole frames (rows of row_elems elements): fold / sample selection
+// (agg.py:208-231 `coords[train_inds]`, featlinearmap.py:447-452).  One workgroup walks rows, 16 bytes per lane when
+// the row allows it.
+template <typename T>
+__global__ __launch_bounds__(256) void take_frames_kernel(const T* __restrict__ src, int64_t n_src, int64_t row_elems,
+                                                          const int64_t* __restrict__ idx, int64_t n, int vec_ok,
+                                                          T* __restrict__ out) {
+  constexpr int V = 16 / sizeof(T);
+  typedef T __attribute__((ext_vector_type(V))) vec_t;
+  for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
+    const int64_t r = idx[i];
+    if (r < 0 || r >= n_src) continue;  // (the host checks the range; never read outside the array)
+    const T* s = src + r * row_elems;
+    T* o = out + i * row_elems;
+    if (vec_ok) {
+      for (int64_t e = threadIdx.x; e < row_elems / V; e += blockDim.x)
+        reinterpret_cast<vec_t*>(o)[e] = __builtin_nontemporal_load(reinterpret_cast<const vec_t*>(s) + e);
+    } else {
+      for (int64_t e = threadIdx.x; e < row_elems; e += blockDim.x) o[e] = s[e];
+    }
+  }
+}
+
+// out[t] = [a[t] ; b[t]] along the site axis, converted to the output type (np.concatenate(..., axis=1) of
+// trajectory/core.py:388-390 and map/tmap.py:430-436)
+template <typename TA, typename TB, typename TO>
+__global__ __launch_bounds__(256) void concat_sites_kernel(const TA* __restrict__ a, int64_t row_a, const TB* __restrict__ b,
+                                                           int64_t row_b, int64_t nT, TO* __restrict__ out) {
+  const int64_t row_o = row_a + row_b, total = nT * row_o;
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t t = e / row_o, c = e - t * row_o;
+    out[e] = c < row_a ? (TO)a[t * row_a + c] : (TO)b[t * row_b + (c - row_a)];
+  }
+}
+
+// out = alpha * x (NullForcesTMap's `fill_value * coords`, map/tmap.py:399-401; jgauss.py:573 `0 * traj.forces`):
+// a product, not a fill -- NaN x anything and 0 x inf stay what NumPy makes of them
+template <typename T>
+__global__ __launch_bounds__(256) void scale_kernel(const T* __restrict__ x, int64_t n, T alpha, T* __restrict__ out) {
+  for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n; e += (int64_t)gridDim.x * blockDim.x)
+    out[e] = alpha * x[e];
+}
+
 }  // namespace aggf
 
 using namespace aggf;
@@ -314,6 +359,60 @@ extern "C" int aggf_synth_normal(void* out, int64_t T, int32_t N, int dtype, uin
     hipLaunchKernelGGL(synth_normal_kernel<float>, grid, dim3(256), 0, stream, (float*)out, T, N, seed, frame_offset, mean, sigma, lattice);
   else
     return fail(AGGF_ERR_ARG, "aggf_synth_normal: bad dtype");
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_take_frames(const void* src, int64_t n_src, int64_t row_elems, int dtype, const int64_t* idx, int64_t n,
+                                void* out, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!src || !idx || !out) return fail(AGGF_ERR_ARG, "aggf_take_frames: NULL pointer");
+  if (n_src <= 0 || row_elems <= 0 || n < 0) return fail(AGGF_ERR_ARG, "aggf_take_frames: bad shape");
+  if (dtype != AGGF_F32 && dtype != AGGF_F64) return fail(AGGF_ERR_ARG, "aggf_take_frames: bad dtype");
+  if (n == 0) return AGGF_OK;
+  const size_t es = dtype == AGGF_F64 ? 8 : 4;
+  const int vec_ok = (((uintptr_t)src | (uintptr_t)out) & 15) == 0 && (row_elems * es) % 16 == 0;
+  int64_t g = n < 8192 ? n : 8192;
+  if (dtype == AGGF_F64)
+    hipLaunchKernelGGL(take_frames_kernel<double>, dim3((unsigned)g), dim3(256), 0, stream, (const double*)src, n_src, row_elems, idx, n, vec_ok, (double*)out);
+  else
+    hipLaunchKernelGGL(take_frames_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n_src, row_elems, idx, n, vec_ok, (float*)out);
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_concat_sites(const void* a, int32_t Na, int a_dtype, const void* b, int32_t Nb, int b_dtype, int64_t T,
+                                 void* out, int out_dtype, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!a || !b || !out) return fail(AGGF_ERR_ARG, "aggf_concat_sites: NULL pointer");
+  if (Na <= 0 || Nb <= 0 || T < 0) return fail(AGGF_ERR_ARG, "aggf_concat_sites: bad shape");
+  if (T == 0) return AGGF_OK;
+  const int64_t ra = (int64_t)Na * 3, rb = (int64_t)Nb * 3;
+  const dim3 grid = stream_grid(T * (ra + rb)), block(256);
+#define AGGF_CC(TA_, TB_, TO_) \
+  hipLaunchKernelGGL((concat_sites_kernel<TA_, TB_, TO_>), grid, block, 0, stream, (const TA_*)a, ra, (const TB_*)b, rb, T, (TO_*)out)
+  if (a_dtype == AGGF_F32 && b_dtype == AGGF_F32 && out_dtype == AGGF_F32) AGGF_CC(float, float, float);
+  else if (a_dtype == AGGF_F64 && b_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_CC(double, double, double);
+  else if (a_dtype == AGGF_F32 && b_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_CC(float, double, double);
+  else if (a_dtype == AGGF_F64 && b_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_CC(double, float, double);
+  else if (a_dtype == AGGF_F32 && b_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_CC(float, float, double);
+  else return fail(AGGF_ERR_ARG, "aggf_concat_sites: out_dtype must hold the promotion of the inputs");
+#undef AGGF_CC
+  AGGF_LAUNCH_OK();
+  return AGGF_OK;
+}
+
+extern "C" int aggf_scale(const void* x, int64_t count, int dtype, double alpha, void* out, void* stream_v) {
+  hipStream_t stream = (hipStream_t)stream_v;
+  if (!x || !out) return fail(AGGF_ERR_ARG, "aggf_scale: NULL pointer");
+  if (count < 0) return fail(AGGF_ERR_ARG, "aggf_scale: negative count");
+  if (count == 0) return AGGF_OK;
+  if (dtype == AGGF_F64)
+    hipLaunchKernelGGL(scale_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)x, count, alpha, (double*)out);
+  else if (dtype == AGGF_F32)
+    hipLaunchKernelGGL(scale_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)x, count, (float)alpha, (float*)out);
+  else
+    return fail(AGGF_ERR_ARG, "aggf_scale: bad dtype");
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

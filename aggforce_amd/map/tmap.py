@@ -191,7 +191,9 @@ class NullForcesTMap(TMap):
     def __call__(self, t: CoordsTrajectory) -> Trajectory:
         if isinstance(t, ForcesTrajectory) and self.warn_input_forces:
             warn("Discarding forces on input trajectory.", stacklevel=0)
-        return Trajectory(coords=t.coords, forces=self.fill_value * t.coords)
+        from .. import _kernels as K
+
+        return Trajectory(coords=t.coords, forces=K.scaled(t.coords, self.fill_value))
 
     def map_arrays(self, coords, forces=None) -> Tuple:
         """Like TMap.map_arrays, but ``forces`` may be omitted."""

@@ -152,8 +152,7 @@ def cv_joptgauss_fold_grams(coords, forces, coord_map: LinearMap, var: float, kb
     prob = LinearProblem(aug_cmap, constraints, f_dev.device)
     grams = []
     for idx in folds:  # one fold's frames at a time: the gathered copies never exceed a fold
-        sel = torch.as_tensor(np.asarray(idx), device=f_dev.device)
-        fk, ck = f_dev[sel].contiguous(), c_dev[sel].contiguous()
+        fk, ck = K.take_frames(f_dev, idx), K.take_frames(c_dev, idx)
         if noise is not None:
             augmenter.inject_noise(np.asarray(noise)[np.asarray(idx)])
         y, fak, cols = augmenter.noise_sites(ck, kbt)  # (every call advances the augmenter's stream: independent draws)
@@ -305,7 +304,7 @@ def stagedjforcegauss_map(
     noise = list(noise) if noise is not None else []
     if noise:
         augmenter.inject_noise(noise[0])
-    zeroforce_traj = Trajectory(coords=traj.coords, forces=0 * traj.forces)
+    zeroforce_traj = Trajectory(coords=traj.coords, forces=K.scaled(traj.forces, 0))
     aug_traj = AugmentedTrajectory.from_trajectory(t=zeroforce_traj, augmenter=augmenter, kbt=kbt)
     pmapped_traj = RATMap(tmap=pre_tmap)(aug_traj)
     pmapped_tmap = qp_linear_map(

@@ -528,7 +528,7 @@ def cv_id_gb(coords, forces, coord_map: LinearMap, kbt: float, n_constraint_fram
     bounds = np.concatenate([[0], np.cumsum(lens)]).astype(np.int64)
     c_dev, f_dev = K.as_device(coords), K.as_device(forces)
     pidx = torch.as_tensor(np.concatenate(folds), device=c_dev.device)
-    c_p, f_p = c_dev[pidx].contiguous(), f_dev[pidx].contiguous()  # frames in fold order: a fold is a row range
+    c_p, f_p = K.take_frames(c_dev, pidx), K.take_frames(f_dev, pidx)  # frames in fold order: a fold is a row range
     su = _fused_setup(c_p, f_p, coord_map, constraints, use_id, gb_kwargs, None)
     del c_p, f_p
     geo, n_id, n_ch, n_basis, n_cg = su.geo, su.n_id, su.n_ch, su.n_basis, su.n_cg

@@ -36,11 +36,13 @@ def _concat_sites(parts):
         import torch
         from .._kernels import as_device
 
+        from .._kernels import concat_sites
+
         parts = [as_device(p) for p in parts]
-        dt = parts[0].dtype
+        out = parts[0]
         for p in parts[1:]:
-            dt = torch.promote_types(dt, p.dtype)
-        return torch.cat([p.to(dt) for p in parts], dim=1)
+            out = concat_sites(out, p)  # (aggf_concat_sites: conversion to the promoted dtype rides along)
+        return out
     return np.concatenate(parts, axis=1)
 
 

@@ -477,6 +477,20 @@ int aggf_comm_init(const void* id, size_t id_bytes, int32_t rank, int32_t world,
 int aggf_comm_destroy(void* comm);
 int aggf_allreduce_sum(void* buf, int64_t count, int dtype, void* comm, void* stream);
 
+/* Frame-sized housekeeping of the host layer (the reference does it in NumPy on (n_frames, n_sites, 3) arrays):
+ *   aggf_take_frames   out[i, :] = src[idx[i], :], whole frames of row_elems elements each (fold / sample selection:
+ *                      agg.py:208-231 `coords[train_inds]`, featlinearmap.py:447-452); idx: int64 on the device, every
+ *                      entry in [0, n_src) (entries outside are skipped: their output rows are left untouched);
+ *   aggf_concat_sites  out[t] = [a[t] ; b[t]] along the site axis (np.concatenate(axis=1) of trajectory/core.py:388-390,
+ *                      map/tmap.py:430-436), a: (T, Na, 3), b: (T, Nb, 3), out in the NumPy promotion of the two;
+ *   aggf_scale         out = alpha x, elementwise in `dtype` (map/tmap.py:399-401 `fill_value * coords`: a product,
+ *                      so NaN and 0 x inf behave as in NumPy). */
+int aggf_take_frames(const void* src, int64_t n_src, int64_t row_elems, int dtype, const int64_t* idx, int64_t n,
+                     void* out, void* stream);
+int aggf_concat_sites(const void* a, int32_t Na, int a_dtype, const void* b, int32_t Nb, int b_dtype, int64_t T,
+                      void* out, int out_dtype, void* stream);
+int aggf_scale(const void* x, int64_t count, int dtype, double alpha, void* out, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Synthetic trajectories for benchmarks and full-size property tests (no
  * reference counterpart).  out[t,a,d] = mean + sigma * z(seed, frame_offset+t, a, d)
