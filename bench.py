@@ -172,12 +172,12 @@ def replicated_spread(t, world):
 
 def profiled_traffic(workload, world):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
-    (profiles/r03_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
+    (profiles/r04_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
     and counts 128-byte requests as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM): x 2."""
     if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_c3_rocprof_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_rocprof_summary.json")))
         rd = [e["FETCH_SIZE"]["per_dispatch"] for e in d["pmc_fetch"] if "gram_tile" in e["kernel"]][0]
         wr = [e["WRITE_SIZE"]["per_dispatch"] for e in d.get("pmc_write", []) if "gram_tile" in e["kernel"]]
         return 2.0 * rd * 1024 + (wr[0] * 1024 if wr else 0.0)
@@ -188,7 +188,7 @@ def profiled_traffic(workload, world):
 def profile_label():
     """Where `traffic` / `mfma_busy_frac_pmc` come from: PMC passes are separate rocprofv3 runs by construction, so
     the line quotes the committed profile and says which one (file, and the tree / date recorded inside it)."""
-    rel = "profiles/r03_c3_rocprof_summary.json"
+    rel = "profiles/r04_c3_rocprof_summary.json"
     label = f"{rel} (separate rocprofv3 --pmc passes; NOT measured in this run)"
     try:
         src = json.load(open(os.path.join(ROOT, rel))).get("profiled_from") or {}
@@ -201,11 +201,11 @@ def profile_label():
 
 def profiled_mfma_busy(workload, world):
     """Fraction of the Gram kernel's cycles in which the MFMA pipes were busy, from the committed PMC pass
-    (profiles/r03_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    (profiles/r04_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
     if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r03_c3_mfma_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_mfma_counters.json")))
         return [v["mfma_utilisation"] for k, v in d["kernels"].items() if "gram_tile" in k][0]
     except Exception:
         return None
@@ -237,6 +237,36 @@ def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores, cmat=None, constraint
     if cmat is None:
         cmat = orc.list_mapping_matrix([[i * (N // n_cg)] for i in range(n_cg)], N)
     cons = set() if constraints is None else constraints
+    # The sequence is timed TWICE on the same sample and the faster pass is reported (the first pass also warms the
+    # BLAS thread pool and the page cache of the sample; box-to-box the figure still moves by tens of per cent with the
+    # host's load and core count: a stated baseline, not a measured speed-up -- VERDICT r3 weak 11).
+    passes = []
+    for _rep in range(2):
+        passes.append(_cpu_pass(orc, rng, coords, forces, cmat, cons, l2, noised, N, n_cg, np_dtype, T_cpu))
+    best = min(passes, key=lambda p: p["lin"] * (T_total / T_cpu) + p["solve"])
+    t_aug, gram_s, solve_s, apply_s, n_red_cpu, res, mc_sum = (best[k] for k in ("aug", "gram", "solve", "apply", "n_red", "res", "mc"))
+    full = best["lin"] * (T_total / T_cpu) + solve_s
+    values = [T_total / (p["lin"] * (T_total / T_cpu) + p["solve"]) for p in passes]
+    return {
+        "value": T_total / full,
+        "unit": "frames/s",
+        "cores": cores,
+        "kind": "port",
+        "passes_frames_per_s": values,
+        "sample": (f"{T_cpu} of {T_total} frames x {N} atoms on the host ({os.cpu_count()} logical cores, BLAS threads "
+                   f"= cores field; the einsum apply is single-threaded as in the reference), faster of two passes: "
+                   + (f"augment {t_aug:.2f}s, " if noised is not None else "")
+                   + f"gram {gram_s:.2f}s (n_red {n_red_cpu}), "
+                   f"solve {solve_s:.2f}s (exact direct solve instead of {n_cg} OSQP runs), "
+                   + ("re-augment + " if noised is not None else "")
+                   + f"apply+residual {apply_s:.2f}s; T-linear stages scaled to {T_total} frames, "
+                   f"solve counted once"),
+        "_check": float(res + mc_sum * 0),
+    }
+
+
+def _cpu_pass(orc, rng, coords, forces, cmat, cons, l2, noised, N, n_cg, np_dtype, T_cpu):
+    """One timed pass of the reference's operation sequence on the sample (see cpu_baseline)."""
     t_aug = 0.0
     fit_cmat, fit_coords, fit_forces = cmat, coords, forces
     if noised is not None:
@@ -259,23 +289,8 @@ def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores, cmat=None, constraint
     mf = orc.linearmap_apply(fit_forces, W)
     res = orc.force_smoothness(mf)
     t3 = time.perf_counter()
-    lin = t_aug + (t1 - t0) + (t3 - t2)
-    full = lin * (T_total / T_cpu) + (t2 - t1)
-    return {
-        "value": T_total / full,
-        "unit": "frames/s",
-        "cores": cores,
-        "kind": "port",
-        "sample": (f"{T_cpu} of {T_total} frames x {N} atoms on the host ({os.cpu_count()} logical cores, BLAS threads "
-                   f"= cores field; the einsum apply is single-threaded as in the reference): "
-                   + (f"augment {t_aug:.2f}s, " if noised is not None else "")
-                   + f"gram {t1 - t0:.2f}s (n_red {pr['qp_mat'].shape[0]}), "
-                   f"solve {t2 - t1:.2f}s (exact direct solve instead of {n_cg} OSQP runs), "
-                   + ("re-augment + " if noised is not None else "")
-                   + f"apply+residual {t3 - t2:.2f}s; T-linear stages scaled to {T_total} frames, "
-                   f"solve counted once"),
-        "_check": float(res + mc.sum() * 0),
-    }
+    return {"lin": t_aug + (t1 - t0) + (t3 - t2), "aug": t_aug, "gram": t1 - t0, "solve": t2 - t1, "apply": t3 - t2,
+            "n_red": pr["qp_mat"].shape[0], "res": float(res), "mc": float(mc.sum())}
 
 
 def cpu_baseline_featurised(cores, n_basis=8, outer=8.0, T_cpu=500):
@@ -500,13 +515,18 @@ def main():
             algo_bytes = 3.0 * N * s_bytes * T_local
             achieved = algo_bytes / (gram_ms * 1e-3) / 1e9
             roof = {"kernel": "aggf_gram = gram_small_kernel<double, double, 5, 8, 8> (fused group sums, one pass over F) + gram_reduce_small_kernel",
-                    "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
+                    "bound": "hbm", "co_limited_by": "hbm+mfma+lds: per frame and CU 403 cycles of HBM, 336 of MFMA (28 upper-triangle "
+                    "16x16 blocks), ~230 of LDS; ablations in profiles/r04_small_ablate.jsonl (no MFMA phase 2.86 ms, no loads "
+                    "4.05, no group sums 3.73, complete 4.79)",
+                    "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "ms_per_launch": gram_ms, "bytes_per_launch": algo_bytes,
                     "flops_per_launch": flops, "mfma_tflops": flops / (gram_ms * 1e-3) / 1e12}
         else:
             achieved = flops / (gram_ms * 1e-3) / 1e12
-            kname = "gram_tile_dma_kernel<%s> (+ gram_reduce_kernel) = aggf_gram" % (
-                "double, 0, 3, 2, 8, true, false, 1, true" if gdt == "f64" else "float, 0, 3, 2, 8, true, false, 1, true")
+            # the full template name, as rocprofv3 prints it: <T, ABL, NBUF, WPS, NW, SPREAD_DMA, ES, ES_DMA_AFTER, TWO>
+            kname = "gram_tile_dma_kernel<%s, 0, 3, 2, 8, true, 1, true, %s> (+ gram_reduce_kernel) = %s" % (
+                "double" if gdt == "f64" else "float", "true" if args.workload == "c5" else "false",
+                "aggf_gram_pair" if args.workload == "c5" else "aggf_gram")
             if args.variant == "pairs":
                 kname = "pack_groups_kernel (constraint-group sums) + " + kname
             roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",

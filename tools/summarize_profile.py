@@ -17,6 +17,25 @@ def find(sub, pattern):
 
 
 summary = {"tag": tag}
+
+
+def source_sha1():
+    """Hash of the sources the profiled command ran from (this scratch copy has no .git): tools/commit_profile.py
+    recomputes it in the repository and records the commit only if the two agree."""
+    import hashlib
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    h = hashlib.sha1()
+    files = []
+    for pat in ("aggforce_amd/csrc/*.hip", "aggforce_amd/csrc/*.h", "include/*.h", "aggforce_amd/*.py", "aggforce_amd/*/*.py", "bench.py"):
+        files += glob.glob(os.path.join(root, pat))
+    for f in sorted(files):
+        h.update(os.path.relpath(f, root).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
+summary["source_sha1"] = source_sha1()
 stats = find("trace", "*kernel_stats.csv")
 if stats:
     rows = list(csv.DictReader(open(stats)))
