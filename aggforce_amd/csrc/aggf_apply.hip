@@ -622,25 +622,37 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
 // frame and component): nan_seen is conservative -- an infinity meeting a zero coefficient sets it too.
 // Workgroups b and b + 8 (same XCD under round-robin dispatch; speed only) take the two 128-site blocks of one frame
 // block: the second reader of a P tile finds it in that XCD's L2.
-constexpr int AD_TF = 64, AD_TC = 128, AD_KA = 16, AD_NBUF = 3, AD_THREADS = 1024;
-constexpr int AD_P_ELEMS = AD_TF * 64;
+constexpr int AD_TC = 128, AD_KA = 16;
 constexpr int AD_M_ELEMS = AD_TC * 16;
-constexpr int AD_BUF = AD_P_ELEMS + AD_M_ELEMS;  // 6144 doubles = 48 KB per stage
 
 __device__ __forceinline__ void ad_wait_vmcnt(int n) {
   if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
   else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
+  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
 }
 
-template <int MODE>
-__global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* __restrict__ P, int64_t T, int32_t N,
+// TF frames x 128 sites per workgroup, TF / 16 x 4 waves (wave tile 16 frames x 32 sites), NBUF ring slots:
+//   <1, 32, 2> (shipped): 8 waves, 64 KB of LDS -- two INDEPENDENT workgroups per CU as in K1: one's barrier and
+//                         operand-read phase is covered by the other's MFMAs;
+//   <2, 64, 3>: 16 waves, one workgroup per CU (144 KB of LDS), the second wave pair of every SIMD half a stage behind.
+// c3, same box: <2, 64, 3> 105.2-105.3 ms, <1, 32, 2> 103.2-103.9 ms (the dense variant's two applies 194.8 -> 189.6 ms).
+// With two slots a stage has exactly one stage time to land: spreading its four pieces over the NEXT stage's MFMA groups
+// instead of issuing them right behind the barrier costs 6 % (109.5 ms) -- the kernel is sensitive to landing latency,
+// and a third slot does not fit twice into 160 KB.
+template <int MODE, int TF, int NBUF>
+__global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(const double* __restrict__ P, int64_t T, int32_t N,
                                                                  const double* __restrict__ Mx, int32_t n_cg, int32_t ncb,
                                                                  int64_t nfb, double* __restrict__ out,
                                                                  double* __restrict__ sumsq_partials,
                                                                  int32_t* __restrict__ nan_seen) {
   using MF = Mfma<double>;
+  static_assert(NBUF == 3 || MODE == 1, "two slots: every piece behind the barrier, no stagger");
+  constexpr int NWF = TF / 16, NW = NWF * 4;       // waves along the frames x 4 along the sites
+  constexpr int PP = (TF / 2) / NW, MP = 16 / NW;  // DMA pieces per wave and stage: P (2 rows each), M (8 rows each)
+  constexpr int NPIECE = PP + MP;
+  constexpr int P_ELEMS = TF * 64, BUF = P_ELEMS + AD_M_ELEMS;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   double* smem = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -653,44 +665,52 @@ __global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* 
   const int cb = rem >> 3;
   const int64_t fb = grp * 8 + (rem & 7);
   if (fb >= nfb) return;  // (the grid is padded to whole groups; uniform: no barrier has been reached)
-  const int64_t t0 = fb * AD_TF;
+  const int64_t t0 = fb * TF;
   const int c0 = cb * AD_TC;
   const int64_t rowP = (int64_t)N * 3;
   const int n_stage = N / AD_KA;
 
-  // this wave's three DMA pieces: P pieces wave and wave + 16 (2 rows each), M piece wave (8 rows)
-  const double* gsrc[3];
-  int lbase[3];
-  bool ok[3];
+  // this wave's DMA pieces: PP pieces of the P tile (2 rows each), then MP pieces of the M tile (8 rows each)
+  const double* gsrc[NPIECE];
+  int lbase[NPIECE];
+  bool ok[NPIECE];
 #pragma unroll
-  for (int q = 0; q < 2; ++q) {
-    const int pp = wave + 16 * q;
+  for (int q = 0; q < PP; ++q) {
+    const int pp = wave + NW * q;
     const int row = 2 * pp + (lane >> 5), slot = lane & 31;
     const int chunk = (slot - (row & 15)) & 31;
     ok[q] = chunk < 24 && t0 + row < T;
     gsrc[q] = P + (t0 + row) * rowP + chunk * 2;
     lbase[q] = pp * 128;
   }
-  {
-    const int row = 8 * wave + (lane >> 3), slot = lane & 7;
+#pragma unroll
+  for (int q = 0; q < MP; ++q) {
+    const int mp = wave + NW * q;
+    const int row = 8 * mp + (lane >> 3), slot = lane & 7;
     const int chunk = (slot - (row >> 1)) & 7;
-    ok[2] = c0 + row < n_cg;
-    gsrc[2] = Mx + (int64_t)(c0 + row) * N + chunk * 2;
-    lbase[2] = AD_P_ELEMS + wave * 128;
+    ok[PP + q] = c0 + row < n_cg;
+    gsrc[PP + q] = Mx + (int64_t)(c0 + row) * N + chunk * 2;
+    lbase[PP + q] = P_ELEMS + mp * 128;
   }
   // pieces with no active lane are skipped by the hardware and do not count in vmcnt: wave-uniform tallies
-  const int act0 = __any(ok[0]) ? 1 : 0, act1 = __any(ok[1]) ? 1 : 0, act2 = __any(ok[2]) ? 1 : 0;
-  const int n_first = __builtin_amdgcn_readfirstlane(act0 + act1);  // issued in front of the stage barrier
-  const int n_all = __builtin_amdgcn_readfirstlane(act0 + act1 + act2);
+  int n_first = 0, n_all = 0;  // (n_first: the two pieces MODE 0 issues in front of the stage barrier)
+#pragma unroll
+  for (int q = 0; q < NPIECE; ++q) {
+    const int act = __any(ok[q]) ? 1 : 0;
+    n_all += act;
+    if (q < 2) n_first += act;
+  }
+  n_first = __builtin_amdgcn_readfirstlane(n_first);
+  n_all = __builtin_amdgcn_readfirstlane(n_all);
   auto issue_piece = [&](int s, int q) {
     if (ok[q])
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(gsrc[q] + (int64_t)s * (q == 2 ? AD_KA : AD_KA * 3)),
-          (__attribute__((address_space(3))) void*)(smem + (s % AD_NBUF) * AD_BUF + lbase[q]), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(gsrc[q] + (int64_t)s * (q >= PP ? AD_KA : AD_KA * 3)),
+          (__attribute__((address_space(3))) void*)(smem + (s % NBUF) * BUF + lbase[q]), 16, 0, 0);
   };
 
   // MFMA operand offsets (doubles, inside a stage buffer)
-  const int wf = wave & 3, wc = wave >> 2;
+  const int wf = wave % NWF, wc = wave / NWF;
   int offA[4][3], offB[4];
   {
     const int row = 16 * wf + (lane & 15), kq = lane >> 4;
@@ -705,7 +725,7 @@ __global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* 
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int e = 4 * kk + kq;
-      offB[kk] = AD_P_ELEMS + j * 16 + (((e >> 1) + (j >> 1)) & 7) * 2 + (e & 1);
+      offB[kk] = P_ELEMS + j * 16 + (((e >> 1) + (j >> 1)) & 7) * 2 + (e & 1);
     }
   }
 
@@ -716,10 +736,10 @@ __global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* 
     for (int d = 0; d < 3; ++d) acc[n][d] = acc_zero<double>();
 
 #pragma unroll
-  for (int q = 0; q < 3; ++q) issue_piece(0, q);
+  for (int q = 0; q < NPIECE; ++q) issue_piece(0, q);
   if (n_stage > 1) {
 #pragma unroll
-    for (int q = 0; q < 3; ++q) issue_piece(1, q);
+    for (int q = 0; q < NPIECE; ++q) issue_piece(1, q);
   }
   ad_wait_vmcnt(n_stage > 1 ? n_all : 0);
   __builtin_amdgcn_s_barrier();
@@ -733,9 +753,9 @@ __global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* 
   //         c3, same box, two runs each: MODE 0 107.1 / 106.6 ms, MODE 1 106.0 / 106.5, MODE 2 104.9 / 105.5 (the
   //         register-staged kernel: 105.4-105.8) -- the staging was never the limiter; what the DMA form buys is the
   //         single fetch of P: rocprofv3 FETCH_SIZE x 2 = 109.5 GB per launch against 202.3 GB (98.3 GB algorithmic).
-  const int bar_kk = (MODE == 2 && wave >= 8) ? 1 : 3;
+  const int bar_kk = (MODE == 2 && wave >= NW / 2) ? 1 : 3;
   for (int it = 0; it < n_stage; ++it) {
-    const double* buf = smem + (it % AD_NBUF) * AD_BUF;
+    const double* buf = smem + (it % NBUF) * BUF;
     const bool issue_now = it + 2 < n_stage;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -753,12 +773,8 @@ __global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* 
         __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
         if (issue_now) {
-          if (MODE == 0) {
-            issue_piece(it + 2, 2);
-          } else {
 #pragma unroll
-            for (int q = 0; q < 3; ++q) issue_piece(it + 2, q);
-          }
+          for (int q = (MODE == 0 ? 2 : 0); q < NPIECE; ++q) issue_piece(it + 2, q);
         }
       }
 #pragma unroll
@@ -792,22 +808,23 @@ __global__ __launch_bounds__(AD_THREADS, 4) void apply_dma_kernel(const double* 
   if (sumsq_partials) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    __shared__ double wsum[AD_THREADS / 64];
+    __shared__ double wsum[NW];
     if (lane == 0) wsum[wave] = ss;
     __syncthreads();
     if (tid == 0) {
       double tot = 0.0;
 #pragma unroll
-      for (int w = 0; w < AD_THREADS / 64; ++w) tot += wsum[w];
+      for (int w = 0; w < NW; ++w) tot += wsum[w];
       sumsq_partials[fb * ncb + cb] = tot;
     }
   }
 }
 
+template <int MODE, int TF, int NBUF>
 static int apply_dma_launch(const double* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
                             double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, hipStream_t stream) {
   const int ncb = (int)ceil_div(n_cg, AD_TC);
-  const int64_t nfb = ceil_div(T, AD_TF);
+  const int64_t nfb = ceil_div(T, TF);
   const int64_t nblocks = round_up(nfb, 8) * ncb;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "apply grid too large");
   double* partials = nullptr;
@@ -816,15 +833,16 @@ static int apply_dma_launch(const double* P, int64_t T, int32_t N, const double*
       return fail(AGGF_ERR_WORKSPACE, "aggf_linearmap_apply: workspace too small for sumsq");
     partials = reinterpret_cast<double*>(ws);
   }
-  constexpr size_t lds = (size_t)AD_NBUF * AD_BUF * sizeof(double);  // 144 KB: one workgroup per CU
+  constexpr size_t lds = (size_t)NBUF * (TF * 64 + AD_M_ELEMS) * sizeof(double);  // <64, 3>: 144 KB; <32, 2>: 64 KB
   static thread_local PerDeviceOnce once;
   bool& done = *once.flag();
   if (!done) {
-    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<MODE, TF, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)lds));
     done = true;
   }
-  hipLaunchKernelGGL(apply_dma_kernel<2>, dim3((unsigned)nblocks), dim3(AD_THREADS), lds, stream, P, T, N, Mx, n_cg, ncb, nfb,
-                     out, partials, nan_seen);
+  hipLaunchKernelGGL((apply_dma_kernel<MODE, TF, NBUF>), dim3((unsigned)nblocks), dim3(TF * 16), lds, stream, P, T, N, Mx,
+                     n_cg, ncb, nfb, out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
     hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nfb * ncb, sumsq);
@@ -848,8 +866,8 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   if (n_cg > 64) {
     if constexpr (std::is_same<TIn, double>::value && std::is_same<TC, double>::value) {
       if (nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && N >= 2 * AD_KA)
-        return apply_dma_launch((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws, ws_bytes,
-                                stream);
+        return apply_dma_launch<1, 32, 2>((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws,
+                                          ws_bytes, stream);
     }
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);
