@@ -634,10 +634,12 @@ __device__ __forceinline__ void ad_wait_vmcnt(int n) {
 }
 
 // TF frames x 128 sites per workgroup, TF / 16 x 4 waves (wave tile 16 frames x 32 sites), NBUF ring slots:
-//   <1, 32, 2> (shipped): 8 waves, 64 KB of LDS -- two INDEPENDENT workgroups per CU as in K1: one's barrier and
-//                         operand-read phase is covered by the other's MFMAs;
-//   <2, 64, 3>: 16 waves, one workgroup per CU (144 KB of LDS), the second wave pair of every SIMD half a stage behind.
-// c3, same box: <2, 64, 3> 105.2-105.3 ms, <1, 32, 2> 103.2-103.9 ms (the dense variant's two applies 194.8 -> 189.6 ms).
+//   <2, 64, 3> (n_cg > 128): 16 waves, one workgroup per CU (144 KB of LDS), the second wave pair of every SIMD half
+//                         a stage behind; the site blocks of a frame block stay in lock-step and share P through the L2;
+//   <1, 32, 2> (n_cg <= 128): 8 waves, 64 KB of LDS -- two INDEPENDENT workgroups per CU as in K1: one's barrier and
+//                         operand-read phase is covered by the other's MFMAs.
+// c3 (n_cg 256), same box: <2, 64, 3> 105.2-105.3 ms, FETCH x 2 109.5 GB; <1, 32, 2> 103.2-103.9 ms (MFMA-busy 0.86 against
+// 0.83; the dense variant's two applies 194.8 -> 189.6 ms) but FETCH x 2 145.7 GB: its pairs drift apart.
 // With two slots a stage has exactly one stage time to land: spreading its four pieces over the NEXT stage's MFMA groups
 // instead of issuing them right behind the barrier costs 6 % (109.5 ms) -- the kernel is sensitive to landing latency,
 // and a third slot does not fit twice into 160 KB.
@@ -866,8 +868,16 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   if (n_cg > 64) {
     if constexpr (std::is_same<TIn, double>::value && std::is_same<TC, double>::value) {
       if (nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && N >= 2 * AD_KA)
+      {
+        // More than one 128-site block: the 16-wave form, whose site blocks of a frame block run in lock-step on one XCD
+        // and share the P tile through its L2 (FETCH x 2 = 109.5 GB per launch at c3; the two-workgroup form drifts:
+        // 145.7 GB).  A single site block has no second reader: the faster two-workgroup form.
+        if (n_cg > AD_TC)
+          return apply_dma_launch<2, 64, 3>((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws,
+                                            ws_bytes, stream);
         return apply_dma_launch<1, 32, 2>((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws,
                                           ws_bytes, stream);
+      }
     }
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);

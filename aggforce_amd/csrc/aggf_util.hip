@@ -72,16 +72,35 @@ constexpr int SUMSQ_BLOCKS = 1024;
 template <typename T>
 __global__ __launch_bounds__(256) void sumsq_kernel(const T* __restrict__ x, int64_t n,
                                                     double* __restrict__ partials) {
-  // contiguous slice per workgroup, fixed order inside: lane-strided, lane tree, wave sum
-  const int64_t per = (n + gridDim.x - 1) / gridDim.x;
-  const int64_t b = (int64_t)blockIdx.x * per;
-  int64_t e = b + per;
-  if (e > n) e = n;
-  double s = 0.0;
-  for (int64_t i = b + threadIdx.x; i < e; i += 256) {
-    const double v = (double)x[i];
-    s += v * v;
+  // Fixed order, whatever the hardware does: workgroup w takes the 4-KiB chunks w, w + G, w + 2G, ... (G = the fixed
+  // grid: together the workgroups sweep the array as one dense front -- with a private contiguous slice per workgroup
+  // 1024 far-apart streams hit the HBM channels at once: 4.2 TB/s), a thread one 16-byte piece of each chunk, four
+  // chunks in flight, four accumulators combined in a fixed order; then lane tree, wave sum.
+  constexpr int V = 16 / sizeof(T);
+  typedef T __attribute__((ext_vector_type(V))) vec_t;
+  const int64_t n_vec = (((uintptr_t)x & 15) == 0) ? n / V : 0;  // whole 16-byte pieces (an unaligned array: scalar tail only)
+  const int64_t n_chunk = n_vec / 256;                              // whole chunks of 256 pieces
+  const vec_t* xv = reinterpret_cast<const vec_t*>(x);
+  double acc[4] = {0.0, 0.0, 0.0, 0.0};
+  int64_t c = blockIdx.x;
+  for (; c + 3 * (int64_t)gridDim.x < n_chunk; c += 4 * (int64_t)gridDim.x) {
+    vec_t v[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) v[u] = __builtin_nontemporal_load(xv + (c + u * (int64_t)gridDim.x) * 256 + threadIdx.x);
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[u] += (double)v[u][e] * (double)v[u][e];
   }
+  for (; c < n_chunk; c += gridDim.x) {
+    const vec_t v = __builtin_nontemporal_load(xv + c * 256 + threadIdx.x);
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[0] += (double)v[e] * (double)v[e];
+  }
+  // what is left behind the last whole chunk (fewer than 256 pieces + a ragged end): the last workgroup, in order
+  if (blockIdx.x == gridDim.x - 1)
+    for (int64_t i = n_chunk * 256 * V + threadIdx.x; i < n; i += 256) acc[1] += (double)x[i] * (double)x[i];
+  double s = (acc[0] + acc[1]) + (acc[2] + acc[3]);
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off, 64);
   __shared__ double w[4];
