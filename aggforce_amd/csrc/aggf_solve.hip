@@ -209,45 +209,40 @@ __device__ __forceinline__ double rsqrt_newton(double d) {
 // tools/potrf_probe.hip: shader cycles of thread 0 at the phase boundaries of one diagonal block
 __device__ unsigned long long aggf_potrf_prof[8];
 #define AGGF_PP(i) do { if (threadIdx.x == 0) aggf_potrf_prof[i] = __builtin_readcyclecounter(); } while (0)
+// phase sums inside potrf64_factor_invert: [8] sub-blocks, [9] panels, [10] trailing updates, [11] inverse levels
+__device__ unsigned long long aggf_potrf_phase[6];
+#define AGGF_PH_BEGIN unsigned long long ph_t = __builtin_readcyclecounter(), ph_s[6] = {0, 0, 0, 0, 0, 0}
+#define AGGF_PH(i) do { const unsigned long long n_ = __builtin_readcyclecounter(); ph_s[i] += n_ - ph_t; ph_t = n_; } while (0)
+#define AGGF_PH_LANDED asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#define AGGF_PH_END do { if (threadIdx.x == 0) for (int i_ = 0; i_ < 6; ++i_) aggf_potrf_phase[i_] = ph_s[i_]; } while (0)
 #else
 #define AGGF_PP(i)
+#define AGGF_PH_BEGIN
+#define AGGF_PH(i)
+#define AGGF_PH_LANDED
+#define AGGF_PH_END
 #endif
-constexpr int POTRF3_LDS = (2 * NB * (NB + 1) + 2 * 2 * PB) * (int)sizeof(double);
-__global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict__ Akk, int64_t lda,
-                                                             double* __restrict__ Linv,
-                                                             double* __restrict__ info, int pivot_base,
-                                                             int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
+// LDS of the diagonal-block kernel: A / L and L^-1 (64 x 65 each) + the exchange buffers of the sub-block step
+constexpr int POTRF_XCHG = 2 * (PB * 4 + 4 * PB);  // doubles: [2][16][4] column blocks + [2][4][16] rows of Z
+constexpr int POTRF3_LDS = (2 * NB * (NB + 1) + POTRF_XCHG) * (int)sizeof(double);
+
+// In place, by the 256 threads of a workgroup: a (lower triangle of a 64 x 64 block, zeros above) <- its Cholesky factor
+// L, x <- L^-1 (x must come in zeroed).  Starts and ends with a barrier.
+//
+// The 16 x 16 diagonal sub-blocks advance FOUR columns per barrier (round 4; one column per barrier cost 765 cycles per
+// column, the LDS round trip + barrier + the 1/sqrt chain): the threads exchange a 16 x 4 column block and 4 rows of Z,
+// then every thread factors the 4 x 4 diagonal micro-block itself (10 entries, four chained 1/sqrt) and forward-
+// substitutes the two rows it needs (its own row i and row c) and the four Z rows alongside.  Every entry sees the same
+// operations in the same order as with one column per step: the results are bit-identical to the previous kernel's.
+__device__ __forceinline__ void potrf64_factor_invert(double (*a)[NB + 1], double (*x)[NB + 1], double* xchg,
+                                                      double* __restrict__ info, int pivot_base) {
   using MF = Mfma<double>;
-  extern __shared__ __attribute__((aligned(16))) char potrf_smem[];
-  double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem);        // A, then L (lower)
-  double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem) + NB;   // L^-1
-  double* colbuf = reinterpret_cast<double*>(potrf_smem) + 2 * NB * (NB + 1);    // [2][16] scaled... raw column j
-  double* zrow = colbuf + 2 * PB;                                                // [2][16] row j of Z
+  typedef double __attribute__((ext_vector_type(2))) d2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  Akk += blockIdx.x * a_ps;  // blockIdx.x = problem of a batched solve
-  Linv += blockIdx.x * linv_ps;
-  info += blockIdx.x * info_ps;
-  AGGF_PP(0);
-  {
-    // all 16 loads of a thread in flight together (the upper triangle is storage of the same matrix: read and dropped;
-    // with the predicate inside the load the compiler waited for each one: 20 k cycles for this loop)
-    double tmp[NB * NB / 256];
-#pragma unroll
-    for (int q = 0; q < NB * NB / 256; ++q) {
-      const int e = tid + 256 * q;
-      tmp[q] = Akk[(int64_t)(e / NB) * lda + (e % NB)];
-    }
-#pragma unroll
-    for (int q = 0; q < NB * NB / 256; ++q) {
-      const int e = tid + 256 * q, r = e / NB, c = e % NB;
-      a[r][c] = (c <= r) ? tmp[q] : 0.0;
-      x[r][c] = 0.0;
-    }
-  }
-  __syncthreads();
-  AGGF_PP(1);
   const int si = tid >> 4, sc = tid & 15;  // sub-block entry (row, column) of this thread
+  __syncthreads();
+  AGGF_PH_BEGIN;
   for (int kb = 0; kb < NB / PB; ++kb) {
     const int k0 = kb * PB;
     // 1. diagonal sub-block: right-looking Cholesky on the 256 entries, the identity alongside
@@ -255,29 +250,84 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
       double v = a[k0 + si][k0 + sc];     // A[i][c] (lower part meaningful)
       double z = si == sc ? 1.0 : 0.0;    // Z[i][c]
 #pragma unroll
-      for (int j = 0; j < PB; ++j) {
-        double* cb = colbuf + (j & 1) * PB;
-        double* zb = zrow + (j & 1) * PB;
-        if (sc == j) cb[si] = v;          // column j as it stands (rows >= j matter)
-        if (si == j) zb[sc] = z;          // row j of Z (final: rows are only touched by earlier columns)
+      for (int jb = 0; jb < PB / 4; ++jb) {
+        const int j0 = 4 * jb;
+        double* cb = xchg + (jb & 1) * (PB * 4);                  // [16][4]: columns j0 .. j0+3 as they stand
+        double* zb = xchg + 2 * (PB * 4) + (jb & 1) * (4 * PB);   // [4][16]: rows j0 .. j0+3 of Z
+        if ((sc >> 2) == jb) cb[si * 4 + (sc & 3)] = v;
+        if ((si >> 2) == jb) zb[(si & 3) * PB + sc] = z;
         __syncthreads();
-        double d = cb[j];
-        if (!(d > 0.0)) {
-          if (tid == 0 && info[0] == 0.0) info[0] = (double)(pivot_base + k0 + j + 1);
-          d = 1.0;
+        const d2* cb2 = reinterpret_cast<const d2*>(cb);
+        const d2 q0 = cb2[(j0 + 0) * 2], q1 = cb2[(j0 + 1) * 2], q2 = cb2[(j0 + 2) * 2], q2h = cb2[(j0 + 2) * 2 + 1],
+                 q3 = cb2[(j0 + 3) * 2], q3h = cb2[(j0 + 3) * 2 + 1];
+        const d2 ail = cb2[si * 2], aih = cb2[si * 2 + 1], acl = cb2[sc * 2], ach = cb2[sc * 2 + 1];
+        double d00 = q0[0], d10 = q1[0], d11 = q1[1], d20 = q2[0], d21 = q2[1], d22 = q2h[0], d30 = q3[0], d31 = q3[1],
+               d32 = q3h[0], d33 = q3h[1];
+        const double ai0 = ail[0], ac0 = acl[0];
+        double ai1 = ail[1], ai2 = aih[0], ai3 = aih[1];
+        double ac1 = acl[1], ac2 = ach[0], ac3 = ach[1];
+        double z0 = zb[0 * PB + sc], z1 = zb[1 * PB + sc], z2 = zb[2 * PB + sc], z3 = zb[3 * PB + sc];
+        const int piv = pivot_base + k0 + j0 + 1;
+#ifdef AGGF_POTRF_PROF
+        AGGF_PH_LANDED;
+        AGGF_PH(4);
+#endif
+        // column j0
+        if (!(d00 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 0); d00 = 1.0; }
+        const double rs0 = rsqrt_newton(d00);
+        const double l10 = d10 * rs0, l20 = d20 * rs0, l30 = d30 * rs0;
+        const double li0 = ai0 * rs0, lc0 = ac0 * rs0, x0 = z0 * rs0, g0 = d00 * rs0;
+        d11 = fma(-l10, l10, d11); d21 = fma(-l20, l10, d21); d31 = fma(-l30, l10, d31);
+        d22 = fma(-l20, l20, d22); d32 = fma(-l30, l20, d32); d33 = fma(-l30, l30, d33);
+        ai1 = fma(-li0, l10, ai1); ai2 = fma(-li0, l20, ai2); ai3 = fma(-li0, l30, ai3);
+        ac1 = fma(-lc0, l10, ac1); ac2 = fma(-lc0, l20, ac2); ac3 = fma(-lc0, l30, ac3);
+        z1 = fma(-l10, x0, z1); z2 = fma(-l20, x0, z2); z3 = fma(-l30, x0, z3);
+        // column j0 + 1
+        if (!(d11 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 1); d11 = 1.0; }
+        const double rs1 = rsqrt_newton(d11);
+        const double l21 = d21 * rs1, l31 = d31 * rs1;
+        const double li1 = ai1 * rs1, lc1 = ac1 * rs1, x1 = z1 * rs1, g1 = d11 * rs1;
+        d22 = fma(-l21, l21, d22); d32 = fma(-l31, l21, d32); d33 = fma(-l31, l31, d33);
+        ai2 = fma(-li1, l21, ai2); ai3 = fma(-li1, l31, ai3);
+        ac2 = fma(-lc1, l21, ac2); ac3 = fma(-lc1, l31, ac3);
+        z2 = fma(-l21, x1, z2); z3 = fma(-l31, x1, z3);
+        // column j0 + 2
+        if (!(d22 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 2); d22 = 1.0; }
+        const double rs2 = rsqrt_newton(d22);
+        const double l32 = d32 * rs2;
+        const double li2 = ai2 * rs2, lc2 = ac2 * rs2, x2 = z2 * rs2, g2 = d22 * rs2;
+        d33 = fma(-l32, l32, d33);
+        ai3 = fma(-li2, l32, ai3);
+        ac3 = fma(-lc2, l32, ac3);
+        z3 = fma(-l32, x2, z3);
+        // column j0 + 3
+        if (!(d33 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 3); d33 = 1.0; }
+        const double rs3 = rsqrt_newton(d33);
+        const double li3 = ai3 * rs3, lc3 = ac3 * rs3, x3 = z3 * rs3, g3 = d33 * rs3;
+        // this thread's entry of the sub-block and of Z
+        if ((sc >> 2) == jb) {
+          const int p = sc & 3;
+          const double lsel = p == 0 ? li0 : (p == 1 ? li1 : (p == 2 ? li2 : li3));
+          const double gsel = p == 0 ? g0 : (p == 1 ? g1 : (p == 2 ? g2 : g3));
+          v = si == sc ? gsel : (si > sc ? lsel : 0.0);
+        } else if (sc >= j0 + 4 && si >= j0 + 4) {                  // (only c <= i is ever read)
+          v = fma(-li3, lc3, fma(-li2, lc2, fma(-li1, lc1, fma(-li0, lc0, v))));
         }
-        const double rs = rsqrt_newton(d);
-        const double l_i = cb[si] * rs, l_c = cb[sc] * rs;   // L[i][j], L[c][j]
-        const double xj = zb[sc] * rs;                         // X[j][c] = Z[j][c] / L[j][j]
-        if (sc == j) v = si == j ? d * rs : (si > j ? l_i : 0.0);
-        else if (si > j && sc > j) v = fma(-l_i, l_c, v);      // (only c <= i is ever read)
-        if (si == j) z = xj;
-        else if (si > j) z = fma(-l_i, xj, z);
+        if ((si >> 2) == jb) {
+          const int q = si & 3;
+          z = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
+        } else if (si >= j0 + 4) {
+          z = fma(-li3, x3, fma(-li2, x2, fma(-li1, x1, fma(-li0, x0, z))));
+        }
+#ifdef AGGF_POTRF_PROF
+        AGGF_PH(5);
+#endif
       }
       a[k0 + si][k0 + sc] = sc <= si ? v : 0.0;
       x[k0 + si][k0 + sc] = sc <= si ? z : 0.0;
     }
     __syncthreads();
+    AGGF_PH(0);
     const int nt16 = (NB - k0 - PB) / PB;  // 16-row tiles below the sub-block: 3, 2, 1, 0
     // 2. panel below: P = A_panel X_kk'  (wave w takes row tile w); in place -- a wave reads and writes its own rows only
     if (wave < nt16) {
@@ -290,6 +340,7 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
       for (int r = 0; r < 4; ++r) a[r0 + MF::row(lane, r)][k0 + li] = acc[r];
     }
     __syncthreads();
+    AGGF_PH(1);
     // 3. trailing block -= P P' on the lower tiles (ti >= tj), dealt to the waves
     {
       int q = 0;
@@ -308,13 +359,8 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
         }
     }
     __syncthreads();
+    AGGF_PH(2);
   }
-  AGGF_PP(2);
-  for (int e = tid; e < NB * NB; e += 256) {
-    const int r = e / NB, c = e - r * NB;
-    if (c <= r) Akk[(int64_t)r * lda + c] = a[r][c];
-  }
-  AGGF_PP(3);
   // sub-blocks of the inverse below the diagonal, by distance d from it:
   //   X(bi,bj) = -X(bi,bi) * sum_{k = bj}^{bi-1} L(bi,k) X(k,bj)        (one block per wave)
   for (int d = 1; d < NB / PB; ++d) {
@@ -339,12 +385,176 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
     }
     __syncthreads();
   }
-  AGGF_PP(4);
+  AGGF_PH(3);
+  AGGF_PH_END;
+}
+
+__global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict__ Akk, int64_t lda,
+                                                             double* __restrict__ Linv,
+                                                             double* __restrict__ info, int pivot_base,
+                                                             int64_t a_ps, int64_t linv_ps, int64_t info_ps) {
+  extern __shared__ __attribute__((aligned(16))) char potrf_smem[];
+  double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem);        // A, then L (lower)
+  double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem) + NB;   // L^-1
+  double* xchg = reinterpret_cast<double*>(potrf_smem) + 2 * NB * (NB + 1);
+  const int tid = threadIdx.x;
+  Akk += blockIdx.x * a_ps;  // blockIdx.x = problem of a batched solve
+  Linv += blockIdx.x * linv_ps;
+  info += blockIdx.x * info_ps;
+  AGGF_PP(0);
+  {
+    // all 16 loads of a thread in flight together (the upper triangle is storage of the same matrix: read and dropped;
+    // with the predicate inside the load the compiler waited for each one: 20 k cycles for this loop)
+    double tmp[NB * NB / 256];
+#pragma unroll
+    for (int q = 0; q < NB * NB / 256; ++q) {
+      const int e = tid + 256 * q;
+      tmp[q] = Akk[(int64_t)(e / NB) * lda + (e % NB)];
+    }
+#pragma unroll
+    for (int q = 0; q < NB * NB / 256; ++q) {
+      const int e = tid + 256 * q, r = e / NB, c = e % NB;
+      a[r][c] = (c <= r) ? tmp[q] : 0.0;
+      x[r][c] = 0.0;
+    }
+  }
+  AGGF_PP(1);
+  potrf64_factor_invert(a, x, xchg, info, pivot_base);
+  AGGF_PP(2);
+  for (int e = tid; e < NB * NB; e += 256) {
+    const int r = e / NB, c = e - r * NB;
+    if (c <= r) Akk[(int64_t)r * lda + c] = a[r][c];
+  }
+  AGGF_PP(3);
   for (int e = tid; e < NB * NB; e += 256) {
     const int r = e / NB, c = e - r * NB;
     Linv[r * NB + c] = x[r][c];
   }
+  AGGF_PP(4);
   AGGF_PP(5);
+}
+
+// One 64-column step of the factorisation INSIDE a 256-wide outer panel, in one launch (left-looking): block column k
+// of P = rows of the diagonal block and the `nrb` 64-row blocks below it (the extra rows of the right-hand sides ride
+// along) first receives the products with the j earlier block columns of its outer panel (K = 64 j <= 192), then the
+// diagonal block is factored and inverted, then the rows below are multiplied by the inverse.  Every workgroup forms and
+// factors the diagonal block ITSELF (the same 32 KB from the L2 for all of them, ~13 us of redundant work on otherwise
+// idle CUs) and then owns row blocks blockIdx.x, blockIdx.x + gridDim.x, ...: the chain diag -> panel -> inner update of
+// the right-looking form (three dependent launches, 28 + 13 + 13 us at n = 4096) becomes one launch.  Workgroup 0 stores
+// the factor of the diagonal block and its inverse.  blockIdx.y = problem of a batched solve.
+constexpr int STEP_LDS = (4 * NB * (NB + 1) + POTRF_XCHG) * (int)sizeof(double);
+__global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, int64_t ld, int k, int j, int nrb,
+                                                       double* __restrict__ Linv, double* __restrict__ info,
+                                                       int pivot_base, int64_t p_ps, int64_t linv_ps, int64_t info_ps) {
+  using MF = Mfma<double>;
+  extern __shared__ __attribute__((aligned(16))) char step_smem[];
+  double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem);            // diagonal block, then its factor
+  double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem) + NB;       // its inverse
+  double (*sk)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem) + 2 * NB;  // L(k, p): rows of the diagonal block
+  double (*sr)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem) + 3 * NB;  // L(r, p): rows of the row block; then U
+  double* xchg = reinterpret_cast<double*>(step_smem) + 4 * NB * (NB + 1);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lk = lane >> 4;
+  P += blockIdx.y * p_ps;
+  Linv += blockIdx.y * linv_ps;
+  info += blockIdx.y * info_ps;
+  const int64_t kr = (int64_t)k * NB;          // first row / column of the diagonal block
+  const int64_t pc = (int64_t)(k - j) * NB;    // first column of the outer panel
+  int rb = blockIdx.x;                         // row block of this workgroup (-1 + ... below): rows kr + 64 (rb + 1) ..
+  const bool has_rows = rb < nrb;
+
+  // a 64 x 64 block of P (rows r0.., columns c0..) into an LDS tile, 16 loads per thread in flight
+  auto stage = [&](double (*dst)[NB + 1], int64_t r0, int64_t c0) {
+    double tmp[NB * NB / 256];
+#pragma unroll
+    for (int q = 0; q < NB * NB / 256; ++q) {
+      const int e = tid + 256 * q;
+      tmp[q] = P[(r0 + e / NB) * ld + c0 + (e % NB)];
+    }
+#pragma unroll
+    for (int q = 0; q < NB * NB / 256; ++q) {
+      const int e = tid + 256 * q;
+      dst[e / NB][e % NB] = tmp[q];
+    }
+  };
+  // wave w owns the 16-row tile w of a 64 x 64 result: four 16 x 16 accumulators (column tiles 0..3)
+  auto load_acc = [&](f64x4 (&acc)[4], int64_t r0, int64_t c0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) acc[t][r] = P[(r0 + wave * 16 + MF::row(lane, r)) * ld + c0 + t * 16 + li];
+  };
+  // acc -= rows(lhs tile row `wave`) * rows(rhs)'   over the 64 columns of the staged tiles
+  auto minus_abt = [&](f64x4 (&acc)[4], double (*lhs)[NB + 1], double (*rhs)[NB + 1]) {
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double av = -lhs[wave * 16 + li][kk * 4 + lk];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) acc[t] = MF::mma(av, rhs[t * 16 + li][kk * 4 + lk], acc[t]);
+    }
+  };
+
+  f64x4 accD[4], accU[4];
+  load_acc(accD, kr, kr);
+  if (has_rows) load_acc(accU, kr + (int64_t)(rb + 1) * NB, kr);
+  for (int p = 0; p < j; ++p) {
+    stage(sk, kr, pc + (int64_t)p * NB);
+    if (has_rows) stage(sr, kr + (int64_t)(rb + 1) * NB, pc + (int64_t)p * NB);
+    __syncthreads();
+    minus_abt(accD, sk, sk);
+    if (has_rows) minus_abt(accU, sr, sk);
+    __syncthreads();
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int row = wave * 16 + MF::row(lane, r), col = t * 16 + li;
+      a[row][col] = col <= row ? accD[t][r] : 0.0;
+      x[row][col] = 0.0;
+    }
+  potrf64_factor_invert(a, x, xchg, info, pivot_base);
+  if (blockIdx.x == 0) {
+    for (int e = tid; e < NB * NB; e += 256) {
+      const int r = e / NB, c = e - r * NB;
+      if (c <= r) P[(kr + r) * ld + kr + c] = a[r][c];
+      Linv[r * NB + c] = x[r][c];
+    }
+  }
+  // rows below: L(r, k) = U X'   (X lower triangular: column tile t needs the contraction index up to 16 (t + 1) only)
+  for (bool first = true; rb < nrb; rb += gridDim.x, first = false) {
+    const int64_t r0 = kr + (int64_t)(rb + 1) * NB;
+    if (!first) {
+      load_acc(accU, r0, kr);
+      for (int p = 0; p < j; ++p) {
+        __syncthreads();
+        stage(sk, kr, pc + (int64_t)p * NB);
+        stage(sr, r0, pc + (int64_t)p * NB);
+        __syncthreads();
+        minus_abt(accU, sr, sk);
+      }
+    }
+    __syncthreads();  // sr free (and, first pass, the factor's last barrier passed)
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) sr[wave * 16 + MF::row(lane, r)][t * 16 + li] = accU[t][r];
+    __syncthreads();
+    f64x4 out[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) out[t] = acc_zero<double>();
+#pragma unroll
+    for (int kk = 0; kk < NB / 4; ++kk) {
+      const double uv = sr[wave * 16 + li][kk * 4 + lk];
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+        if (kk < 4 * (t + 1)) out[t] = MF::mma(uv, x[t * 16 + li][kk * 4 + lk], out[t]);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) P[(r0 + wave * 16 + MF::row(lane, r)) * ld + kr + t * 16 + li] = out[t][r];
+  }
 }
 
 // Helper kernels of the solve.  blockIdx.y = problem of a batched solve; every array argument comes
@@ -643,23 +853,41 @@ static void build_big_inverses(Ctx& c, Mat L, int npad, Mat Dinv) {
 // sides comes out of the factorisation and needs no launches of its own.
 static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_base, int extra_rows = 0) {
   const int nb = npad / NB;
+  static thread_local PerDeviceOnce attr_once3;
+  bool& attr_done3 = *attr_once3.flag();
+  if (!attr_done3) {
+    if (hipFuncSetAttribute((const void*)potrf_diag_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            POTRF3_LDS) != hipSuccess ||
+        hipFuncSetAttribute((const void*)chol_step_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, STEP_LDS) !=
+            hipSuccess)
+      c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
+    attr_done3 = true;
+  }
+  // workgroups per problem that find a CU of their own (the step kernel takes a CU's LDS)
+  const int gx_max = device_cu_count() / c.nprob > 0 ? device_cu_count() / c.nprob : 1;
   for (int k0 = 0; k0 < nb && !c.rc; k0 += OUTER_PANELS) {
     const int kend = k0 + OUTER_PANELS < nb ? k0 + OUTER_PANELS : nb;
+    // One launch per 64-column step (chol_step_kernel, left-looking inside the outer panel) while a workgroup has at
+    // most 8 row blocks to walk; the large batched solves keep the three launches per step (diagonal block, panel,
+    // right-looking inner update), whose GEMMs spread the rows over the whole chip.  One form per outer panel: the two
+    // differ in WHEN a block column receives the inner updates.
+    const int nrb0 = (npad - (k0 + 1) * NB + extra_rows) / NB;
+    const bool one_launch = ceil_div(nrb0 > 0 ? nrb0 : 1, gx_max) <= 8;
     for (int k = k0; k < kend && !c.rc; ++k) {
       const Mat Akk = P.at((int64_t)k * NB, (int64_t)k * NB);
       const Mat Dk{Dinv.p + (int64_t)k * NB * NB, NB, Dinv.ps};
-      static thread_local PerDeviceOnce attr_once3;
-      bool& attr_done3 = *attr_once3.flag();
-      if (!attr_done3) {
-        if (hipFuncSetAttribute((const void*)potrf_diag_mfma_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                POTRF3_LDS) != hipSuccess)
-          c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
-        attr_done3 = true;
+      const int rem = npad - (k + 1) * NB + extra_rows;
+      if (one_launch) {
+        const int nrb = rem / NB;
+        const int gx = nrb < 1 ? 1 : (nrb < gx_max ? nrb : gx_max);
+        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)gx, (unsigned)c.nprob), dim3(256), STEP_LDS, c.stream, P.p,
+                           P.ld, k, k - k0, nrb, Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
+        if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "chol_step launch failed");
+        continue;
       }
-      hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, (int64_t)npad,
+      hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, P.ld,
                          Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
       if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
-      const int rem = npad - (k + 1) * NB + extra_rows;
       if (rem <= 0) break;
       const Mat panel = Akk.at(NB, 0);  // rows below the diagonal block, same columns
       // panel <- panel * Linv'  (in place: every workgroup reads exactly the rows it writes)

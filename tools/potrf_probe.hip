@@ -30,8 +30,12 @@ int main() {
     hipEventElapsedTime(&ms, e0, e1);
     unsigned long long p[8];
     hipMemcpyFromSymbol(p, HIP_SYMBOL(aggf::aggf_potrf_prof), sizeof(p));
-    printf("rep %d: event %.1f us | cycles: load %llu, factor (4 sub-blocks + panels + trailing) %llu, store L %llu, inverse levels %llu, "
-           "store X %llu, total %llu\n", rep, ms * 1e3, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[5] - p[4], p[5] - p[0]);
+    printf("rep %d: event %.1f us | cycles: load %llu, factor + inverse levels %llu, store L %llu, store X %llu, total %llu\n", rep,
+           ms * 1e3, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[4] - p[0]);
+    unsigned long long ph[6];
+    hipMemcpyFromSymbol(ph, HIP_SYMBOL(aggf::aggf_potrf_phase), sizeof(ph));
+    printf("        inside the factor: sub-blocks %llu (exchange through the LDS %llu + arithmetic %llu, both included), panels %llu, trailing %llu, inverse levels %llu\n",
+           ph[0] + ph[4] + ph[5], ph[4], ph[5], ph[1], ph[2], ph[3]);
   }
   return 0;
 }
