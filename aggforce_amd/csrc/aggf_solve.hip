@@ -198,11 +198,10 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), 2) void gemm_tile_kerne
 //    (k = (lane >> 4) + 4 r), so no LDS round trip is needed.
 constexpr int PB = 16;
 __device__ __forceinline__ double rsqrt_newton(double d) {
-  double rs = __builtin_amdgcn_rsq(d);
-  double e = fma(-d * rs, rs, 1.0);
-  rs = fma(rs * e, fma(e, 0.375, 0.5), rs);
-  e = fma(-d * rs, rs, 1.0);
-  return fma(rs * 0.5, e, rs);
+  // v_rsq_f64 is good to 5.2e-8; the third-order correction leaves 1.4e-16 (a further Newton step: 1.37e-16)
+  const double rs = __builtin_amdgcn_rsq(d);
+  const double e = fma(-d * rs, rs, 1.0);
+  return fma(rs * e, fma(e, 0.375, 0.5), rs);
 }
 
 #ifdef AGGF_POTRF_PROF
@@ -222,110 +221,135 @@ __device__ unsigned long long aggf_potrf_phase[6];
 #define AGGF_PH_LANDED
 #define AGGF_PH_END
 #endif
-// LDS of the diagonal-block kernel: A / L and L^-1 (64 x 65 each) + the exchange buffers of the sub-block step
-constexpr int POTRF_XCHG = 2 * (PB * 4 + 4 * PB);  // doubles: [2][16][4] column blocks + [2][4][16] rows of Z
-constexpr int POTRF3_LDS = (2 * NB * (NB + 1) + POTRF_XCHG) * (int)sizeof(double);
+// LDS of the diagonal-block kernel: A / L and L^-1 (64 x 65 each)
+constexpr int POTRF3_LDS = 2 * NB * (NB + 1) * (int)sizeof(double);
+
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+  const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+  const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+  return __hiloint2double(hi, lo);
+}
+
+// One wave factors AND inverts the 16 x 16 sub-block at (k0, k0) of the LDS block `a` (lower storage), four columns per
+// step, everything in registers:
+//   * the sub-block sits in the accumulator layout of v_mfma_f64_16x16x4 as a full SYMMETRIC matrix
+//     (lane (c = lane & 15, q = lane >> 4) holds rows q, q+4, q+8, q+12 of column c), Z = the running inverse likewise;
+//   * the 4 x 4 diagonal micro-block (10 entries) is read with v_readlane into wave-uniform values, factored
+//     (four chained 1/sqrt: v_rsq_f64 + one third-order correction -- 1.4e-16 relative, a second step changes nothing,
+//     tools/dp_latency.hip) and inverted (M = L_d^-1) by every lane alike;
+//   * rows j0..j0+3 of the symmetric matrix ARE the transposed column block in the B-operand layout, so one MFMA with
+//     M as the A operand gives the normalised columns L(:, j0..j0+3) = A(:, j0..) M' -- in the OPERAND layout
+//     (lane (row, k)), which is what the rank-4 update C -= L L' needs for both operands: a second MFMA, no LDS, no
+//     barrier, no transposition.  The same two MFMAs move Z: rows j0.. of Z are X = M Z(j0.., :), then Z -= L X.
+// 1740 cycles per four columns with the exchange through the LDS (520 for the round trip + barrier, 1220 of arithmetic
+// issue: every thread repeated the micro-block's factorisation and three forward substitutions) -> see DESIGN.md.
+__device__ __forceinline__ void potrf16_wave(double (*a)[NB + 1], double (*x)[NB + 1], int k0,
+                                             double* __restrict__ info, int pivot0) {
+  using MF = Mfma<double>;
+  const int lane = threadIdx.x & 63, li = lane & 15, lk = lane >> 4;
+  f64x4 ac, zc;
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lk + 4 * r;
+    ac[r] = row >= li ? a[k0 + row][k0 + li] : a[k0 + li][k0 + row];
+    zc[r] = row == li ? 1.0 : 0.0;
+  }
+  // The two MFMAs that move Z do not feed the next micro-block's pivots.  Issue order per step (pinned with scheduling
+  // barriers; the matrix pipe takes one 64-cycle MFMA at a time): v_readlanes, two 1/sqrt chains, [Z -= L X of the
+  // previous step], two more chains, M, [L = A M'], [A -= L L'], [X = M Z(j0.., :)] -- the Z products run under the
+  // scalar chains instead of standing in front of them.
+  double lv_prev = 0.0;
+  f64x4 xr = acc_zero<double>();
+  const f64x4 zero = acc_zero<double>();
+#pragma unroll
+  for (int jb = 0; jb < PB / 4; ++jb) {
+    const int j0 = 4 * jb;
+    // entry (j0+q, j0+p) of the symmetric matrix: register jb of lane (c = j0+p, q)
+    const double blk = ac[jb];
+    double d00 = readlane_f64(blk, j0 + 0), d10 = readlane_f64(blk, j0 + 16), d20 = readlane_f64(blk, j0 + 32),
+           d30 = readlane_f64(blk, j0 + 48), d11 = readlane_f64(blk, j0 + 1 + 16), d21 = readlane_f64(blk, j0 + 1 + 32),
+           d31 = readlane_f64(blk, j0 + 1 + 48), d22 = readlane_f64(blk, j0 + 2 + 32), d32 = readlane_f64(blk, j0 + 2 + 48),
+           d33 = readlane_f64(blk, j0 + 3 + 48);
+    const int piv = pivot0 + j0 + 1;
+    if (!(d00 > 0.0)) { if (lane == 0 && info[0] == 0.0) info[0] = (double)(piv + 0); d00 = 1.0; }
+    const double rs0 = rsqrt_newton(d00);
+    const double l10 = d10 * rs0, l20 = d20 * rs0, l30 = d30 * rs0;
+    d11 = fma(-l10, l10, d11); d21 = fma(-l20, l10, d21); d31 = fma(-l30, l10, d31);
+    d22 = fma(-l20, l20, d22); d32 = fma(-l30, l20, d32); d33 = fma(-l30, l30, d33);
+    if (!(d11 > 0.0)) { if (lane == 0 && info[0] == 0.0) info[0] = (double)(piv + 1); d11 = 1.0; }
+    const double rs1 = rsqrt_newton(d11);
+    const double l21 = d21 * rs1, l31 = d31 * rs1;
+    d22 = fma(-l21, l21, d22); d32 = fma(-l31, l21, d32); d33 = fma(-l31, l31, d33);
+    __builtin_amdgcn_sched_barrier(0);
+    if (jb > 0) {  // Z of the previous step: xr holds rows j0-4 .. j0-1 of the inverse, lane (c, k): X[j0 - 4 + k][c]
+      const double xv = xr[0];
+      zc = MF::mma(-lv_prev, xv, zc);
+      zc[jb - 1] = xv;
+    }
+    __builtin_amdgcn_sched_barrier(0);
+    if (!(d22 > 0.0)) { if (lane == 0 && info[0] == 0.0) info[0] = (double)(piv + 2); d22 = 1.0; }
+    const double rs2 = rsqrt_newton(d22);
+    const double l32 = d32 * rs2;
+    d33 = fma(-l32, l32, d33);
+    if (!(d33 > 0.0)) { if (lane == 0 && info[0] == 0.0) info[0] = (double)(piv + 3); d33 = 1.0; }
+    const double rs3 = rsqrt_newton(d33);
+    // M = L_d^-1 (lower): the identity forward-substituted
+    const double m10 = -(l10 * rs0) * rs1;
+    const double m21 = -(l21 * rs1) * rs2;
+    const double m32 = -(l32 * rs2) * rs3;
+    const double m20 = -fma(l21, m10, l20 * rs0) * rs2;
+    const double m31 = -fma(l32, m21, l31 * rs1) * rs3;
+    const double m30 = -fma(l32, m20, fma(l31, m10, l30 * rs0)) * rs3;
+    // A operand: lane (k = li < 4, p = lk) holds M[k][p]
+    double am = 0.0;
+    am = lane == 0 ? rs0 : am;
+    am = lane == 1 ? m10 : am;
+    am = lane == 2 ? m20 : am;
+    am = lane == 3 ? m30 : am;
+    am = lane == 17 ? rs1 : am;
+    am = lane == 18 ? m21 : am;
+    am = lane == 19 ? m31 : am;
+    am = lane == 34 ? rs2 : am;
+    am = lane == 35 ? m32 : am;
+    am = lane == 51 ? rs3 : am;
+    __builtin_amdgcn_sched_barrier(0);
+    // L(c, j0 + k) in lane (c, k): zero above the diagonal and for the rows that are final already
+    const f64x4 lt = MF::mma(am, blk, zero);
+    const double lv = li >= j0 + lk ? lt[0] : 0.0;
+    ac = MF::mma(-lv, lv, ac);
+    __builtin_amdgcn_sched_barrier(0);
+    xr = MF::mma(am, zc[jb], zero);
+    a[k0 + li][k0 + j0 + lk] = lv;
+    lv_prev = lv;
+    __builtin_amdgcn_sched_barrier(0);
+  }
+  {
+    const double xv = xr[0];
+    zc = MF::mma(-lv_prev, xv, zc);
+    zc[PB / 4 - 1] = xv;
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    const int row = lk + 4 * r;
+    x[k0 + row][k0 + li] = li <= row ? zc[r] : 0.0;
+  }
+}
 
 // In place, by the 256 threads of a workgroup: a (lower triangle of a 64 x 64 block, zeros above) <- its Cholesky factor
-// L, x <- L^-1 (x must come in zeroed).  Starts and ends with a barrier.
-//
-// The 16 x 16 diagonal sub-blocks advance FOUR columns per barrier (round 4; one column per barrier cost 765 cycles per
-// column, the LDS round trip + barrier + the 1/sqrt chain): the threads exchange a 16 x 4 column block and 4 rows of Z,
-// then every thread factors the 4 x 4 diagonal micro-block itself (10 entries, four chained 1/sqrt) and forward-
-// substitutes the two rows it needs (its own row i and row c) and the four Z rows alongside.  Every entry sees the same
-// operations in the same order as with one column per step: the results are bit-identical to the previous kernel's.
-__device__ __forceinline__ void potrf64_factor_invert(double (*a)[NB + 1], double (*x)[NB + 1], double* xchg,
+// L, x <- L^-1.  Starts and ends with a barrier.  Four 16-column steps: the diagonal sub-block by one wave
+// (potrf16_wave), the panel below and the trailing tiles by all four on MFMA; then the sub-blocks of the inverse
+// below the diagonal, level by level.
+__device__ __forceinline__ void potrf64_factor_invert(double (*a)[NB + 1], double (*x)[NB + 1],
                                                       double* __restrict__ info, int pivot_base) {
   using MF = Mfma<double>;
-  typedef double __attribute__((ext_vector_type(2))) d2;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
-  const int si = tid >> 4, sc = tid & 15;  // sub-block entry (row, column) of this thread
   __syncthreads();
   AGGF_PH_BEGIN;
   for (int kb = 0; kb < NB / PB; ++kb) {
     const int k0 = kb * PB;
-    // 1. diagonal sub-block: right-looking Cholesky on the 256 entries, the identity alongside
-    {
-      double v = a[k0 + si][k0 + sc];     // A[i][c] (lower part meaningful)
-      double z = si == sc ? 1.0 : 0.0;    // Z[i][c]
-#pragma unroll
-      for (int jb = 0; jb < PB / 4; ++jb) {
-        const int j0 = 4 * jb;
-        double* cb = xchg + (jb & 1) * (PB * 4);                  // [16][4]: columns j0 .. j0+3 as they stand
-        double* zb = xchg + 2 * (PB * 4) + (jb & 1) * (4 * PB);   // [4][16]: rows j0 .. j0+3 of Z
-        if ((sc >> 2) == jb) cb[si * 4 + (sc & 3)] = v;
-        if ((si >> 2) == jb) zb[(si & 3) * PB + sc] = z;
-        __syncthreads();
-        const d2* cb2 = reinterpret_cast<const d2*>(cb);
-        const d2 q0 = cb2[(j0 + 0) * 2], q1 = cb2[(j0 + 1) * 2], q2 = cb2[(j0 + 2) * 2], q2h = cb2[(j0 + 2) * 2 + 1],
-                 q3 = cb2[(j0 + 3) * 2], q3h = cb2[(j0 + 3) * 2 + 1];
-        const d2 ail = cb2[si * 2], aih = cb2[si * 2 + 1], acl = cb2[sc * 2], ach = cb2[sc * 2 + 1];
-        double d00 = q0[0], d10 = q1[0], d11 = q1[1], d20 = q2[0], d21 = q2[1], d22 = q2h[0], d30 = q3[0], d31 = q3[1],
-               d32 = q3h[0], d33 = q3h[1];
-        const double ai0 = ail[0], ac0 = acl[0];
-        double ai1 = ail[1], ai2 = aih[0], ai3 = aih[1];
-        double ac1 = acl[1], ac2 = ach[0], ac3 = ach[1];
-        double z0 = zb[0 * PB + sc], z1 = zb[1 * PB + sc], z2 = zb[2 * PB + sc], z3 = zb[3 * PB + sc];
-        const int piv = pivot_base + k0 + j0 + 1;
-#ifdef AGGF_POTRF_PROF
-        AGGF_PH_LANDED;
-        AGGF_PH(4);
-#endif
-        // column j0
-        if (!(d00 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 0); d00 = 1.0; }
-        const double rs0 = rsqrt_newton(d00);
-        const double l10 = d10 * rs0, l20 = d20 * rs0, l30 = d30 * rs0;
-        const double li0 = ai0 * rs0, lc0 = ac0 * rs0, x0 = z0 * rs0, g0 = d00 * rs0;
-        d11 = fma(-l10, l10, d11); d21 = fma(-l20, l10, d21); d31 = fma(-l30, l10, d31);
-        d22 = fma(-l20, l20, d22); d32 = fma(-l30, l20, d32); d33 = fma(-l30, l30, d33);
-        ai1 = fma(-li0, l10, ai1); ai2 = fma(-li0, l20, ai2); ai3 = fma(-li0, l30, ai3);
-        ac1 = fma(-lc0, l10, ac1); ac2 = fma(-lc0, l20, ac2); ac3 = fma(-lc0, l30, ac3);
-        z1 = fma(-l10, x0, z1); z2 = fma(-l20, x0, z2); z3 = fma(-l30, x0, z3);
-        // column j0 + 1
-        if (!(d11 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 1); d11 = 1.0; }
-        const double rs1 = rsqrt_newton(d11);
-        const double l21 = d21 * rs1, l31 = d31 * rs1;
-        const double li1 = ai1 * rs1, lc1 = ac1 * rs1, x1 = z1 * rs1, g1 = d11 * rs1;
-        d22 = fma(-l21, l21, d22); d32 = fma(-l31, l21, d32); d33 = fma(-l31, l31, d33);
-        ai2 = fma(-li1, l21, ai2); ai3 = fma(-li1, l31, ai3);
-        ac2 = fma(-lc1, l21, ac2); ac3 = fma(-lc1, l31, ac3);
-        z2 = fma(-l21, x1, z2); z3 = fma(-l31, x1, z3);
-        // column j0 + 2
-        if (!(d22 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 2); d22 = 1.0; }
-        const double rs2 = rsqrt_newton(d22);
-        const double l32 = d32 * rs2;
-        const double li2 = ai2 * rs2, lc2 = ac2 * rs2, x2 = z2 * rs2, g2 = d22 * rs2;
-        d33 = fma(-l32, l32, d33);
-        ai3 = fma(-li2, l32, ai3);
-        ac3 = fma(-lc2, l32, ac3);
-        z3 = fma(-l32, x2, z3);
-        // column j0 + 3
-        if (!(d33 > 0.0)) { if (tid == 0 && info[0] == 0.0) info[0] = (double)(piv + 3); d33 = 1.0; }
-        const double rs3 = rsqrt_newton(d33);
-        const double li3 = ai3 * rs3, lc3 = ac3 * rs3, x3 = z3 * rs3, g3 = d33 * rs3;
-        // this thread's entry of the sub-block and of Z
-        if ((sc >> 2) == jb) {
-          const int p = sc & 3;
-          const double lsel = p == 0 ? li0 : (p == 1 ? li1 : (p == 2 ? li2 : li3));
-          const double gsel = p == 0 ? g0 : (p == 1 ? g1 : (p == 2 ? g2 : g3));
-          v = si == sc ? gsel : (si > sc ? lsel : 0.0);
-        } else if (sc >= j0 + 4 && si >= j0 + 4) {                  // (only c <= i is ever read)
-          v = fma(-li3, lc3, fma(-li2, lc2, fma(-li1, lc1, fma(-li0, lc0, v))));
-        }
-        if ((si >> 2) == jb) {
-          const int q = si & 3;
-          z = q == 0 ? x0 : (q == 1 ? x1 : (q == 2 ? x2 : x3));
-        } else if (si >= j0 + 4) {
-          z = fma(-li3, x3, fma(-li2, x2, fma(-li1, x1, fma(-li0, x0, z))));
-        }
-#ifdef AGGF_POTRF_PROF
-        AGGF_PH(5);
-#endif
-      }
-      a[k0 + si][k0 + sc] = sc <= si ? v : 0.0;
-      x[k0 + si][k0 + sc] = sc <= si ? z : 0.0;
-    }
+    // 1. diagonal sub-block: factored and inverted by wave 0 alone, in registers (see potrf16_wave)
+    if (wave == 0) potrf16_wave(a, x, k0, info, pivot_base + k0);
     __syncthreads();
     AGGF_PH(0);
     const int nt16 = (NB - k0 - PB) / PB;  // 16-row tiles below the sub-block: 3, 2, 1, 0
@@ -396,7 +420,6 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
   extern __shared__ __attribute__((aligned(16))) char potrf_smem[];
   double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem);        // A, then L (lower)
   double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(potrf_smem) + NB;   // L^-1
-  double* xchg = reinterpret_cast<double*>(potrf_smem) + 2 * NB * (NB + 1);
   const int tid = threadIdx.x;
   Akk += blockIdx.x * a_ps;  // blockIdx.x = problem of a batched solve
   Linv += blockIdx.x * linv_ps;
@@ -419,7 +442,7 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
     }
   }
   AGGF_PP(1);
-  potrf64_factor_invert(a, x, xchg, info, pivot_base);
+  potrf64_factor_invert(a, x, info, pivot_base);
   AGGF_PP(2);
   for (int e = tid; e < NB * NB; e += 256) {
     const int r = e / NB, c = e - r * NB;
@@ -442,7 +465,7 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
 // idle CUs) and then owns row blocks blockIdx.x, blockIdx.x + gridDim.x, ...: the chain diag -> panel -> inner update of
 // the right-looking form (three dependent launches, 28 + 13 + 13 us at n = 4096) becomes one launch.  Workgroup 0 stores
 // the factor of the diagonal block and its inverse.  blockIdx.y = problem of a batched solve.
-constexpr int STEP_LDS = (4 * NB * (NB + 1) + POTRF_XCHG) * (int)sizeof(double);
+constexpr int STEP_LDS = 4 * NB * (NB + 1) * (int)sizeof(double);
 __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, int64_t ld, int k, int j, int nrb,
                                                        double* __restrict__ Linv, double* __restrict__ info,
                                                        int pivot_base, int64_t p_ps, int64_t linv_ps, int64_t info_ps) {
@@ -452,7 +475,6 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, 
   double (*x)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem) + NB;       // its inverse
   double (*sk)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem) + 2 * NB;  // L(k, p): rows of the diagonal block
   double (*sr)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem) + 3 * NB;  // L(r, p): rows of the row block; then U
-  double* xchg = reinterpret_cast<double*>(step_smem) + 4 * NB * (NB + 1);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int li = lane & 15, lk = lane >> 4;
   P += blockIdx.y * p_ps;
@@ -513,7 +535,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, 
       a[row][col] = col <= row ? accD[t][r] : 0.0;
       x[row][col] = 0.0;
     }
-  potrf64_factor_invert(a, x, xchg, info, pivot_base);
+  potrf64_factor_invert(a, x, info, pivot_base);
   if (blockIdx.x == 0) {
     for (int e = tid; e < NB * NB; e += 256) {
       const int r = e / NB, c = e - r * NB;

@@ -34,8 +34,7 @@ int main() {
            ms * 1e3, p[1] - p[0], p[2] - p[1], p[3] - p[2], p[4] - p[3], p[4] - p[0]);
     unsigned long long ph[6];
     hipMemcpyFromSymbol(ph, HIP_SYMBOL(aggf::aggf_potrf_phase), sizeof(ph));
-    printf("        inside the factor: sub-blocks %llu (exchange through the LDS %llu + arithmetic %llu, both included), panels %llu, trailing %llu, inverse levels %llu\n",
-           ph[0] + ph[4] + ph[5], ph[4], ph[5], ph[1], ph[2], ph[3]);
+    printf("        inside the factor: sub-blocks %llu, panels %llu, trailing %llu, inverse levels %llu\n", ph[0], ph[1], ph[2], ph[3]);
   }
   return 0;
 }
