@@ -36,17 +36,21 @@ def bench_cv():
     coords = K.synth_normal(T, N, torch.float32, 2, sigma=0.3, lattice=1.5)
     cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
     grid = {"l2_regularization": [0.0, 1e-3, 1e-1, 10.0]}
-    res = {}
+    res, times = {}, {}
     for name, reuse in (("one_pass", True), ("loop", False)):
-        for rep in range(2):
+        times[name] = []
+        for rep in range(4 if reuse else 2):
             t0 = sync()
             r = project_forces_grid_cv(grid, coords, forces, n_folds=5, rng=np.random.default_rng(0),
                                        coord_map=cmap, constrained_inds=None, reuse_gram=reuse)
-            res[name] = (sync() - t0, r)
+            times[name].append(sync() - t0)
+        res[name] = (min(times[name][1:]), r)
     a, b = res["one_pass"][1]["scores"], res["loop"][1]["scores"]
     worst = max(abs(a[k] - b[k]) / abs(b[k]) for k in a)
+    # (every repetition is listed: a box has shown one-off stalls of seconds in either form; the first is the warm-up)
     emit(row="cv", workload=f"{T} x {N} x {n_cg} fp32, 5 folds x 4 l2 values", one_pass_s=res["one_pass"][0],
-         loop_s=res["loop"][0], speedup=res["loop"][0] / res["one_pass"][0], max_rel_score_diff=worst)
+         loop_s=res["loop"][0], speedup=res["loop"][0] / res["one_pass"][0], max_rel_score_diff=worst,
+         one_pass_reps_s=times["one_pass"], loop_reps_s=times["loop"])
 
 
 def bench_cv_noised():
@@ -79,14 +83,18 @@ def bench_staged():
     coords = K.synth_normal(T, N, torch.float32, 4, sigma=0.3, lattice=1.5)
     cmap = LinearMap([[i * (N // n_cg)] for i in range(n_cg)], n_fg_sites=N)
     traj = Trajectory(coords=coords, forces=forces)
-    for rep in range(2):
+    fits, applies = [], []
+    for rep in range(4):
         t0 = sync()
         tm = stagedjoptgauss_map(traj, cmap, var=0.05, kbt=0.6, seed=7)
         t1 = sync()
         mapped = tm(traj)
         t2 = sync()
-    emit(row="staged", workload=f"stagedjoptgauss_map, {T} x {N} x {n_cg} fp32", fit_s=t1 - t0, apply_s=t2 - t1,
-         frames_per_s=T / (t2 - t0), mapped_shape=list(mapped.forces.shape))
+        fits.append(t1 - t0)
+        applies.append(t2 - t1)
+    fit_s, apply_s = min(fits[1:]), min(applies[1:])
+    emit(row="staged", workload=f"stagedjoptgauss_map, {T} x {N} x {n_cg} fp32", fit_s=fit_s, apply_s=apply_s,
+         frames_per_s=T / (fit_s + apply_s), mapped_shape=list(mapped.forces.shape), fit_reps_s=fits, apply_reps_s=applies)
 
 
 def bench_k6():
