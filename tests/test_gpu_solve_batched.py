@@ -86,3 +86,49 @@ def test_general_solve_matches_oracle_across_block_counts():
             e[i] = 1.0
             ref = orc.eq_qp_solve(Gh + 1e-3 * np.eye(n), None, Ah, e)
             assert np.max(np.abs(X[i] - ref)) < 1e-7 * max(1.0, np.max(np.abs(ref))), (n, m, i)
+
+
+def test_factorisation_forms_agree(monkeypatch):
+    """K2's factorisation takes one launch per 64-column step (every workgroup factors the diagonal block itself and
+    walks its share of the row blocks) or, when a workgroup would have more than 8 row blocks to walk, three launches
+    per step (diagonal block, panel, right-looking inner update).  ``AGGF_SOLVE_WGS=1`` (workgroups per problem of the
+    step kernel; read per call) puts a 1000-variable system through BOTH: the first outer panels take the three-launch
+    form, the later ones the one-launch form with ONE workgroup walking all row blocks.  Same solution as the default
+    schedule (one workgroup per row block) up to rounding, same reported pivot for an indefinite matrix."""
+    rng = np.random.default_rng(5)
+    n, m = 1000, 40
+    R = rng.standard_normal((3 * n, n))
+    G = torch.from_numpy(R.T @ R).cuda()
+    A = torch.from_numpy(rng.standard_normal((m, n))).cuda()
+    B = torch.from_numpy(np.eye(m)).cuda()
+    pins = torch.arange(0, n, n // m, dtype=torch.int32)[:m].cuda()
+
+    def solves():
+        X, st = K.eq_qp_solve(G, 1e-3, None, A, B, schur_reg=1e-12, n_refine=2)
+        Xb, stb = K.eq_qp_solve_batched(torch.stack([G, 2.0 * G, G]), 1e-3, None, torch.stack([A, A, A]),
+                                        torch.stack([B, B, B]), schur_reg=1e-12, n_refine=2)
+        Xp, stp = K.eq_qp_solve_pinned(G, 1e-3, None, pins)
+        return [X, Xb, Xp], [st, stb, stp]
+
+    monkeypatch.delenv("AGGF_SOLVE_WGS", raising=False)
+    ref, ref_st = solves()
+    monkeypatch.setenv("AGGF_SOLVE_WGS", "1")
+    got, got_st = solves()
+    for a, b, sa, sb in zip(ref, got, ref_st, got_st):
+        assert float(sa.reshape(-1, 4)[:, 0].abs().max()) == 0.0 and float(sb.reshape(-1, 4)[:, 0].abs().max()) == 0.0
+        scale = float(a.abs().max())
+        assert float((a - b).abs().max()) < 1e-9 * scale
+    assert float((A @ got[0].T - B).abs().max()) < 1e-9
+    # an indefinite matrix: the first non-positive pivot is the same 1-based index in every form
+    Gbad = G.clone()
+    Gbad[700:, :] = 0.0
+    Gbad[:, 700:] = 0.0
+    Gbad[700:, 700:] = -torch.eye(n - 700, dtype=torch.float64, device="cuda")
+    for env in (None, "1", "3"):
+        if env is None:
+            monkeypatch.delenv("AGGF_SOLVE_WGS", raising=False)
+        else:
+            monkeypatch.setenv("AGGF_SOLVE_WGS", env)
+        _, st = K.eq_qp_solve(Gbad, 0.0, None, A[:, :] * 0.0 + torch.eye(m, n, dtype=torch.float64, device="cuda"), B,
+                              schur_reg=0.0, n_refine=0)
+        assert float(st[0]) == 701.0, (env, st)
