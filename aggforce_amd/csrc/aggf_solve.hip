@@ -885,8 +885,13 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
       c.rc = fail(AGGF_ERR_HIP, "potrf LDS attribute failed");
     attr_done3 = true;
   }
-  // workgroups per problem that find a CU of their own (the step kernel takes a CU's LDS)
-  const int gx_max = device_cu_count() / c.nprob > 0 ? device_cu_count() / c.nprob : 1;
+  // workgroups per problem that find a CU of their own (the step kernel takes a CU's LDS).  AGGF_SOLVE_WGS (tests: read
+  // per call) caps it, which sends small systems through the row walk and the three-launch form.
+  int gx_max = device_cu_count() / c.nprob > 0 ? device_cu_count() / c.nprob : 1;
+  if (const char* e = getenv("AGGF_SOLVE_WGS")) {
+    const int cap = atoi(e);
+    if (cap > 0 && cap < gx_max) gx_max = cap;
+  }
   for (int k0 = 0; k0 < nb && !c.rc; k0 += OUTER_PANELS) {
     const int kend = k0 + OUTER_PANELS < nb ? k0 + OUTER_PANELS : nb;
     // One launch per 64-column step (chol_step_kernel, left-looking inside the outer panel) while a workgroup has at
