@@ -16,6 +16,8 @@
 
 #include "aggf_common.h"
 
+#include <type_traits>
+
 namespace aggf {
 
 constexpr int TILE = 128;         // output tile edge (reduced atoms)
@@ -577,7 +579,7 @@ constexpr int SM_FAST_MEMBERS = 4;  // group members summed without a loop (larg
 template <typename TIn>
 static size_t small_raw_bytes(int32_t N, int kbs) { return (size_t)round_up((int64_t)kbs * 3 * N * sizeof(TIn), 16) + 16; }
 
-template <typename TIn, typename TC, int NV, int KBS, int NWV>
+template <typename TIn, typename TC, int NV, int KBS, int NWV, int W, int C>
 __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     const TIn* __restrict__ F, int64_t T, int32_t N, const int32_t* __restrict__ grp_ptr,
     const int32_t* __restrict__ grp_atoms, int32_t n_red, int64_t frames_per_split, int32_t raw_bytes,
@@ -585,19 +587,31 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   using M = Mfma<TC>;
   using acc_t = typename M::acc_t;
   constexpr int SM_THREADS = 64 * NWV;
-  constexpr int SM_ENT = KBS * ROW_ELEMS / SM_THREADS;      // panel entries per thread and stage: 6
-  constexpr int SM_MAXBLK = (36 + NWV - 1) / NWV;           // upper-triangle blocks per wave: 9 / 5
-  static_assert(KBS * ROW_ELEMS % SM_THREADS == 0, "entry split");
+  // W = panel width in reduced columns (128, 64 or 32, n_red <= W) with KBS = 8 * 128 / W frames per stage: a stage
+  // is the same amount of panel whatever the system's size, so the per-stage costs (three barriers, the table-driven
+  // group sums over ALL panel columns, the fetch latency) are spread over 2x / 4x the frames of a 64- / 32-column
+  // system.  (With the 128-wide panel for everything, 32 atoms streamed at 0.19 of 8 TB/s and 64 atoms at 0.30
+  // against CLN025's 0.45: profiles/r04_stream_kernels.jsonl.)
+  constexpr int RE = 3 * W, RS = RE + ROW_PAD;              // panel row: elements / stride
+  constexpr int SM_ENT = KBS * RE / SM_THREADS;             // panel entries per thread and stage: 6
+  // C = 16x16 blocks of the upper triangle per ACTIVE wave: wave w owns blocks w C .. w C + C - 1 of the row-major list
+  // (n_blocks <= NWV C); the waves behind the list skip the MFMA phase, the last active one pads its share with
+  // repeats of block 0 whose accumulators are dropped.  Every active wave thus runs the SAME unconditional sequence
+  // of MFMAs: with a test per block (blocks dealt round-robin, 3 or 4 per wave at CLN025) the compiler wrapped every
+  // conditional MFMA in copies of the accumulator set behind an s_nop for the MFMA's full latency -- ~150 cycles per
+  // block step and nothing overlapped (tools/small_probe.hip: MFMA phase 3500 of 10300 cycles per stage at CLN025).
+  constexpr int SM_MAXBLK = C;
+  static_assert(KBS * RE % SM_THREADS == 0 && KBS * W == 8 * TILE, "entry split");
   typedef float __attribute__((ext_vector_type(4))) v16_t;  // one 16-byte piece, whatever the dtype
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  TC* panel = reinterpret_cast<TC*>(smem_raw);                         // [SM_KB][ROW_STRIDE]
-  TIn* raw = reinterpret_cast<TIn*>(smem_raw + KBS * ROW_STRIDE * sizeof(TC));  // SM_KB frames as in HBM
+  TC* panel = reinterpret_cast<TC*>(smem_raw);                         // [KBS][RS]
+  TIn* raw = reinterpret_cast<TIn*>(smem_raw + KBS * RS * sizeof(TC));  // SM_KB frames as in HBM
   // (raw_bytes includes one extra zeroed 16-byte piece: the "no member" slot of the table below)
-  int32_t* atoms_s = reinterpret_cast<int32_t*>(smem_raw + KBS * ROW_STRIDE * sizeof(TC) + raw_bytes);  // [N]
+  int32_t* atoms_s = reinterpret_cast<int32_t*>(smem_raw + KBS * RS * sizeof(TC) + raw_bytes);  // [N]
   int32_t* ptr_s = atoms_s + N;                                                                           // [129]
   // per panel column c = 3 g + d: offsets (3 atom + d) of the first 4 members of group g inside a frame,
   // 0xFFFF = none -- one 8-byte LDS read instead of a chain of dependent ones per member
-  unsigned short* memb_s = reinterpret_cast<unsigned short*>(smem_raw + KBS * ROW_STRIDE * sizeof(TC) + raw_bytes +
+  unsigned short* memb_s = reinterpret_cast<unsigned short*>(smem_raw + KBS * RS * sizeof(TC) + raw_bytes +
                                                              (((int64_t)N + TILE + 1) * 4 + 15) / 16 * 16);  // [384][4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -619,7 +633,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   __syncthreads();
   bool big_groups = false;  // uniform: some group has more than SM_FAST_MEMBERS members
   for (int g = 0; g < n_red; ++g) big_groups |= ptr_s[g + 1] - ptr_s[g] > SM_FAST_MEMBERS;
-  for (int c = tid; c < ROW_ELEMS; c += SM_THREADS) {
+  for (int c = tid; c < RE; c += SM_THREADS) {
     const int g = c / 3, d = c - 3 * g;
 #pragma unroll
     for (int j = 0; j < SM_FAST_MEMBERS; ++j)
@@ -683,12 +697,12 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 #pragma unroll
     for (int i = 0; i < SM_ENT; ++i) {
       const int e = tid + SM_THREADS * i;  // (frame in stage, reduced column, xyz); padding columns sum nothing
-      mem[i] = *reinterpret_cast<const uint2*>(memb_s + (e % ROW_ELEMS) * 4);
+      mem[i] = *reinterpret_cast<const uint2*>(memb_s + (e % RE) * 4);
     }
 #pragma unroll
     for (int i = 0; i < SM_ENT; ++i) {
       const int e = tid + SM_THREADS * i;
-      const int base = (e / ROW_ELEMS) * (int)row_in;
+      const int base = (e / RE) * (int)row_in;
       const int o0 = mem[i].x & 0xFFFF, o1 = mem[i].x >> 16, o2 = mem[i].y & 0xFFFF, o3 = mem[i].y >> 16;
       const TC v0 = (TC)raw[o0 == 0xFFFF ? zero_idx : base + o0], v1 = (TC)raw[o1 == 0xFFFF ? zero_idx : base + o1],
                v2 = (TC)raw[o2 == 0xFFFF ? zero_idx : base + o2], v3 = (TC)raw[o3 == 0xFFFF ? zero_idx : base + o3];
@@ -698,7 +712,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 #pragma unroll
       for (int i = 0; i < SM_ENT; ++i) {
         const int e = tid + SM_THREADS * i;
-        const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
+        const int r = e / RE, c = e - r * RE;
         const int g = c / 3, d = c - 3 * g;
         for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) sum[i] += (TC)raw[r * (int)row_in + 3 * atoms_s[j] + d];
       }
@@ -706,29 +720,34 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 #pragma unroll
     for (int i = 0; i < SM_ENT; ++i) {
       const int e = tid + SM_THREADS * i;
-      const int r = e / ROW_ELEMS, c = e - r * ROW_ELEMS;
-      panel[r * ROW_STRIDE + c] = sum[i];
+      const int r = e / RE, c = e - r * RE;
+      panel[r * RS + c] = sum[i];
     }
   };
 
-  // this wave's 16x16 blocks of the upper triangle: q = wave, wave + NWV, ... in row-major order
+  // this wave's 16x16 blocks of the upper triangle: q = wave C + k in row-major order
   const int nb = (n_red + 15) / 16;
+  const int n_blocks = nb * (nb + 1) / 2;
+  const bool mfma_wave = wave * C < n_blocks;
   int b_i[SM_MAXBLK], b_j[SM_MAXBLK];
+  bool b_real[SM_MAXBLK];
 #pragma unroll
   for (int k = 0; k < SM_MAXBLK; ++k) {
-    int q = wave + NWV * k, bi = 0, rowlen = nb;
-    while (bi < nb && q >= rowlen) {
+    int q = wave * C + k, bi = 0, rowlen = nb;
+    b_real[k] = q < n_blocks;
+    if (!b_real[k]) q = 0;
+    while (q >= rowlen) {
       q -= rowlen;
       --rowlen;
       ++bi;
     }
-    b_i[k] = bi < nb ? bi : -1;
+    b_i[k] = bi;
     b_j[k] = bi + q;
   }
   acc_t acc[SM_MAXBLK];
 #pragma unroll
   for (int k = 0; k < SM_MAXBLK; ++k) acc[k] = acc_zero<TC>();
-  const int off = (lane >> 4) * ROW_STRIDE + 3 * (lane & 15);
+  const int off = (lane >> 4) * RS + 3 * (lane & 15);
 
   // De-phase the workgroups that share a CU: they do identical work, so two that start together stay in lock-step
   // and sit in the same phase (fetch wait / LDS group sums / MFMA) at the same time -- the three phases then add up
@@ -757,20 +776,22 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     AGGF_SP_T(q4);
     __syncthreads();
     AGGF_SP_T(q5);
+    if (AGGF_SMALL_ABL != 1 && mfma_wave) {
 #pragma unroll
-    for (int kk = 0; kk < KBS / 4; ++kk)
+      for (int kk = 0; kk < KBS / 4; ++kk)
 #pragma unroll
-      for (int d = 0; d < 3; ++d)
+        for (int d = 0; d < 3; ++d) {
 #pragma unroll
-        for (int k = 0; k < SM_MAXBLK; ++k)
-          if (b_i[k] >= 0 && AGGF_SMALL_ABL != 1) {
-            // (one LDS round trip per MFMA.  Tried: all operands of a group read first -- 20 more VGPRs, spills,
-            // 5.8 -> 9.0 ms; one item ahead -- 10 spills, 6.5 ms; a compile-time block count with straight-line code --
-            // the scheduler hoists every read: 79-108 spilled VGPRs.  The staged frames take the registers.)
-            const TC a = panel[off + kk * 4 * ROW_STRIDE + 48 * b_i[k] + d];
-            const TC b = panel[off + kk * 4 * ROW_STRIDE + 48 * b_j[k] + d];
+          for (int k = 0; k < C; ++k) {
+            const TC a = panel[off + kk * 4 * RS + 48 * b_i[k] + d];
+            const TC b = panel[off + kk * 4 * RS + 48 * b_j[k] + d];
             acc[k] = M::mma(a, b, acc[k]);
           }
+          // (operand reads of the next group stay behind this point: hoisted over the whole phase they spill 70-100
+          // registers at the 128-register cap of two workgroups per CU)
+          __builtin_amdgcn_sched_barrier(0);
+        }
+    }
 #ifdef AGGF_SMALL_PROF
     const uint64_t q6 = __builtin_readcyclecounter();
     pf[0] += q1 - q0;  // barrier 1
@@ -792,7 +813,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   TC* slab = slabs + (int64_t)blockIdx.x * (TILE * TILE);
 #pragma unroll
   for (int k = 0; k < SM_MAXBLK; ++k)
-    if (b_i[k] >= 0) {
+    if (b_real[k]) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) slab[(b_i[k] * 16 + M::row(lane, r)) * TILE + b_j[k] * 16 + (lane & 15)] = acc[k][r];
     }
@@ -1029,30 +1050,48 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   ws += table_bytes(p);
   TC* slabs = reinterpret_cast<TC*>(ws);
   if (p.staging == STAGE_SMALL) {
-    constexpr int kbs = 8, threads = 512;
+    constexpr int threads = 512;
+    // panel width 32 / 64 / 128 reduced columns with 32 / 16 / 8 frames per stage (see gram_small_kernel); the wider
+    // class when the stage's raw frames would not fit the registers that carry them (SM_MAXVEC 16-byte pieces per thread)
+    int width = n_red <= 32 ? 32 : (n_red <= 64 ? 64 : TILE);
+    while (width < TILE && small_raw_bytes<TIn>(N, 8 * TILE / width) / 16 - 1 > (size_t)SM_MAXVEC * threads) width *= 2;
+    const int kbs = 8 * TILE / width;
     const size_t raw_bytes = small_raw_bytes<TIn>(N, kbs);
-    const size_t lds = (size_t)kbs * ROW_STRIDE * sizeof(TC) + raw_bytes + (size_t)round_up(((int64_t)N + TILE + 1) * 4, 16) +
-                       (size_t)ROW_ELEMS * 4 * sizeof(unsigned short);
+    const size_t lds = (size_t)kbs * (3 * width + ROW_PAD) * sizeof(TC) + raw_bytes +
+                       (size_t)round_up(((int64_t)N + TILE + 1) * 4, 16) + (size_t)3 * width * 4 * sizeof(unsigned short);
     const int nv = (int)ceil_div((int64_t)(raw_bytes / 16 - 1), threads);
     if (nv > SM_MAXVEC) return fail(AGGF_ERR_ARG, "aggf_gram: small-system kernel: frame too large");
-#define AGGF_SMALL(NVC, KBC, NWC)                                                                                    \
+    const int nb16 = (n_red + 15) / 16, n_blocks = nb16 * (nb16 + 1) / 2;
+    const int per_wave = (int)ceil_div((int64_t)n_blocks, 8);  // blocks per active wave (template C)
+#define AGGF_SMALL(NVC, KBC, NWC, WC, CC)                                                                            \
   do {                                                                                                               \
     if (lds > 65536) {                                                                                               \
       static thread_local PerDeviceOnce attr_once;                                                                   \
       bool& attr_done = *attr_once.flag();                                                                           \
       if (!attr_done) {                                                                                              \
-        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_kernel<TIn, TC, NVC, KBC, NWC>,                      \
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_small_kernel<TIn, TC, NVC, KBC, NWC, WC, CC>,              \
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));             \
         attr_done = true;                                                                                            \
       }                                                                                                              \
     }                                                                                                                \
-    hipLaunchKernelGGL((gram_small_kernel<TIn, TC, NVC, KBC, NWC>), dim3((unsigned)p.ksplit), dim3(64 * NWC), lds,   \
-                       stream, reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red,                    \
-                       p.frames_per_split, (int32_t)raw_bytes, slabs);                                               \
+    hipLaunchKernelGGL((gram_small_kernel<TIn, TC, NVC, KBC, NWC, WC, CC>), dim3((unsigned)p.ksplit),                \
+                       dim3(64 * NWC), lds, stream, reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms,      \
+                       n_red, p.frames_per_split, (int32_t)raw_bytes, slabs);                                        \
   } while (0)
-    if (nv <= 3) AGGF_SMALL(3, 8, 8);
-    else if (nv <= 5) AGGF_SMALL(5, 8, 8);
-    else AGGF_SMALL(8, 8, 8);
+#define AGGF_SMALL_NV(KBC, WC, CC)                                                                                   \
+  do {                                                                                                               \
+    if (nv <= 3) AGGF_SMALL(3, KBC, 8, WC, CC);                                                                      \
+    else if (nv <= 5) AGGF_SMALL(5, KBC, 8, WC, CC);                                                                 \
+    else AGGF_SMALL(8, KBC, 8, WC, CC);                                                                              \
+  } while (0)
+    if (width == 32) AGGF_SMALL_NV(32, 32, 1);                       // 1 or 3 blocks
+    else if (width == 64 && per_wave <= 1) AGGF_SMALL_NV(16, 64, 1);  // 6 blocks
+    else if (width == 64) AGGF_SMALL_NV(16, 64, 2);                  // 10
+    else if (per_wave <= 2) AGGF_SMALL_NV(8, TILE, 2);               // 15
+    else if (per_wave == 3) AGGF_SMALL_NV(8, TILE, 3);               // 21
+    else if (per_wave == 4) AGGF_SMALL_NV(8, TILE, 4);               // 28
+    else AGGF_SMALL_NV(8, TILE, 5);                                  // 36
+#undef AGGF_SMALL_NV
 #undef AGGF_SMALL
     AGGF_LAUNCH_OK();
     hipLaunchKernelGGL((gram_reduce_small_kernel<TC>), dim3(TILE), dim3(256), 0, stream, slabs, p.ksplit, n_red,

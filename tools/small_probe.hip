@@ -5,9 +5,12 @@
 
 #include <vector>
 
-int main() {
-  const int64_t T = 4000000;
-  const int32_t N = 175, n_red = 97;
+// usage: small_probe            CLN025-like (175 atoms, 97 reduced columns)
+//        small_probe <atoms>    unconstrained system of that many atoms, 16.8 GB of frames
+int main(int argc, char** argv) {
+  const bool plain = argc > 1;
+  const int32_t N = plain ? atoi(argv[1]) : 175, n_red = plain ? N : 97;
+  const int64_t T = plain ? (int64_t)(16.8e9 / (24.0 * N)) : 4000000;
   // CLN025-like groups: 59 groups (38 anchors alone ... here: first 38 atoms alone, then groups of 2-3)
   std::vector<int32_t> ptr(n_red + 1), atoms(N);
   int a = 0;
@@ -38,7 +41,7 @@ int main() {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     hipEventRecord(e0);
-    int rc = aggf_gram(F, T, N, AGGF_F64, AGGF_F64, dptr, datoms, n_red, G, 0, ws, need, nullptr);
+    int rc = aggf_gram(F, T, N, AGGF_F64, AGGF_F64, plain ? nullptr : dptr, plain ? nullptr : datoms, n_red, G, 0, ws, need, nullptr);
     hipEventRecord(e1);
     hipDeviceSynchronize();
     float ms;
@@ -46,7 +49,7 @@ int main() {
     unsigned long long pf[9];
     hipMemcpyFromSymbol(pf, HIP_SYMBOL(aggf::aggf_small_prof), sizeof(pf));
     const double waves = (double)pf[8], stages = (double)pf[7] / waves;
-    printf("rc %d  %.3f ms  waves %.0f  stages/wave %.1f\n", rc, ms, waves, stages);
+    printf("%d atoms, %d columns: rc %d  %.3f ms  waves %.0f  stages/wave %.1f\n", N, n_red, rc, ms, waves, stages);
     const char* names[7] = {"barrier1", "park+loadwait", "barrier2", "group sums", "barrier3", "MFMA phase", "fetch issue"};
     double tot = 0;
     for (int i = 0; i < 7; ++i) tot += (double)pf[i];

@@ -84,6 +84,16 @@ def main():
     fc = K.synth_normal(Tc, Nc, torch.float64, 6, sigma=30.0)
     report("gram_small_kernel<double,double> (CLN025, n_red 97)", fc.numel() * 8, timed(lambda: prob.gram(fc)),
            "HBM / MFMA / LDS co-limited, see DESIGN section 6")
+    del fc
+    # K1s below the ridge point (fp64: 3 n^2 flop per 24 n bytes = n / 8 flop/B against 12.5 of the machine): the same
+    # kernel on systems where the HBM alone is the bound
+    for Ns in (32, 64, 96, 128):
+        Ts = int(16.8e9 / (Ns * 24))
+        fs = K.synth_normal(Ts, Ns, torch.float64, 7, sigma=30.0)
+        ps = LinearProblem(LinearMap([[0], [Ns // 2]], n_fg_sites=Ns), None, torch.device("cuda", 0))
+        report(f"gram_small_kernel<double,double> ({Ns} atoms unconstrained, {Ts} frames)", fs.numel() * 8,
+               timed(lambda: ps.gram(fs)), f"{Ns / 8:.0f} flop/B")
+        del fs
 
 
 if __name__ == "__main__":
