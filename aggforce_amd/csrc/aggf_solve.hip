@@ -464,7 +464,7 @@ __global__ __launch_bounds__(256) void potrf_diag_mfma_kernel(double* __restrict
 // factors the diagonal block ITSELF (the same 32 KB from the L2 for all of them, ~13 us of redundant work on otherwise
 // idle CUs) and then owns row blocks blockIdx.x, blockIdx.x + gridDim.x, ...: the chain diag -> panel -> inner update of
 // the right-looking form (three dependent launches, 28 + 13 + 13 us at n = 4096) becomes one launch.  Workgroup 0 stores
-// the factor of the diagonal block and its inverse.  blockIdx.y = problem of a batched solve.
+// the inverse of the diagonal block (the block itself stays as it was: see below).  blockIdx.y = problem of a batched solve.
 constexpr int STEP_LDS = 4 * NB * (NB + 1) * (int)sizeof(double);
 __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, int64_t ld, int k, int j, int nrb,
                                                        double* __restrict__ Linv, double* __restrict__ info,
@@ -536,12 +536,12 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, 
       x[row][col] = 0.0;
     }
   potrf64_factor_invert(a, x, info, pivot_base);
+  // Workgroup 0 stores the inverse.  The FACTOR of the diagonal block is not stored: every workgroup of this launch
+  // reads the block from P when it starts, and one that is dispatched late (a busy GPU, a second process on it) would
+  // find it half overwritten -- seen once as two ranks of a rehearsal on one GPU disagreeing on the solved map.  Nothing
+  // reads the diagonal blocks of the factor afterwards: the solves use their inverses, the updates the blocks below.
   if (blockIdx.x == 0) {
-    for (int e = tid; e < NB * NB; e += 256) {
-      const int r = e / NB, c = e - r * NB;
-      if (c <= r) P[(kr + r) * ld + kr + c] = a[r][c];
-      Linv[r * NB + c] = x[r][c];
-    }
+    for (int e = tid; e < NB * NB; e += 256) Linv[e] = x[e / NB][e % NB];
   }
   // rows below: L(r, k) = U X'   (X lower triangular: column tile t needs the contraction index up to 16 (t + 1) only)
   for (bool first = true; rb < nrb; rb += gridDim.x, first = false) {
