@@ -357,9 +357,13 @@ __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict
 // 8 frames x 3 = 24 columns = two 16-column blocks (waves 0 and 1 multiply, all 8 waves fetch and park); stages are
 // dealt round-robin to 2 resident workgroups per CU.  NaN policy, fused NaN scan and sum of squares as in the tile
 // kernel.
-constexpr int AS_KB = 8, AS_THREADS = 512, AS_NV = 5;   // 5 x 16 B x 512 threads = 40 KB of frames per stage
+// Frames per stage KB = 8 / 12 / 20 / 40 (-> 24 / 36 / 60 / 120 columns in NBLK = 2 / 4 / 4 / 8 blocks of 16, the K steps
+// of a block split over KQ = 4 / 2 / 2 / 1 waves), chosen so that a stage is ~30 KB of frames whatever the atom count: with 8 frames
+// for everything, 32 atoms streamed at 0.36 of 8 TB/s and 64 atoms at 0.50 against 0.68 at 128 atoms (two barriers and
+// the partial-sum exchange per 6 KB / 12 KB of frames; profiles/r04_stream_kernels.jsonl).
+constexpr int AS_THREADS = 512, AS_NV = 5;   // 5 x 16 B x 512 threads = 40 KB of frames per stage at most
 
-template <typename TIn, typename TC, bool NANREP>
+template <typename TIn, typename TC, bool NANREP, int AS_KB, int NBLK>
 __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
     const TIn* __restrict__ P, int64_t T, int32_t N, const TC* __restrict__ Mx, int32_t n_cg, TC nan_fill,
     int32_t raw_bytes, int32_t n_pad, TC* __restrict__ out, double* __restrict__ sumsq_partials,
@@ -442,12 +446,14 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
   };
 
   // MFMA operands.  A[i = site][k = atom]: lane reads ms[lane & 15][a0 + (lane >> 4)].
-  // B[k = atom][j = column]: column j = 16 blk + (lane & 15) = 3 t + d (j < 24; others: the zero slot).
-  // All 8 waves multiply: wave = (column block blk = wave & 1) x (K quarter kq = wave >> 1: K steps kq, kq + 4,
-  // ...); the 4 partial accumulators of a block are summed through LDS in a fixed order.  (With only the two
+  // B[k = atom][j = column]: column j = 16 blk + (lane & 15) = 3 t + d (j < 3 KB; others: the zero slot).
+  // All 8 waves multiply: wave = (column block blk = wave % NBLK) x (K share kq = wave / NBLK: K steps kq, kq + KQ,
+  // ...); the KQ partial accumulators of a block are summed through LDS in a fixed order.  (With only the two
   // block waves multiplying, the 44 dependent LDS-read + MFMA steps of a stage were the critical path: 7.1 ms at
   // CLN025 x 4e6 frames.)
-  const int blk = wave & 1, kq = wave >> 1;
+  constexpr int KQ = 8 / NBLK;
+  static_assert(NBLK * KQ == 8 && 16 * NBLK >= 3 * AS_KB, "wave split");
+  const int blk = wave % NBLK, kq = wave / NBLK;
   const int offA = (lane & 15) * ms_ld + (lane >> 4);
   const int j = 16 * blk + (lane & 15);
   const bool col_ok = j < AS_KB * 3;
@@ -466,8 +472,8 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
     if (s + 1 < n_it) fetch(s + 1);
     acc_t acc = acc_zero<TC>();
     // two K steps per trip: both pairs of operand reads are in flight before the first MFMA
-    for (int a0 = 4 * kq; a0 < n_pad; a0 += 32) {
-      const int a1 = a0 + 16;
+    for (int a0 = 4 * kq; a0 < n_pad; a0 += 8 * KQ) {
+      const int a1 = a0 + 4 * KQ;
       const bool second = a1 < n_pad;
       const TC xa = ms[offA + a0];
       // atoms past N (the last K step): the element at that address belongs to the NEXT frame -- read the zero
@@ -488,10 +494,9 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
         for (int r = 0; r < 4; ++r) {
           const int c = MF::row(lane, r);
           if (c < n_cg) {
-            TC v = part[((blk + 0) * 4 + r) * 64 + lane];
-            v += part[((blk + 2) * 4 + r) * 64 + lane];
-            v += part[((blk + 4) * 4 + r) * 64 + lane];
-            v += part[((blk + 6) * 4 + r) * 64 + lane];
+            TC v = part[(blk * 4 + r) * 64 + lane];
+#pragma unroll
+            for (int q = 1; q < KQ; ++q) v += part[((blk + NBLK * q) * 4 + r) * 64 + lane];
             out[(t * n_cg + c) * 3 + jd] = v;
             ss += (double)v * (double)v;
           }
@@ -503,22 +508,34 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
   if (sumsq_partials) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) ss += __shfl_down(ss, off, 64);
-    __shared__ double wsum[2];
-    if (lane == 0 && wave < 2) wsum[wave] = ss;  // (waves 0 and 1 wrote the outputs)
+    __shared__ double wsum[NBLK];
+    if (lane == 0 && wave < NBLK) wsum[wave] = ss;  // (the kq = 0 waves wrote the outputs)
     __syncthreads();
-    if (tid == 0) sumsq_partials[blockIdx.x] = wsum[0] + wsum[1];
+    if (tid == 0) {
+      double tot = wsum[0];
+#pragma unroll
+      for (int q = 1; q < NBLK; ++q) tot += wsum[q];
+      sumsq_partials[blockIdx.x] = tot;
+    }
   }
 }
 
-template <typename TIn, typename TC>
+// frames per stage of the few-sites kernel for this frame size (0: the frames of even 8 do not fit the registers)
+template <typename TIn>
+static int apply_small_frames(int32_t N) {
+  const int64_t frame = (int64_t)3 * N * (int64_t)sizeof(TIn), cap = (int64_t)AS_NV * AS_THREADS * 16;
+  return 40 * frame <= cap ? 40 : (20 * frame <= cap ? 20 : (12 * frame <= cap ? 12 : (8 * frame <= cap ? 8 : 0)));
+}
+
+template <typename TIn, typename TC, int KB, int NBLK>
 static int apply_small_launch(const void* P, int64_t T, int32_t N, const void* Mx, int32_t n_cg, int nan_mode,
                               double nan_fill, void* out, double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes,
                               hipStream_t stream) {
-  const int32_t raw_bytes = (int32_t)((int64_t)AS_KB * 3 * N * sizeof(TIn));  // a multiple of 16 for 4- and 8-byte elements
+  const int32_t raw_bytes = (int32_t)((int64_t)KB * 3 * N * sizeof(TIn));  // a multiple of 16 for 4- and 8-byte elements
   const int32_t n_pad = (int32_t)round_up(N, 4);
   const size_t lds = (size_t)raw_bytes + 64 + (size_t)16 * (n_pad + 2) * sizeof(TC) + (size_t)8 * 4 * 64 * sizeof(TC);
   int64_t nwg = 2 * (int64_t)device_cu_count();
-  const int64_t n_stage_all = ceil_div(T, AS_KB);
+  const int64_t n_stage_all = ceil_div(T, KB);
   if (nwg > n_stage_all) nwg = n_stage_all;
   double* partials = nullptr;
   if (sumsq) {
@@ -532,19 +549,19 @@ static int apply_small_launch(const void* P, int64_t T, int32_t N, const void* M
     bool& done = rep ? *once_t.flag() : *once_f.flag();
     if (!done) {
       if (rep)
-        AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_small_kernel<TIn, TC, true>,
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_small_kernel<TIn, TC, true, KB, NBLK>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
       else
-        AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_small_kernel<TIn, TC, false>,
+        AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_small_kernel<TIn, TC, false, KB, NBLK>,
                                         hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
       done = true;
     }
   }
   if (rep)
-    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, true>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
+    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, true, KB, NBLK>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
                        (const TIn*)P, T, N, (const TC*)Mx, n_cg, (TC)nan_fill, raw_bytes, n_pad, (TC*)out, partials, nan_seen);
   else
-    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, false>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
+    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, false, KB, NBLK>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
                        (const TIn*)P, T, N, (const TC*)Mx, n_cg, (TC)0, raw_bytes, n_pad, (TC*)out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
@@ -862,9 +879,16 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   // workgroups per CU (103 ms), 64 x 256 at 4 waves per SIMD (spills: 282 ms), 32 x 256 at 2 waves per SIMD (P read
   // once, 232 registers: 109.8 against 108.4 ms).
   // few sites: the streaming kernel (frames of a stage must fit AS_NV 16-byte loads per thread; P 16-byte aligned)
-  if (n_cg <= 16 && (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) <= (int64_t)AS_NV * AS_THREADS * 16 &&
-      (int64_t)AS_KB * 3 * N * (int64_t)sizeof(TIn) >= 16 && (((uintptr_t)P & 15) == 0) && T >= 64)
-    return apply_small_launch<TIn, TC>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
+  const int small_kb = apply_small_frames<TIn>(N);
+  if (n_cg <= 16 && small_kb > 0 && (((uintptr_t)P & 15) == 0) && T >= 64) {
+    if (small_kb == 40)
+      return apply_small_launch<TIn, TC, 40, 8>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
+    if (small_kb == 20)
+      return apply_small_launch<TIn, TC, 20, 4>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
+    if (small_kb == 12)
+      return apply_small_launch<TIn, TC, 12, 4>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
+    return apply_small_launch<TIn, TC, 8, 2>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
+  }
   if (n_cg > 64) {
     if constexpr (std::is_same<TIn, double>::value && std::is_same<TC, double>::value) {
       if (nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && N >= 2 * AD_KA)

@@ -93,6 +93,10 @@ def main():
         ps = LinearProblem(LinearMap([[0], [Ns // 2]], n_fg_sites=Ns), None, torch.device("cuda", 0))
         report(f"gram_small_kernel<double,double> ({Ns} atoms unconstrained, {Ts} frames)", fs.numel() * 8,
                timed(lambda: ps.gram(fs)), f"{Ns / 8:.0f} flop/B")
+        # K3s: a dense 4-site map applied to the same frames (apply_small_kernel)
+        ms4 = LinearMap(np.abs(np.random.default_rng(Ns).standard_normal((4, Ns))) + 0.1)
+        report(f"apply_small_kernel<double,double> ({Ns} atoms -> 4 sites, {Ts} frames)", fs.numel() * 8 + Ts * 4 * 24,
+               timed(lambda: ms4(fs)), "read (T, N, 3), write (T, 4, 3)")
         del fs
 
 
