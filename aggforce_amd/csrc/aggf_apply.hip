@@ -319,29 +319,35 @@ __global__ __launch_bounds__(256) void sum_partials_kernel(const double* __restr
 // in which the reference's NaN -> 0 / NaN -> -1 products differ, map/core.py:226-236).
 constexpr int SG_UF = 8;
 
+// `lanes` (a power of two <= 256) threads serve one frame's 3 n_cg output elements and 256 / lanes frames share a
+// workgroup pass: with few sites (CLN025: 30 elements) a whole workgroup per frame left 226 of its 256 threads idle
+// (c1: 3.7 ms for 5 GB of lines).
 template <typename TIn, typename TO>
 __global__ __launch_bounds__(256) void slice_gather_kernel(const TIn* __restrict__ P, int64_t T,
                                                            int32_t N, const int32_t* __restrict__ idx,
                                                            int32_t n_cg, TO* __restrict__ out,
-                                                           int32_t* __restrict__ nan_seen) {
+                                                           int32_t* __restrict__ nan_seen, int lanes) {
   const int row_out = n_cg * 3;
-  const int e = blockIdx.y * 256 + threadIdx.x;
+  const int fpw = 256 / lanes;                       // frames per workgroup pass
+  const int f = threadIdx.x / lanes;                 // this thread's frame inside a pass
+  const int e = blockIdx.y * lanes + (threadIdx.x & (lanes - 1));
   const bool valid = e < row_out;
   const int c = valid ? e / 3 : 0;
   const int64_t off = (int64_t)idx[c] * 3 + (e - 3 * c);
   const int64_t row_in = (int64_t)N * 3;
   bool saw_nan = false;
-  for (int64_t t0 = (int64_t)blockIdx.x * SG_UF; t0 < T; t0 += (int64_t)gridDim.x * SG_UF) {
+  const int64_t step = (int64_t)SG_UF * fpw;
+  for (int64_t t0 = (int64_t)blockIdx.x * step + f; t0 < T; t0 += (int64_t)gridDim.x * step) {
     TIn v[SG_UF];
 #pragma unroll
     for (int u = 0; u < SG_UF; ++u) {
       v[u] = (TIn)0;
-      if (valid && t0 + u < T) v[u] = __builtin_nontemporal_load(P + (t0 + u) * row_in + off);
+      if (valid && t0 + (int64_t)u * fpw < T) v[u] = __builtin_nontemporal_load(P + (t0 + (int64_t)u * fpw) * row_in + off);
     }
 #pragma unroll
     for (int u = 0; u < SG_UF; ++u) {
       saw_nan |= (v[u] != v[u]);
-      if (valid && t0 + u < T) __builtin_nontemporal_store((TO)v[u], out + (t0 + u) * row_out + e);
+      if (valid && t0 + (int64_t)u * fpw < T) __builtin_nontemporal_store((TO)v[u], out + (t0 + (int64_t)u * fpw) * row_out + e);
     }
   }
   if (nan_seen && __any(saw_nan) && (threadIdx.x & 63) == 0) atomicOr(nan_seen, 1);
@@ -948,24 +954,26 @@ extern "C" int aggf_slice_gather(const void* P, int64_t T, int32_t N, int in_dty
   hipStream_t stream = (hipStream_t)stream_v;
   if (!P || !idx || !out) return fail(AGGF_ERR_ARG, "aggf_slice_gather: NULL pointer");
   if (T <= 0 || N <= 0 || n_cg <= 0) return fail(AGGF_ERR_ARG, "aggf_slice_gather: empty problem");
-  const int64_t gy = ceil_div((int64_t)n_cg * 3, 256);
+  int lanes = 256;  // threads per frame: the smallest power of two that covers the frame's 3 n_cg elements
+  while (lanes > 1 && lanes / 2 >= n_cg * 3) lanes /= 2;
+  const int64_t gy = ceil_div((int64_t)n_cg * 3, lanes);
   if (gy > 65535) return fail(AGGF_ERR_ARG, "aggf_slice_gather: too many sites");
   // enough workgroups to keep the memory system busy on their own (8 frames in flight per thread), few enough that
   // the kernel stays a guest beside a compute kernel on another stream; AGGF_GATHER_WGS overrides (benchmarks)
   static const char* force = getenv("AGGF_GATHER_WGS");
   int64_t gx = force ? atoll(force) : 4 * (int64_t)device_cu_count() / gy;
-  const int64_t need = ceil_div(T, SG_UF);
+  const int64_t need = ceil_div(T, (int64_t)SG_UF * (256 / lanes));
   if (gx > need) gx = need;
   if (gx < 1) gx = 1;
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out, nan_seen);
+    hipLaunchKernelGGL((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out, nan_seen, lanes);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out, nan_seen);
+    hipLaunchKernelGGL((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out, nan_seen, lanes);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out, nan_seen);
+    hipLaunchKernelGGL((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out, nan_seen, lanes);
   else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out, nan_seen);
+    hipLaunchKernelGGL((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out, nan_seen, lanes);
   else
     return fail(AGGF_ERR_ARG, "aggf_slice_gather: unsupported dtype combination");
   AGGF_LAUNCH_OK();
