@@ -593,6 +593,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   // system.  (With the 128-wide panel for everything, 32 atoms streamed at 0.19 of 8 TB/s and 64 atoms at 0.30
   // against CLN025's 0.45: profiles/r04_stream_kernels.jsonl.)
   constexpr int RE = 3 * W, RS = RE + ROW_PAD;              // panel row: elements / stride
+  constexpr int WT = W > TILE ? W : TILE;                   // edge of the slab (and of the column tables)
   constexpr int SM_ENT = KBS * RE / SM_THREADS;             // panel entries per thread and stage: 6
   // C = 16x16 blocks of the upper triangle per ACTIVE wave: wave w owns blocks w C .. w C + C - 1 of the row-major list
   // (n_blocks <= NWV C); the waves behind the list skip the MFMA phase, the last active one pads its share with
@@ -608,11 +609,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   TIn* raw = reinterpret_cast<TIn*>(smem_raw + KBS * RS * sizeof(TC));  // SM_KB frames as in HBM
   // (raw_bytes includes one extra zeroed 16-byte piece: the "no member" slot of the table below)
   int32_t* atoms_s = reinterpret_cast<int32_t*>(smem_raw + KBS * RS * sizeof(TC) + raw_bytes);  // [N]
-  int32_t* ptr_s = atoms_s + N;                                                                           // [129]
+  int32_t* ptr_s = atoms_s + N;                                                                           // [WT + 1]
   // per panel column c = 3 g + d: offsets (3 atom + d) of the first 4 members of group g inside a frame,
   // 0xFFFF = none -- one 8-byte LDS read instead of a chain of dependent ones per member
   unsigned short* memb_s = reinterpret_cast<unsigned short*>(smem_raw + KBS * RS * sizeof(TC) + raw_bytes +
-                                                             (((int64_t)N + TILE + 1) * 4 + 15) / 16 * 16);  // [384][4]
+                                                             (((int64_t)N + WT + 1) * 4 + 15) / 16 * 16);  // [RE][4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // Stages are dealt round-robin to the workgroups (stage = blockIdx.x + k * gridDim.x): the workgroups that run
@@ -627,7 +628,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   const int64_t row_in = (int64_t)N * 3;
   // column -> member atoms (CSR) in LDS; without constraint groups column g is atom g
   for (int a = tid; a < N; a += SM_THREADS) atoms_s[a] = grp_atoms ? grp_atoms[a] : a;
-  for (int g = tid; g <= TILE; g += SM_THREADS) ptr_s[g] = g <= n_red ? (grp_ptr ? grp_ptr[g] : g) : (grp_ptr ? grp_ptr[n_red] : n_red);
+  for (int g = tid; g <= WT; g += SM_THREADS) ptr_s[g] = g <= n_red ? (grp_ptr ? grp_ptr[g] : g) : (grp_ptr ? grp_ptr[n_red] : n_red);
   const int zero_idx = (raw_bytes - 16) / (int)sizeof(TIn);
   if (tid < 16 / (int)sizeof(TIn)) raw[zero_idx + tid] = (TIn)0;
   __syncthreads();
@@ -829,26 +830,26 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     atomicAdd(&aggf_small_prof[8], 1ull);
   }
 #endif
-  TC* slab = slabs + (int64_t)blockIdx.x * (TILE * TILE);
+  TC* slab = slabs + (int64_t)blockIdx.x * (WT * WT);
 #pragma unroll
   for (int k = 0; k < SM_MAXBLK; ++k)
     if (b_real[k]) {
 #pragma unroll
-      for (int r = 0; r < 4; ++r) slab[(b_i[k] * 16 + M::row(lane, r)) * TILE + b_j[k] * 16 + (lane & 15)] = acc[k][r];
+      for (int r = 0; r < 4; ++r) slab[(b_i[k] * 16 + M::row(lane, r)) * WT + b_j[k] * 16 + (lane & 15)] = acc[k][r];
     }
 }
 
 // Slab sum of the single-tile (small-system) path: one workgroup per row of G instead of the generic kernel's 16
 // workgroups per tile (those took 0.84 ms for the 512 slabs of CLN025 -- 15 % of the Gram build).  Thread =
 // (column, parity of the slab index); fixed summation order; upper triangle written and mirrored.
-template <typename T>
-__global__ __launch_bounds__(256) void gram_reduce_small_kernel(const T* __restrict__ slabs, int32_t ksplit,
-                                                                int32_t n_red, int accumulate,
-                                                                double* __restrict__ G) {
-  __shared__ double part[2][TILE];
-  const int row = blockIdx.x, col = threadIdx.x & (TILE - 1), half = threadIdx.x >> 7;
+template <typename T, int WT>
+__global__ __launch_bounds__(2 * WT) void gram_reduce_small_kernel(const T* __restrict__ slabs, int32_t ksplit,
+                                                                   int32_t n_red, int accumulate,
+                                                                   double* __restrict__ G) {
+  __shared__ double part[2][WT];
+  const int row = blockIdx.x, col = threadIdx.x & (WT - 1), half = threadIdx.x / WT;
   double s = 0.0;
-  for (int ks = half; ks < ksplit; ks += 2) s += (double)slabs[((int64_t)ks * TILE + row) * TILE + col];
+  for (int ks = half; ks < ksplit; ks += 2) s += (double)slabs[((int64_t)ks * WT + row) * WT + col];
   part[half][col] = s;
   __syncthreads();
   if (half == 0 && row < n_red && col < n_red && col >= row) {
@@ -912,7 +913,8 @@ static size_t table_bytes(const GramPlan& p) { return (size_t)round_up((int64_t)
 // fp64 at C3: 757 ms (4 waves with the DMAs up front 786 ms, register staging 810 ms, pair tiles and the float32
 // "quad" shape no better: profiles/r04_pruned_variants.patch holds those kernels).
 static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int compute_dtype,
-                     bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p, int32_t first_col = 0) {
+                     bool has_groups, bool aligned, size_t ws_bytes, bool query, GramPlan* p, int32_t first_col = 0,
+                     bool tiles_only = false) {  // tiles_only: the caller's kernel is the tile kernel (aggf_gram_pair)
   p->n_pad = (int32_t)round_up(n_red, TILE);
   p->nt1 = p->n_pad / TILE;
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
@@ -922,8 +924,13 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   // Small systems: register-staged, 8 frames x 8 waves (6.5 ms at CLN025 x 4e6 frames; an LDS-DMA ring of 4 frames per
   // stage took 6.8-7.0 ms, 4 x 4 waves more: profiles/r04_pruned_variants.patch).
   const size_t raw_small = (size_t)round_up((int64_t)8 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
+  // Two output tiles (128 < n_red <= 256): the same kernel with a 256-column panel, 4 frames per stage and 16 waves,
+  // ONE workgroup per CU -- no packed copy, no padding to whole 128-tiles inside the products, constraint groups and
+  // conversion on the way (the pack + tile pipeline spent 19.7 ms on 12 GB of 320-atom frames, 22.6 ms on 144 atoms).
+  const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
+  const bool wide = p->nt1 == 2 && first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
-  if (p->nt1 == 1 && !no_small && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16 && N < 21000 && aligned) {
+  if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide) && !no_small && !tiles_only && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
     // triangle blocks only); one slab per workgroup, 2 workgroups per CU over the frame axis
     p->staging = STAGE_SMALL;
@@ -931,11 +938,11 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->direct = true;
     p->chunk_frames = T;
     p->pack_bytes = 0;
-    // one resident generation of workgroups (2 per CU), each looping over strided stages
-    int64_t nwg = (int64_t)2 * device_cu_count();
+    // one resident generation of workgroups (2 per CU; 1 with the 256-column panel), each looping over strided stages
+    int64_t nwg = (int64_t)(p->nt1 == 2 ? 1 : 2) * device_cu_count();
     const int64_t n_stage_all = ceil_div(T, 8);
     if (nwg > n_stage_all) nwg = n_stage_all;
-    const size_t slab1s = (size_t)TILE * TILE * dtype_size(compute_dtype);
+    const size_t slab1s = (size_t)p->n_pad * p->n_pad * dtype_size(compute_dtype);
     if (!query) {
       if (ws_bytes < table_bytes(*p) + slab1s + 512) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
       const int64_t max_splits = (int64_t)((ws_bytes - table_bytes(*p) - 512) / slab1s);
@@ -1074,14 +1081,17 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     // class when the stage's raw frames would not fit the registers that carry them (SM_MAXVEC 16-byte pieces per thread)
     int width = n_red <= 32 ? 32 : (n_red <= 64 ? 64 : TILE);
     while (width < TILE && small_raw_bytes<TIn>(N, 8 * TILE / width) / 16 - 1 > (size_t)SM_MAXVEC * threads) width *= 2;
+    if (p.nt1 == 2) width = 2 * TILE;
     const int kbs = 8 * TILE / width;
+    const int wt = width > TILE ? width : TILE;
+    const int n_thr = width > TILE ? 1024 : threads;
     const size_t raw_bytes = small_raw_bytes<TIn>(N, kbs);
     const size_t lds = (size_t)kbs * (3 * width + ROW_PAD) * sizeof(TC) + raw_bytes +
-                       (size_t)round_up(((int64_t)N + TILE + 1) * 4, 16) + (size_t)3 * width * 4 * sizeof(unsigned short);
-    const int nv = (int)ceil_div((int64_t)(raw_bytes / 16 - 1), threads);
-    if (nv > SM_MAXVEC) return fail(AGGF_ERR_ARG, "aggf_gram: small-system kernel: frame too large");
+                       (size_t)round_up(((int64_t)N + wt + 1) * 4, 16) + (size_t)3 * width * 4 * sizeof(unsigned short);
+    const int nv = (int)ceil_div((int64_t)(raw_bytes / 16 - 1), n_thr);
+    if (nv > SM_MAXVEC || (width > TILE && nv > 5)) return fail(AGGF_ERR_ARG, "aggf_gram: small-system kernel: frame too large");
     const int nb16 = (n_red + 15) / 16, n_blocks = nb16 * (nb16 + 1) / 2;
-    const int per_wave = (int)ceil_div((int64_t)n_blocks, 8);  // blocks per active wave (template C)
+    const int per_wave = (int)ceil_div((int64_t)n_blocks, width > TILE ? 16 : 8);  // blocks per active wave (template C)
 #define AGGF_SMALL(NVC, KBC, NWC, WC, CC)                                                                            \
   do {                                                                                                               \
     if (lds > 65536) {                                                                                               \
@@ -1103,18 +1113,35 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     else if (nv <= 5) AGGF_SMALL(5, KBC, 8, WC, CC);                                                                 \
     else AGGF_SMALL(8, KBC, 8, WC, CC);                                                                              \
   } while (0)
+#define AGGF_SMALL_WIDE(CC)                                                                                          \
+  do {                                                                                                               \
+    if (nv <= 3) AGGF_SMALL(3, 4, 16, 2 * TILE, CC);                                                                 \
+    else AGGF_SMALL(5, 4, 16, 2 * TILE, CC);                                                                         \
+  } while (0)
     if (width == 32) AGGF_SMALL_NV(32, 32, 1);                       // 1 or 3 blocks
     else if (width == 64 && per_wave <= 1) AGGF_SMALL_NV(16, 64, 1);  // 6 blocks
     else if (width == 64) AGGF_SMALL_NV(16, 64, 2);                  // 10
-    else if (per_wave <= 2) AGGF_SMALL_NV(8, TILE, 2);               // 15
-    else if (per_wave == 3) AGGF_SMALL_NV(8, TILE, 3);               // 21
-    else if (per_wave == 4) AGGF_SMALL_NV(8, TILE, 4);               // 28
-    else AGGF_SMALL_NV(8, TILE, 5);                                  // 36
+    else if (width == TILE && per_wave <= 2) AGGF_SMALL_NV(8, TILE, 2);   // 15
+    else if (width == TILE && per_wave == 3) AGGF_SMALL_NV(8, TILE, 3);   // 21
+    else if (width == TILE && per_wave == 4) AGGF_SMALL_NV(8, TILE, 4);   // 28
+    else if (width == TILE) AGGF_SMALL_NV(8, TILE, 5);                    // 36
+    else if (per_wave <= 3) AGGF_SMALL_WIDE(3);                      // 256-column panel, 16 waves: 45 blocks
+    else if (per_wave == 4) AGGF_SMALL_WIDE(4);                      // 55
+    else if (per_wave == 5) AGGF_SMALL_WIDE(5);                      // 66, 78
+    else if (per_wave == 6) AGGF_SMALL_WIDE(6);                      // 91
+    else if (per_wave == 7) AGGF_SMALL_WIDE(7);                      // 105
+    else if (per_wave == 8) AGGF_SMALL_WIDE(8);                      // 120
+    else AGGF_SMALL_WIDE(9);                                         // 136
+#undef AGGF_SMALL_WIDE
 #undef AGGF_SMALL_NV
 #undef AGGF_SMALL
     AGGF_LAUNCH_OK();
-    hipLaunchKernelGGL((gram_reduce_small_kernel<TC>), dim3(TILE), dim3(256), 0, stream, slabs, p.ksplit, n_red,
-                       accumulate, G);
+    if (width > TILE)
+      hipLaunchKernelGGL((gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
+                         n_red, accumulate, G);
+    else
+      hipLaunchKernelGGL((gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
+                         accumulate, G);
     AGGF_LAUNCH_OK();
     return AGGF_OK;
   }
@@ -1300,7 +1327,9 @@ static int gram_pair_typed(const T* F, const T* F2, int64_t rows, int32_t N, int
 
 extern "C" size_t aggf_gram_pair_workspace_bytes(int64_t T, int32_t N, int32_t N2, int dtype) {
   if (T <= 0 || N <= 0 || N2 <= 0) return 0;
-  return aggf_gram_workspace_bytes(T, N + N2, N + N2, dtype, dtype, 0);
+  GramPlan p;
+  make_plan(T, N + N2, N + N2, dtype, dtype, false, true, 0, true, &p, 0, true);
+  return table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) + p.pack_bytes + 1024;
 }
 
 extern "C" int aggf_gram_pair(const void* F, int32_t N, const void* F2, int32_t N2, int64_t T, int dtype, double* G,
@@ -1314,7 +1343,7 @@ extern "C" int aggf_gram_pair(const void* F, int32_t N, const void* F2, int32_t 
   if ((((uintptr_t)F | (uintptr_t)F2) & 15) != 0) return fail(AGGF_ERR_ARG, "aggf_gram_pair: arrays must be 16-byte aligned");
   if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram_pair: workspace not 256-byte aligned");
   GramPlan p;
-  int rc = make_plan(T, N + N2, N + N2, dtype, dtype, false, true, ws_bytes, false, &p, 0);
+  int rc = make_plan(T, N + N2, N + N2, dtype, dtype, false, true, ws_bytes, false, &p, 0, true);
   if (rc) return rc;
   if (!p.direct || p.staging == STAGE_SMALL) return fail(AGGF_ERR_ARG, "aggf_gram_pair: unsupported layout");
   if (table_bytes(p) + (size_t)round_up((int64_t)p.slab_bytes, 256) > ws_bytes)

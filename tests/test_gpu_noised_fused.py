@@ -85,7 +85,8 @@ def test_noised_map_without_extended_arrays_matches_oracle_and_general_path(name
 
 
 def test_gram_pair_and_augmented_gram_kernels():
-    """aggf_gram_pair == aggf_gram of the concatenation (bit for bit: same tiles, same order); aggf_augmented_gram and
+    """aggf_gram_pair == aggf_gram of the concatenation -- bit for bit where both run the tile kernel (same tiles, same
+    order), to rounding at 256 columns, where aggf_gram takes the 256-column streaming kernel; aggf_augmented_gram and
     aggf_sym_group_reduce against dense NumPy algebra."""
     rng = np.random.default_rng(5)
     for dt, T, N, N2 in [(torch.float64, 333, 256, 128), (torch.float32, 1000, 384, 256), (torch.float64, 64, 128, 128)]:
@@ -94,7 +95,10 @@ def test_gram_pair_and_augmented_gram_kernels():
         assert K.gram_pair_ok(a, b)
         Gp = K.gram_pair(a, b)
         Gc = K.gram(torch.cat([a, b], dim=1).contiguous(), None, None, N + N2, dt)
-        assert torch.equal(Gp, Gc)
+        if N + N2 > 256:
+            assert torch.equal(Gp, Gc)
+        else:
+            assert float((Gp - Gc).abs().max()) < 1e-12 * float(Gc.abs().max())
     assert not K.gram_pair_ok(a[:, :100].contiguous(), b)
     n, n2 = 200, 56
     X = rng.standard_normal((n + n2, n + n2))

@@ -1,0 +1,50 @@
+"""GPU box: K1 (aggf_gram) and K3 (aggf_linearmap_apply) over system sizes between the single-tile kernels' range and the
+BASELINE sizes -- ~12 GB of fp64 frames each, unconstrained, 1/16 of the atoms as sites.  JSON lines: time, the rate
+against the roofline that bounds the size (HBM below n/8 = 12.5 flop/B, fp64 MFMA above)."""
+import json
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from aggforce_amd import LinearMap  # noqa: E402
+from aggforce_amd import _kernels as K  # noqa: E402
+
+
+def timed(fn, n=4):
+    fn()
+    torch.cuda.synchronize()
+    best = 1e9
+    for _ in range(n):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    return best
+
+
+def main():
+    sizes = [int(a) for a in sys.argv[1:]] or [144, 192, 256, 320, 384, 512, 768, 1024, 2048]
+    for N in sizes:
+        T = int(12e9 / (24 * N)) // 64 * 64
+        f = K.synth_normal(T, N, torch.float64, 11, sigma=30.0)
+        tg = timed(lambda: K.gram(f, None, None, N, torch.float64))
+        flop = 3.0 * T * N * (N + 1)
+        n_cg = max(1, N // 16)
+        m = torch.from_numpy(np.abs(np.random.default_rng(N).standard_normal((n_cg, N))) + 0.1).cuda()
+        ta = timed(lambda: K.linearmap_apply(f, m))
+        aflop = 2.0 * T * 3 * N * n_cg
+        gb = f.numel() * 8 / 1e9
+        print(json.dumps({"atoms": N, "frames": T, "GB": round(gb, 2),
+                          "gram_ms": round(tg * 1e3, 3), "gram_TFLOPs": round(flop / tg / 1e12, 1),
+                          "gram_frac_mfma": round(flop / tg / 78.6e12, 3), "gram_frac_hbm": round(gb / tg / 8000, 3),
+                          "sites": n_cg, "apply_ms": round(ta * 1e3, 3), "apply_frac_mfma": round(aflop / ta / 78.6e12, 3),
+                          "apply_frac_hbm": round(gb / ta / 8000, 3)}), flush=True)
+        del f, m
+
+
+if __name__ == "__main__":
+    main()
