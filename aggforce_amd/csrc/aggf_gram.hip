@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   // conditional MFMA in copies of the accumulator set behind an s_nop for the MFMA's full latency -- ~150 cycles per
   // block step and nothing overlapped (tools/small_probe.hip: MFMA phase 3500 of 10300 cycles per stage at CLN025).
   constexpr int SM_MAXBLK = C;
-  static_assert(KBS * RE % SM_THREADS == 0 && KBS * W == 8 * TILE, "entry split");
+  static_assert(KBS * RE % SM_THREADS == 0 && KBS >= 4 && (KBS * W == 8 * TILE || (KBS == 4 && W > 2 * TILE)), "entry split");
   typedef float __attribute__((ext_vector_type(4))) v16_t;  // one 16-byte piece, whatever the dtype
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   TC* panel = reinterpret_cast<TC*>(smem_raw);                         // [KBS][RS]
@@ -745,9 +745,14 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     }
   };
 
-  // this wave's 16x16 blocks of the upper triangle: q = wave C + k in row-major order
+  // this wave's 16x16 blocks of the upper triangle: q = first + wave C + k in row-major order.  More than 256 reduced
+  // columns (up to 528 blocks: more accumulators than a CU has registers): gridDim.y workgroups share a frame range,
+  // each stages the WHOLE panel and multiplies ITS contiguous share of the block list.
   const int nb = (n_red + 15) / 16;
-  const int n_blocks = nb * (nb + 1) / 2;
+  const int n_blocks_all = nb * (nb + 1) / 2;
+  const int per_part = (n_blocks_all + (int)gridDim.y - 1) / (int)gridDim.y;
+  const int first_block = (int)blockIdx.y * per_part;
+  const int n_blocks = n_blocks_all - first_block < per_part ? n_blocks_all - first_block : per_part;  // of this workgroup
   const bool mfma_wave = wave * C < n_blocks;
   int b_i[SM_MAXBLK], b_j[SM_MAXBLK];
   bool b_real[SM_MAXBLK];
@@ -755,7 +760,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   for (int k = 0; k < SM_MAXBLK; ++k) {
     int q = wave * C + k, bi = 0, rowlen = nb;
     b_real[k] = q < n_blocks;
-    if (!b_real[k]) q = 0;
+    q = b_real[k] ? q + first_block : 0;
     while (q >= rowlen) {
       q -= rowlen;
       --rowlen;
@@ -830,7 +835,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     atomicAdd(&aggf_small_prof[8], 1ull);
   }
 #endif
-  TC* slab = slabs + (int64_t)blockIdx.x * (WT * WT);
+  TC* slab = slabs + ((int64_t)blockIdx.x * gridDim.y + blockIdx.y) * (WT * WT);
 #pragma unroll
   for (int k = 0; k < SM_MAXBLK; ++k)
     if (b_real[k]) {
@@ -843,17 +848,26 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 // workgroups per tile (those took 0.84 ms for the 512 slabs of CLN025 -- 15 % of the Gram build).  Thread =
 // (column, parity of the slab index); fixed summation order; upper triangle written and mirrored.
 template <typename T, int WT>
-__global__ __launch_bounds__(2 * WT) void gram_reduce_small_kernel(const T* __restrict__ slabs, int32_t ksplit,
-                                                                   int32_t n_red, int accumulate,
-                                                                   double* __restrict__ G) {
-  __shared__ double part[2][WT];
+__global__ __launch_bounds__(2 * WT > 1024 ? 1024 : 2 * WT) void gram_reduce_small_kernel(const T* __restrict__ slabs, int32_t ksplit,
+                                                                                      int32_t n_red, int accumulate,
+                                                                                      double* __restrict__ G, int32_t parts) {
+  constexpr int HALVES = 2 * WT > 1024 ? 1 : 2;
+  __shared__ double part_sum[HALVES][WT];
   const int row = blockIdx.x, col = threadIdx.x & (WT - 1), half = threadIdx.x / WT;
+  // the slab that holds entry (row, col): the workgroup whose share of the block list contains block (row / 16, col / 16)
+  int owner = 0;
+  if (parts > 1 && col >= row) {
+    const int nb = (n_red + 15) / 16, bi = row >> 4, bj = col >> 4;
+    const int n_blocks = nb * (nb + 1) / 2, per_part = (n_blocks + parts - 1) / parts;
+    owner = (bi * nb - bi * (bi - 1) / 2 + (bj - bi)) / per_part;
+  }
   double s = 0.0;
-  for (int ks = half; ks < ksplit; ks += 2) s += (double)slabs[((int64_t)ks * WT + row) * WT + col];
-  part[half][col] = s;
+  for (int ks = half; ks < ksplit; ks += HALVES) s += (double)slabs[(((int64_t)ks * parts + owner) * WT + row) * WT + col];
+  part_sum[half][col] = s;
   __syncthreads();
   if (half == 0 && row < n_red && col < n_red && col >= row) {
-    const double tot = part[0][col] + part[1][col];
+    double tot = part_sum[0][col];
+    if (HALVES == 2) tot += part_sum[HALVES - 1][col];
     double* p = G + (int64_t)row * n_red + col;
     *p = accumulate ? *p + tot : tot;
     if (col > row) {
@@ -873,6 +887,7 @@ struct GramPlan {
   int32_t n_entries;   // tiles computed per split (n_tiles, or fewer with first_tile > 0)
   bool direct;         // gram kernel reads F in place
   int ksplit;
+  int parts = 1;       // small-system kernel above 256 columns: workgroups that share a frame range and split the block list
   int64_t frames_per_split;
   int64_t chunk_frames;  // frames per pack chunk (direct: T)
   size_t slab_bytes, pack_bytes;
@@ -927,8 +942,16 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   // Two output tiles (128 < n_red <= 256): the same kernel with a 256-column panel, 4 frames per stage and 16 waves,
   // ONE workgroup per CU -- no packed copy, no padding to whole 128-tiles inside the products, constraint groups and
   // conversion on the way (the pack + tile pipeline spent 19.7 ms on 12 GB of 320-atom frames, 22.6 ms on 144 atoms).
+  // 257-512 reduced columns (round 4): a 512-column panel and two to four workgroups per frame range, each with a
+  // contiguous share of at most 144 of the up to 528 blocks (more accumulators than one CU has registers); every one
+  // stages the whole panel -- the frames are read `parts` times, which a regime of 32+ flop/B affords.
   const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
-  const bool wide = p->nt1 == 2 && first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
+  // (a layout the tile kernel reads in place -- N a multiple of 128, no groups, no conversion -- keeps it from three
+  // tiles on: 384 atoms 11.4 against 15.2 ms, 512 atoms 14.1 against 20.7)
+  // (and from ~480 columns on the pack + tile pipeline is the faster one again: 500 atoms 19.6 against 27.9 ms)
+  const bool wide = (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct && n_red <= 480)) && first_col == 0 &&
+                    raw_wide <= (size_t)5 * 64 * 16 * 16;
+  p->parts = 1;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
   if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide) && !no_small && !tiles_only && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
@@ -938,11 +961,16 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->direct = true;
     p->chunk_frames = T;
     p->pack_bytes = 0;
-    // one resident generation of workgroups (2 per CU; 1 with the 256-column panel), each looping over strided stages
-    int64_t nwg = (int64_t)(p->nt1 == 2 ? 1 : 2) * device_cu_count();
+    const int nb16 = (n_red + 15) / 16, n_blocks = nb16 * (nb16 + 1) / 2;
+    if (p->nt1 > 2) p->parts = (int)ceil_div((int64_t)n_blocks, 144);
+    // one resident generation of workgroups (2 per CU; 1 with the 256- and 512-column panels), each looping over
+    // strided stages
+    int64_t nwg = (int64_t)(p->nt1 >= 2 ? 1 : 2) * device_cu_count() / p->parts;
+    if (nwg < 1) nwg = 1;
     const int64_t n_stage_all = ceil_div(T, 8);
     if (nwg > n_stage_all) nwg = n_stage_all;
-    const size_t slab1s = (size_t)p->n_pad * p->n_pad * dtype_size(compute_dtype);
+    const int64_t edge = p->nt1 > 2 ? 4 * TILE : p->n_pad;
+    const size_t slab1s = (size_t)p->parts * edge * edge * dtype_size(compute_dtype);
     if (!query) {
       if (ws_bytes < table_bytes(*p) + slab1s + 512) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
       const int64_t max_splits = (int64_t)((ws_bytes - table_bytes(*p) - 512) / slab1s);
@@ -1082,7 +1110,8 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     int width = n_red <= 32 ? 32 : (n_red <= 64 ? 64 : TILE);
     while (width < TILE && small_raw_bytes<TIn>(N, 8 * TILE / width) / 16 - 1 > (size_t)SM_MAXVEC * threads) width *= 2;
     if (p.nt1 == 2) width = 2 * TILE;
-    const int kbs = 8 * TILE / width;
+    if (p.nt1 > 2) width = 4 * TILE;
+    const int kbs = width > 2 * TILE ? 4 : 8 * TILE / width;  // (the MFMA's K = 4 frames is the smallest stage)
     const int wt = width > TILE ? width : TILE;
     const int n_thr = width > TILE ? 1024 : threads;
     const size_t raw_bytes = small_raw_bytes<TIn>(N, kbs);
@@ -1091,7 +1120,8 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     const int nv = (int)ceil_div((int64_t)(raw_bytes / 16 - 1), n_thr);
     if (nv > SM_MAXVEC || (width > TILE && nv > 5)) return fail(AGGF_ERR_ARG, "aggf_gram: small-system kernel: frame too large");
     const int nb16 = (n_red + 15) / 16, n_blocks = nb16 * (nb16 + 1) / 2;
-    const int per_wave = (int)ceil_div((int64_t)n_blocks, width > TILE ? 16 : 8);  // blocks per active wave (template C)
+    const int per_part = (int)ceil_div((int64_t)n_blocks, p.parts);
+    const int per_wave = (int)ceil_div((int64_t)per_part, width > TILE ? 16 : 8);  // blocks per active wave (template C)
 #define AGGF_SMALL(NVC, KBC, NWC, WC, CC)                                                                            \
   do {                                                                                                               \
     if (lds > 65536) {                                                                                               \
@@ -1103,7 +1133,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
         attr_done = true;                                                                                            \
       }                                                                                                              \
     }                                                                                                                \
-    hipLaunchKernelGGL((gram_small_kernel<TIn, TC, NVC, KBC, NWC, WC, CC>), dim3((unsigned)p.ksplit),                \
+    hipLaunchKernelGGL((gram_small_kernel<TIn, TC, NVC, KBC, NWC, WC, CC>), dim3((unsigned)p.ksplit, (unsigned)p.parts), \
                        dim3(64 * NWC), lds, stream, reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms,      \
                        n_red, p.frames_per_split, (int32_t)raw_bytes, slabs);                                        \
   } while (0)
@@ -1113,10 +1143,10 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     else if (nv <= 5) AGGF_SMALL(5, KBC, 8, WC, CC);                                                                 \
     else AGGF_SMALL(8, KBC, 8, WC, CC);                                                                              \
   } while (0)
-#define AGGF_SMALL_WIDE(CC)                                                                                          \
+#define AGGF_SMALL_WIDE(WC, CC)                                                                                      \
   do {                                                                                                               \
-    if (nv <= 3) AGGF_SMALL(3, 4, 16, 2 * TILE, CC);                                                                 \
-    else AGGF_SMALL(5, 4, 16, 2 * TILE, CC);                                                                         \
+    if (nv <= 3) AGGF_SMALL(3, 4, 16, WC, CC);                                                                       \
+    else AGGF_SMALL(5, 4, 16, WC, CC);                                                                               \
   } while (0)
     if (width == 32) AGGF_SMALL_NV(32, 32, 1);                       // 1 or 3 blocks
     else if (width == 64 && per_wave <= 1) AGGF_SMALL_NV(16, 64, 1);  // 6 blocks
@@ -1125,23 +1155,31 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     else if (width == TILE && per_wave == 3) AGGF_SMALL_NV(8, TILE, 3);   // 21
     else if (width == TILE && per_wave == 4) AGGF_SMALL_NV(8, TILE, 4);   // 28
     else if (width == TILE) AGGF_SMALL_NV(8, TILE, 5);                    // 36
-    else if (per_wave <= 3) AGGF_SMALL_WIDE(3);                      // 256-column panel, 16 waves: 45 blocks
-    else if (per_wave == 4) AGGF_SMALL_WIDE(4);                      // 55
-    else if (per_wave == 5) AGGF_SMALL_WIDE(5);                      // 66, 78
-    else if (per_wave == 6) AGGF_SMALL_WIDE(6);                      // 91
-    else if (per_wave == 7) AGGF_SMALL_WIDE(7);                      // 105
-    else if (per_wave == 8) AGGF_SMALL_WIDE(8);                      // 120
-    else AGGF_SMALL_WIDE(9);                                         // 136
+    else if (width == 2 * TILE && per_wave <= 3) AGGF_SMALL_WIDE(2 * TILE, 3);   // 256-column panel, 16 waves: 45 blocks
+    else if (width == 2 * TILE && per_wave == 4) AGGF_SMALL_WIDE(2 * TILE, 4);   // 55
+    else if (width == 2 * TILE && per_wave == 5) AGGF_SMALL_WIDE(2 * TILE, 5);   // 66, 78
+    else if (width == 2 * TILE && per_wave == 6) AGGF_SMALL_WIDE(2 * TILE, 6);   // 91
+    else if (width == 2 * TILE && per_wave == 7) AGGF_SMALL_WIDE(2 * TILE, 7);   // 105
+    else if (width == 2 * TILE && per_wave == 8) AGGF_SMALL_WIDE(2 * TILE, 8);   // 120
+    else if (width == 2 * TILE) AGGF_SMALL_WIDE(2 * TILE, 9);                    // 136
+    else if (per_wave <= 5) AGGF_SMALL_WIDE(4 * TILE, 5);            // 512-column panel: 77 - 80 blocks per workgroup
+    else if (per_wave == 6) AGGF_SMALL_WIDE(4 * TILE, 6);
+    else if (per_wave == 7) AGGF_SMALL_WIDE(4 * TILE, 7);
+    else if (per_wave == 8) AGGF_SMALL_WIDE(4 * TILE, 8);
+    else AGGF_SMALL_WIDE(4 * TILE, 9);                               // <= 144
 #undef AGGF_SMALL_WIDE
 #undef AGGF_SMALL_NV
 #undef AGGF_SMALL
     AGGF_LAUNCH_OK();
-    if (width > TILE)
+    if (width == 4 * TILE)
+      hipLaunchKernelGGL((gram_reduce_small_kernel<TC, 4 * TILE>), dim3(4 * TILE), dim3(1024), 0, stream, slabs, p.ksplit,
+                         n_red, accumulate, G, p.parts);
+    else if (width > TILE)
       hipLaunchKernelGGL((gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
-                         n_red, accumulate, G);
+                         n_red, accumulate, G, 1);
     else
       hipLaunchKernelGGL((gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
-                         accumulate, G);
+                         accumulate, G, 1);
     AGGF_LAUNCH_OK();
     return AGGF_OK;
   }
