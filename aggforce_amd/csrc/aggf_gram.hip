@@ -948,8 +948,9 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
   // (a layout the tile kernel reads in place -- N a multiple of 128, no groups, no conversion -- keeps it from three
   // tiles on: 384 atoms 11.4 against 15.2 ms, 512 atoms 14.1 against 20.7)
-  // (and from ~480 columns on the pack + tile pipeline is the faster one again: 500 atoms 19.6 against 27.9 ms)
-  const bool wide = (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct && n_red <= 480)) && first_col == 0 &&
+  // (and from ~480 columns on the pack + tile pipeline is the faster one again with float64 products: 500 atoms 19.6
+  // against 27.9 ms; with float32 products the streaming kernel keeps its lead up to 512)
+  const bool wide = (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512))) && first_col == 0 &&
                     raw_wide <= (size_t)5 * 64 * 16 * 16;
   p->parts = 1;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)

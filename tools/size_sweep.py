@@ -27,21 +27,27 @@ def timed(fn, n=4):
 
 
 def main():
-    sizes = [int(a) for a in sys.argv[1:]] or [144, 192, 256, 320, 384, 512, 768, 1024, 2048]
+    args = [a for a in sys.argv[1:] if a not in ("f32", "f32f64")]
+    mode = "f32" if "f32" in sys.argv else ("f32f64" if "f32f64" in sys.argv else "f64")  # storage / product dtypes
+    sdt = torch.float64 if mode == "f64" else torch.float32
+    cdt = torch.float32 if mode == "f32" else torch.float64
+    es = 8 if mode == "f64" else 4
+    peak = 157.3e12 if mode == "f32" else 78.6e12
+    sizes = [int(a) for a in args] or [144, 192, 256, 320, 384, 512, 768, 1024, 2048]
     for N in sizes:
-        T = int(12e9 / (24 * N)) // 64 * 64
-        f = K.synth_normal(T, N, torch.float64, 11, sigma=30.0)
-        tg = timed(lambda: K.gram(f, None, None, N, torch.float64))
+        T = int(12e9 / (3 * es * N)) // 64 * 64
+        f = K.synth_normal(T, N, sdt, 11, sigma=30.0)
+        tg = timed(lambda: K.gram(f, None, None, N, cdt))
         flop = 3.0 * T * N * (N + 1)
         n_cg = max(1, N // 16)
-        m = torch.from_numpy(np.abs(np.random.default_rng(N).standard_normal((n_cg, N))) + 0.1).cuda()
+        m = torch.from_numpy(np.abs(np.random.default_rng(N).standard_normal((n_cg, N))) + 0.1).to(cdt).cuda()
         ta = timed(lambda: K.linearmap_apply(f, m))
         aflop = 2.0 * T * 3 * N * n_cg
-        gb = f.numel() * 8 / 1e9
-        print(json.dumps({"atoms": N, "frames": T, "GB": round(gb, 2),
+        gb = f.numel() * es / 1e9
+        print(json.dumps({"dtypes": mode, "atoms": N, "frames": T, "GB": round(gb, 2),
                           "gram_ms": round(tg * 1e3, 3), "gram_TFLOPs": round(flop / tg / 1e12, 1),
-                          "gram_frac_mfma": round(flop / tg / 78.6e12, 3), "gram_frac_hbm": round(gb / tg / 8000, 3),
-                          "sites": n_cg, "apply_ms": round(ta * 1e3, 3), "apply_frac_mfma": round(aflop / ta / 78.6e12, 3),
+                          "gram_frac_mfma": round(flop / tg / peak, 3), "gram_frac_hbm": round(gb / tg / 8000, 3),
+                          "sites": n_cg, "apply_ms": round(ta * 1e3, 3), "apply_frac_mfma": round(aflop / ta / peak, 3),
                           "apply_frac_hbm": round(gb / ta / 8000, 3)}), flush=True)
         del f, m
 
