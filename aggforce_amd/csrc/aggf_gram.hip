@@ -602,7 +602,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   // conditional MFMA in copies of the accumulator set behind an s_nop for the MFMA's full latency -- ~150 cycles per
   // block step and nothing overlapped (tools/small_probe.hip: MFMA phase 3500 of 10300 cycles per stage at CLN025).
   constexpr int SM_MAXBLK = C;
-  static_assert(KBS * RE % SM_THREADS == 0 && KBS >= 4 && (KBS * W == 8 * TILE || (KBS == 4 && W > 2 * TILE)), "entry split");
+  static_assert(KBS * RE % SM_THREADS == 0 && KBS >= 4 && (KBS * W == 8 * TILE || (KBS == 4 && W > 2 * TILE) || (KBS == 8 && W == 2 * TILE)), "entry split");
   typedef float __attribute__((ext_vector_type(4))) v16_t;  // one 16-byte piece, whatever the dtype
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   TC* panel = reinterpret_cast<TC*>(smem_raw);                         // [KBS][RS]
@@ -1112,7 +1112,13 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     while (width < TILE && small_raw_bytes<TIn>(N, 8 * TILE / width) / 16 - 1 > (size_t)SM_MAXVEC * threads) width *= 2;
     if (p.nt1 == 2) width = 2 * TILE;
     if (p.nt1 > 2) width = 4 * TILE;
-    const int kbs = width > 2 * TILE ? 4 : 8 * TILE / width;  // (the MFMA's K = 4 frames is the smallest stage)
+    int kbs = width > 2 * TILE ? 4 : 8 * TILE / width;  // (the MFMA's K = 4 frames is the smallest stage)
+    // 256 columns: 8 frames per stage where they fit (one workgroup per CU: nothing covers a stage's barriers and group
+    // sums but its own MFMAs, and 4 frames are 15 MFMAs per wave)
+    // -- up to 5 blocks per wave (~200 columns): beyond, the longer MFMA phase spills (224 atoms 6.3 -> 9.2 ms)
+    if (width == 2 * TILE && small_raw_bytes<TIn>(N, 8) / 16 - 1 <= (size_t)5 * 1024 &&
+        ((n_red + 15) / 16) * ((n_red + 15) / 16 + 1) / 2 <= 5 * 16)
+      kbs = 8;
     const int wt = width > TILE ? width : TILE;
     const int n_thr = width > TILE ? 1024 : threads;
     const size_t raw_bytes = small_raw_bytes<TIn>(N, kbs);
@@ -1146,7 +1152,9 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   } while (0)
 #define AGGF_SMALL_WIDE(WC, CC)                                                                                      \
   do {                                                                                                               \
-    if (nv <= 3) AGGF_SMALL(3, 4, 16, WC, CC);                                                                       \
+    if (kbs == 8 && nv <= 3) AGGF_SMALL(3, 8, 16, 2 * TILE, CC);                                                     \
+    else if (kbs == 8) AGGF_SMALL(5, 8, 16, 2 * TILE, CC);                                                           \
+    else if (nv <= 3) AGGF_SMALL(3, 4, 16, WC, CC);                                                                  \
     else AGGF_SMALL(5, 4, 16, WC, CC);                                                                               \
   } while (0)
     if (width == 32) AGGF_SMALL_NV(32, 32, 1);                       // 1 or 3 blocks
