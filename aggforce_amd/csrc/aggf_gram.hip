@@ -1152,10 +1152,13 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   } while (0)
 #define AGGF_SMALL_WIDE(WC, CC)                                                                                      \
   do {                                                                                                               \
-    if (kbs == 8 && nv <= 3) AGGF_SMALL(3, 8, 16, 2 * TILE, CC);                                                     \
-    else if (kbs == 8) AGGF_SMALL(5, 8, 16, 2 * TILE, CC);                                                           \
-    else if (nv <= 3) AGGF_SMALL(3, 4, 16, WC, CC);                                                                  \
+    if (nv <= 3) AGGF_SMALL(3, 4, 16, WC, CC);                                                                       \
     else AGGF_SMALL(5, 4, 16, WC, CC);                                                                               \
+  } while (0)
+#define AGGF_SMALL_WIDE8(CC)                                                                                         \
+  do {                                                                                                               \
+    if (nv <= 3) AGGF_SMALL(3, 8, 16, 2 * TILE, CC);                                                                 \
+    else AGGF_SMALL(5, 8, 16, 2 * TILE, CC);                                                                         \
   } while (0)
     if (width == 32) AGGF_SMALL_NV(32, 32, 1);                       // 1 or 3 blocks
     else if (width == 64 && per_wave <= 1) AGGF_SMALL_NV(16, 64, 1);  // 6 blocks
@@ -1164,7 +1167,10 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     else if (width == TILE && per_wave == 3) AGGF_SMALL_NV(8, TILE, 3);   // 21
     else if (width == TILE && per_wave == 4) AGGF_SMALL_NV(8, TILE, 4);   // 28
     else if (width == TILE) AGGF_SMALL_NV(8, TILE, 5);                    // 36
-    else if (width == 2 * TILE && per_wave <= 3) AGGF_SMALL_WIDE(2 * TILE, 3);   // 256-column panel, 16 waves: 45 blocks
+    else if (width == 2 * TILE && kbs == 8 && per_wave <= 3) AGGF_SMALL_WIDE8(3);  // 256-column panel, 16 waves, 8 frames
+    else if (width == 2 * TILE && kbs == 8 && per_wave == 4) AGGF_SMALL_WIDE8(4);
+    else if (width == 2 * TILE && kbs == 8) AGGF_SMALL_WIDE8(5);
+    else if (width == 2 * TILE && per_wave <= 3) AGGF_SMALL_WIDE(2 * TILE, 3);   // 4 frames (the frames of 8 do not fit): 45 blocks
     else if (width == 2 * TILE && per_wave == 4) AGGF_SMALL_WIDE(2 * TILE, 4);   // 55
     else if (width == 2 * TILE && per_wave == 5) AGGF_SMALL_WIDE(2 * TILE, 5);   // 66, 78
     else if (width == 2 * TILE && per_wave == 6) AGGF_SMALL_WIDE(2 * TILE, 6);   // 91
@@ -1177,6 +1183,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     else if (per_wave == 8) AGGF_SMALL_WIDE(4 * TILE, 8);
     else AGGF_SMALL_WIDE(4 * TILE, 9);                               // <= 144
 #undef AGGF_SMALL_WIDE
+#undef AGGF_SMALL_WIDE8
 #undef AGGF_SMALL_NV
 #undef AGGF_SMALL
     AGGF_LAUNCH_OK();
