@@ -912,6 +912,12 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);
   }
+  // 17-48 sites: a 32- or 48-site tile -- the 64-site tile multiplies its empty 16-site column tiles all the same
+  // (20 sites on 320 atoms of float32 frames, float64 map: 6.5 ms for 12 GB, 0.75 of the fp64 MFMA peak in EXECUTED flops)
+  if (n_cg <= 32)
+    return apply_launch<TIn, TC, 256, 32>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
+  if (n_cg <= 48)
+    return apply_launch<TIn, TC, 256, 48>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   return apply_launch<TIn, TC, 256, 64>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                         ws_bytes, stream);
 }
