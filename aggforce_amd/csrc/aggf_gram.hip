@@ -1225,7 +1225,10 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   if (min_env && atoll(min_env) >= 8) PACK_MIN_FRAMES = atoll(min_env);
   const size_t row_elems = (size_t)p.n_pad * 3;
   int64_t cf = p.chunk_frames;
-  bool overlap = !(pack_env && pack_env[0] == 's') && T >= 2 * PACK_MIN_FRAMES && p.chunk_frames / 2 >= PACK_MIN_FRAMES;
+  // (up to 1024 columns the tile kernel is short against the pack pass and the throttled pack beside it loses: 700 atoms
+  // 31.0 against 27.1 ms, 1000 atoms 32.9 against 31.4 -- serial there; the min-frames hook still reaches the pipeline)
+  bool overlap = !(pack_env && pack_env[0] == 's') && T >= 2 * PACK_MIN_FRAMES && p.chunk_frames / 2 >= PACK_MIN_FRAMES &&
+                 (p.n_pad > 1024 || min_env);
   const bool same_stream = pack_env && pack_env[0] == 'c';  // (measurement: the overlapped form's chunks, one stream)
   PackPipe* pipe = overlap ? pack_pipe() : nullptr;
   if (overlap && !pipe) overlap = false;  // no side stream: the serial form
