@@ -244,7 +244,7 @@ int aggf_condnormal_augment(const void* coords, const void* forces, int64_t T, i
  *                          the same Philox stream as aggf_condnormal_augment (out_dtype: aug_dtype or AGGF_F64);
  *   aggf_gram_pair         Gx ((N + N2)^2 float64) of [F | F2] read where they lie: same dtype for both arrays
  *                          and the products, N % 128 == 0, N2 % 128 == 0, 16-byte aligned (otherwise
- *                          AGGF_ERR_ARG: concatenate and call aggf_gram); workspace as aggf_gram's for N + N2 sites;
+ *                          AGGF_ERR_ARG: concatenate and call aggf_gram); workspace: aggf_gram_pair_workspace_bytes;
  *   aggf_augmented_gram    G_aug = Tm' Gx Tm (exactly symmetric); C as compressed columns: for atom a the entries
  *                          c_idx[k], c_val[k], k in [c_ptr[a], c_ptr[a+1]);
  *   aggf_sym_group_reduce  C' G C for the 0/1 constraint matrix of qplinear.py:147-164 given as CSR groups
