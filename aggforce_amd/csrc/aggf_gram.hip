@@ -887,6 +887,7 @@ struct GramPlan {
   int32_t n_entries;   // tiles computed per split (n_tiles, or fewer with first_tile > 0)
   bool direct;         // gram kernel reads F in place
   int ksplit;
+  bool wide256 = false;  // small-system kernel: 113-128 columns on the 256-column panel (16 waves, 3 blocks per wave)
   int parts = 1;       // small-system kernel above 256 columns: workgroups that share a frame range and split the block list
   int64_t frames_per_split;
   int64_t chunk_frames;  // frames per pack chunk (direct: T)
@@ -953,8 +954,13 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   const bool wide = (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512))) && first_col == 0 &&
                     raw_wide <= (size_t)5 * 64 * 16 * 16;
   p->parts = 1;
+  // 113-128 columns are 36 blocks = 5 per wave of the 8-wave form, which spills (128 unconstrained atoms: 5.7 ms for
+  // 12 GB): the 16-wave 256-column form takes them with 3 blocks per wave (4.4 ms)
+  // (without constraint groups: the table-driven group sums walk all 768 panel columns -- 117 columns of 175 atoms
+  // in pairs 6.8 ms there against 6.5)
+  p->wide256 = p->nt1 == 1 && n_red > 112 && !has_groups && first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
-  if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide) && !no_small && !tiles_only && N < 21000 && aligned) {
+  if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide || p->wide256) && !no_small && !tiles_only && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
     // triangle blocks only); one slab per workgroup, 2 workgroups per CU over the frame axis
     p->staging = STAGE_SMALL;
@@ -966,11 +972,11 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     if (p->nt1 > 2) p->parts = (int)ceil_div((int64_t)n_blocks, 144);
     // one resident generation of workgroups (2 per CU; 1 with the 256- and 512-column panels), each looping over
     // strided stages
-    int64_t nwg = (int64_t)(p->nt1 >= 2 ? 1 : 2) * device_cu_count() / p->parts;
+    int64_t nwg = (int64_t)(p->nt1 >= 2 || p->wide256 ? 1 : 2) * device_cu_count() / p->parts;
     if (nwg < 1) nwg = 1;
     const int64_t n_stage_all = ceil_div(T, 8);
     if (nwg > n_stage_all) nwg = n_stage_all;
-    const int64_t edge = p->nt1 > 2 ? 4 * TILE : p->n_pad;
+    const int64_t edge = p->nt1 > 2 ? 4 * TILE : (p->wide256 ? 2 * TILE : p->n_pad);
     const size_t slab1s = (size_t)p->parts * edge * edge * dtype_size(compute_dtype);
     if (!query) {
       if (ws_bytes < table_bytes(*p) + slab1s + 512) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
@@ -1110,7 +1116,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     // class when the stage's raw frames would not fit the registers that carry them (SM_MAXVEC 16-byte pieces per thread)
     int width = n_red <= 32 ? 32 : (n_red <= 64 ? 64 : TILE);
     while (width < TILE && small_raw_bytes<TIn>(N, 8 * TILE / width) / 16 - 1 > (size_t)SM_MAXVEC * threads) width *= 2;
-    if (p.nt1 == 2) width = 2 * TILE;
+    if (p.nt1 == 2 || p.wide256) width = 2 * TILE;
     if (p.nt1 > 2) width = 4 * TILE;
     int kbs = width > 2 * TILE ? 4 : 8 * TILE / width;  // (the MFMA's K = 4 frames is the smallest stage)
     // 256 columns: 8 frames per stage where they fit (one workgroup per CU: nothing covers a stage's barriers and group
