@@ -42,6 +42,9 @@ def force_smoothness(array, comm=None) -> float:
     import torch
 
     x = K.as_device(array)
+    if world_size(comm) == 1:  # one device-to-host scalar, no staging of the count on the device
+        n = x.numel()
+        return float(K.sumsq(x).item()) / n if n else float("nan")
     acc = torch.cat([K.sumsq(x), torch.tensor([float(x.numel())], dtype=torch.float64, device=x.device)])
     all_reduce_sum_(acc, comm)
     s, n = acc.tolist()
@@ -52,6 +55,8 @@ def _mean_square(sumsq, count: int, comm=None) -> float:
     """mean of squares from a device sum and an element count (summed over the ranks with ``comm``)."""
     import torch
 
+    if world_size(comm) == 1:
+        return float(sumsq.item()) / count if count else float("nan")
     acc = torch.cat([sumsq.reshape(1).to(torch.float64),
                      torch.tensor([float(count)], dtype=torch.float64, device=sumsq.device)])
     all_reduce_sum_(acc, comm)
