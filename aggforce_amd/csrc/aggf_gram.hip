@@ -937,28 +937,30 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->direct = !has_groups && (N % TILE == 0) && in_dtype == compute_dtype && aligned;
   p->staging = STAGE_DMA8;
   static const char* no_small = getenv("AGGF_GRAM_NO_SMALL");  // tests: force the tiled pipeline on small systems
-  // Small systems: register-staged, 8 frames x 8 waves (6.5 ms at CLN025 x 4e6 frames; an LDS-DMA ring of 4 frames per
-  // stage took 6.8-7.0 ms, 4 x 4 waves more: profiles/r04_pruned_variants.patch).
+  // The streaming kernel (gram_small_kernel: the frames pass through LDS once, group sums / conversion / padding on the
+  // way, only the 16 x 16 blocks of the upper triangle are multiplied) takes
+  //   * n_red <= 128: 8 waves, two workgroups per CU, panel width 32 / 64 / 128 (6.5 ms at CLN025 x 4e6 frames when it
+  //     was written; an LDS-DMA ring of 4 frames per stage took 6.8-7.0 ms, 4 x 4 waves more:
+  //     profiles/r04_pruned_variants.patch);
+  //   * 128 < n_red <= 256 (round 4): a 256-column panel, 16 waves, ONE workgroup per CU -- no packed copy, no padding
+  //     to whole 128-tiles inside the products (the pack + tile pipeline spent 22.6 ms on 12 GB of 144-atom frames,
+  //     17.7 ms on 192 atoms; now 4.7 / 5.4).  113-128 columns WITHOUT constraint groups too: their 36 blocks are 5 per
+  //     wave of the 8-wave form, which spills (128 atoms 5.7 -> 4.4 ms); with groups the table-driven sums over all 768
+  //     panel columns cost more than that (117 columns of 175 atoms in pairs: 6.8 against 6.5 ms);
+  //   * 256 < n_red <= 480 (512 with float32 products) for layouts the tile kernel cannot read in place: a 512-column
+  //     panel and two to four workgroups per frame range, each with a contiguous share of at most 144 of the up to
+  //     528 blocks (more accumulators than one CU has registers); every one stages the whole panel -- the frames are
+  //     read `parts` times, which 32+ flop/B affords (260 atoms 37.9 -> 9.1 ms, 400 atoms 29.5 -> 17.6).  A layout the
+  //     tile kernel reads in place (N a multiple of 128, no groups, no conversion) keeps it from three tiles on (384
+  //     atoms 11.4 against 15.2 ms), and from ~480 columns the pack + tile pipeline wins again with float64 products
+  //     (500 atoms 19.6 against 27.9 ms).
   const size_t raw_small = (size_t)round_up((int64_t)8 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
-  // Two output tiles (128 < n_red <= 256): the same kernel with a 256-column panel, 4 frames per stage and 16 waves,
-  // ONE workgroup per CU -- no packed copy, no padding to whole 128-tiles inside the products, constraint groups and
-  // conversion on the way (the pack + tile pipeline spent 19.7 ms on 12 GB of 320-atom frames, 22.6 ms on 144 atoms).
-  // 257-512 reduced columns (round 4): a 512-column panel and two to four workgroups per frame range, each with a
-  // contiguous share of at most 144 of the up to 528 blocks (more accumulators than one CU has registers); every one
-  // stages the whole panel -- the frames are read `parts` times, which a regime of 32+ flop/B affords.
-  const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
-  // (a layout the tile kernel reads in place -- N a multiple of 128, no groups, no conversion -- keeps it from three
-  // tiles on: 384 atoms 11.4 against 15.2 ms, 512 atoms 14.1 against 20.7)
-  // (and from ~480 columns on the pack + tile pipeline is the faster one again with float64 products: 500 atoms 19.6
-  // against 27.9 ms; with float32 products the streaming kernel keeps its lead up to 512)
-  const bool wide = (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512))) && first_col == 0 &&
-                    raw_wide <= (size_t)5 * 64 * 16 * 16;
+  const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);  // 4 frames, 16 waves
+  const bool wide_fits = first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
+  const bool wide = wide_fits && (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct &&
+                                                   n_red <= (compute_dtype == AGGF_F64 ? 480 : 512)));
   p->parts = 1;
-  // 113-128 columns are 36 blocks = 5 per wave of the 8-wave form, which spills (128 unconstrained atoms: 5.7 ms for
-  // 12 GB): the 16-wave 256-column form takes them with 3 blocks per wave (4.4 ms)
-  // (without constraint groups: the table-driven group sums walk all 768 panel columns -- 117 columns of 175 atoms
-  // in pairs 6.8 ms there against 6.5)
-  p->wide256 = p->nt1 == 1 && n_red > 112 && !has_groups && first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
+  p->wide256 = wide_fits && p->nt1 == 1 && n_red > 112 && !has_groups;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
   if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide || p->wide256) && !no_small && !tiles_only && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
