@@ -560,19 +560,18 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
 }
 
 // ---------------------------------------------------------------------------
-// Small systems: n_red <= 128 (one output tile), e.g. CLN025 (175 atoms, 97 reduced variables).
-// There the Gram build is HBM-bound (n_red (n_red+1) / (N s) = 6.8 flop/B at CLN025 against a machine
-// balance of ~10), so the kernel is organised around ONE pass over the forces, read the way they lie
-// in HBM: the 8 frames of a stage are one contiguous run of 8 x 3N elements, fetched with 16-byte
-// loads into registers while the MFMAs of the previous stage run (2 workgroups per CU x 8 frames:
-// ~64 KB per CU in flight), parked in LDS as they are, and only there turned into the panel the
-// MFMAs read -- constraint-group column sums (`@ con_mat`), dtype conversion and zero padding, all
-// LDS -> LDS.  No packed copy of the trajectory exists (the pack + tile pipeline above reads F,
-// writes a padded copy and reads that again: 3.4x the bytes at CLN025), and only the 16x16 blocks
-// of the upper triangle are multiplied (8 waves, <= 5 blocks each, dealt round-robin).
-// Two shapes: 8 frames per stage x 8 waves (default: 60 KB of LDS at CLN025, two workgroups per CU, 67 KB in
-// flight per CU) and 4 frames x 4 waves (AGGF_GRAM_SMALL=4: three smaller workgroups per CU; measured slower,
-// 10.2 against 7.5 ms at CLN025 x 4e6 frames before the group sums lost their loops).
+// Small and mid-size systems: n_red <= 512, e.g. CLN025 (175 atoms, 97 reduced variables).
+// At CLN025 the Gram build sits on the ridge (n_red (n_red+1) / (N s) = 6.8 flop/B against a machine balance of
+// ~12), below it the HBM is the bound, above it the MFMA pipe -- in all three the kernel is organised around ONE pass
+// over the forces, read the way they lie in HBM: the frames of a stage are one contiguous run of KBS x 3N elements,
+// fetched with 16-byte loads into registers while the MFMAs of the previous stage run, parked in LDS as they are, and
+// only there turned into the panel the MFMAs read -- constraint-group column sums (`@ con_mat`), dtype conversion and
+// zero padding, all LDS -> LDS.  No packed copy of the trajectory exists (the pack + tile pipeline reads F, writes a
+// padded copy and reads that again: 3.4x the bytes at CLN025), and only the 16x16 blocks of the upper triangle are
+// multiplied, dealt to the waves in equal contiguous shares (template C).  Shapes (template W, KBS, NWV; make_plan
+// picks): panel width 32 / 64 / 128 with 32 / 16 / 8 frames per stage, 8 waves, two workgroups per CU; 256 columns
+// with 8 or 4 frames, 16 waves, one workgroup per CU; 512 columns with 4 frames, 16 waves and gridDim.y workgroups
+// sharing a frame range.
 constexpr int SM_MAXVEC = 8;        // 16-byte loads per thread and stage (template NV = 3, 5 or 8)
 constexpr int SM_FAST_MEMBERS = 4;  // group members summed without a loop (larger groups: generic tail loop)
 
