@@ -200,12 +200,16 @@ constexpr int dma_pieces_upto(int groups, int ppw, int g) {
 // TWO: the operand is the column-concatenation [X | X2] of two arrays that lie apart in HBM (panels 0..np1-1 from X,
 // row stride ld; the rest from X2, row stride ld2) -- the noised maps' [forces | generated-site forces], which round 2
 // materialised as one (T, N + n_cg, 3) array twice per step (aggf_gram_pair).
+// EDGE: X is read where it lies although its rows are NOT padded to whole panels (ld = row_elems = 3 N with
+// N % 128 != 0, rows still 16-byte multiples): lanes whose chunk lies past the end of a row issue no DMA -- their
+// LDS slots are zeroed once and stay zero -- and a piece without an active lane does not count in vmcnt, so the
+// counted waits take their numbers from wave-uniform tallies instead of the template's constants.
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, int ES = 0,
-          bool ES_DMA_AFTER = false, bool TWO = false>
+          bool ES_DMA_AFTER = false, bool TWO = false, bool EDGE = false>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs,
-    const T* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0) {
+    const T* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0, int32_t row_elems = 0) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   constexpr int KB = GramCfg<T>::KB;
@@ -258,6 +262,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   // reads (for the ragged last stage) and the LDS element offset of the piece
   int64_t g_off[PPW];
   int l_off[PPW], p_row[PPW];
+  bool c_ok[PPW];
   const T* g_base[TWO ? PPW : 1];
   int64_t g_ld[TWO ? PPW : 1];
   (void)g_base;
@@ -291,6 +296,24 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
       g_off[q] = (int64_t)r * ld + col + elem;
     }
     l_off[q] = panel * PANEL_ELEMS + unit * DmaCfg<T>::UNIT_STRIDE + cp * PE;
+    c_ok[q] = !EDGE || (panel ? tj : ti) * ROW_ELEMS + elem + (int)(16 / sizeof(T)) <= row_elems;
+  }
+  // EDGE: pieces with an active lane (wave-uniform; the others never count in vmcnt), all and those in front of the
+  // early barrier
+  int n_act = PPW, n_act_early = 0;
+  if constexpr (EDGE) {
+    n_act = 0;
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      const int a = __any(c_ok[q]) ? 1 : 0;
+      n_act += a;
+      constexpr int GROUPS_ = 3 * KB / 4;
+      if (ES > 0 && SPREAD_DMA && dma_piece_group(GROUPS_, PPW, q) <= GROUPS_ - ES - (ES_DMA_AFTER ? 1 : 0)) n_act_early += a;
+    }
+    n_act = __builtin_amdgcn_readfirstlane(n_act);
+    n_act_early = __builtin_amdgcn_readfirstlane(n_act_early);
+    for (int e = tid; e < NBUF * BUF_ELEMS; e += NTHREADS) smem[e] = 0;
+    __syncthreads();
   }
 
   // rows past the end of this split's frame range must read as zeros (last stage only)
@@ -321,7 +344,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     // ABL 3 (ablation): every stage re-reads the first rows of the split -> all DMAs hit the L2
     // ABL 4: cycle over 8 stages -> DMAs miss the L1 but hit the L2
     const int64_t t0 = t_begin + (ABL == 3 ? 0 : ABL == 4 ? (int64_t)(stage_of(s) & 7) * KB : (int64_t)stage_of(s) * KB);
-    const bool row_ok = t0 + p_row[q] < t_end;
+    const bool row_ok = t0 + p_row[q] < t_end && c_ok[q];
     if (row_ok) {
       const T* src = TWO ? g_base[TWO ? q : 0] + t0 * g_ld[TWO ? q : 0] + g_off[q] : X + t0 * ld + g_off[q];
       __builtin_amdgcn_global_load_lds(
@@ -348,7 +371,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
 
   if (n_it > 0) issue_stage(0);
   if (AHEAD > 1 && n_it > 1) issue_stage(1);
-  if (AHEAD > 1 && n_it > 1 && ragged_seq != 1) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+  if (AHEAD > 1 && n_it > 1 && ragged_seq != 1) {
+    if constexpr (EDGE) wait_vmcnt_dyn<8>(n_act); else wait_vmcnt<PPW>();
+  } else {
+    wait_vmcnt<0>();
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   __builtin_amdgcn_s_barrier();
   asm volatile("" ::: "memory");
@@ -418,7 +445,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           // (Pieces of stage it+2 that go with later groups are not issued yet: the counted wait allows the rest.)
           constexpr int ISSUED = dma_pieces_upto(GROUPS, PPW, GROUPS - ESG - (DMA_AFTER ? 1 : 0));
           static_assert(ISSUED >= 0 && ISSUED <= PPW, "pieces issued by the barrier group");
-          if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<ISSUED>(); else wait_vmcnt<0>();
+          if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) {
+            if constexpr (EDGE) wait_vmcnt_dyn<8>(n_act_early); else wait_vmcnt<ISSUED>();
+          } else {
+            wait_vmcnt<0>();
+          }
           asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
           __builtin_amdgcn_s_barrier();
           asm volatile("" ::: "memory");
@@ -440,7 +471,11 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     if (ABL != 2 && !EARLY_SYNC) {
       // (the ragged stage of the last split issues fewer DMAs: a counted wait would let pieces
       // of stage it+1 slip through)
-      if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) wait_vmcnt<PPW>(); else wait_vmcnt<0>();
+      if (AHEAD > 1 && it + 2 < n_it && it + 2 != ragged_seq) {
+        if constexpr (EDGE) wait_vmcnt_dyn<8>(n_act); else wait_vmcnt<PPW>();
+      } else {
+        wait_vmcnt<0>();
+      }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
       asm volatile("" ::: "memory");
@@ -886,6 +921,7 @@ struct GramPlan {
   int32_t n_entries;   // tiles computed per split (n_tiles, or fewer with first_tile > 0)
   bool direct;         // gram kernel reads F in place
   int ksplit;
+  bool edge = false;     // tile kernel reads rows that are not padded to whole panels (N % 128 != 0, in place)
   bool wide256 = false;  // small-system kernel: 113-128 columns on the 256-column panel (16 waves, 3 blocks per wave)
   int parts = 1;       // small-system kernel above 256 columns: workgroups that share a frame range and split the block list
   int64_t frames_per_split;
@@ -933,7 +969,11 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->n_pad = (int32_t)round_up(n_red, TILE);
   p->nt1 = p->n_pad / TILE;
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
-  p->direct = !has_groups && (N % TILE == 0) && in_dtype == compute_dtype && aligned;
+  // in place: no groups, no conversion, 16-byte aligned rows of 16-byte multiples; N % 128 != 0 takes the EDGE form of
+  // the tile kernel (aggf_gram_pair's two-array form needs whole panels)
+  p->edge = N % TILE != 0;
+  p->direct = !has_groups && in_dtype == compute_dtype && aligned &&
+              (!p->edge || (!tiles_only && ((int64_t)3 * N * (int64_t)dtype_size(in_dtype)) % 16 == 0));
   p->staging = STAGE_DMA8;
   static const char* no_small = getenv("AGGF_GRAM_NO_SMALL");  // tests: force the tiled pipeline on small systems
   // The streaming kernel (gram_small_kernel: the frames pass through LDS once, group sums / conversion / padding on the
@@ -956,8 +996,10 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   const size_t raw_small = (size_t)round_up((int64_t)8 * 3 * N * (int64_t)dtype_size(in_dtype), 16);
   const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);  // 4 frames, 16 waves
   const bool wide_fits = first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
-  const bool wide = wide_fits && (p->nt1 == 2 || ((p->nt1 == 3 || p->nt1 == 4) && !p->direct &&
-                                                   n_red <= (compute_dtype == AGGF_F64 ? 480 : 512)));
+  // (three tiles: the streaming kernel also beats the EDGE form of the tile kernel up to ~320 columns -- 260 atoms 9.1
+  // against ~17 ms, 360 atoms 18.6 against 12.5; four tiles: the tile kernel in either in-place form is the faster one)
+  const bool wide = wide_fits && (p->nt1 == 2 || (p->nt1 == 3 && (!p->direct || (p->edge && n_red <= 320))) ||
+                                  (p->nt1 == 4 && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512)));
   p->parts = 1;
   p->wide256 = wide_fits && p->nt1 == 1 && n_red > 112 && !has_groups;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
@@ -1046,7 +1088,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   return AGGF_OK;
 }
 
-template <typename T>
+template <typename T, bool EDGE = false>
 static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs,
                        int32_t* tile_table, double* G, int32_t n_red, int accumulate, hipStream_t stream) {
   constexpr int KB = GramCfg<T>::KB;
@@ -1065,15 +1107,16 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   static thread_local PerDeviceOnce attr_once;
   bool& attr_done = *attr_once.flag();
   if (!attr_done) {
-    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true>,
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     attr_done = true;
   }
   hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, p.first_tile);
   AGGF_LAUNCH_OK();
   const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
-  hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true>), dim3((unsigned)round_up(nblk, 512)),
-                     dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs);
+  hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE>), dim3((unsigned)round_up(nblk, 512)),
+                     dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs,
+                     (const T*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0));
   AGGF_LAUNCH_OK();
   hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                      slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
@@ -1208,6 +1251,9 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   }
   if (p.direct) {
     // only reachable with TIn == TC
+    if (p.edge)
+      return launch_gram<TC, true>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G, n_red,
+                                   accumulate, stream);
     return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,
                            n_red, accumulate, stream);
   }
