@@ -997,9 +997,12 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   const size_t raw_wide = (size_t)round_up((int64_t)4 * 3 * N * (int64_t)dtype_size(in_dtype), 16);  // 4 frames, 16 waves
   const bool wide_fits = first_col == 0 && raw_wide <= (size_t)5 * 64 * 16 * 16;
   // (three tiles: the streaming kernel also beats the EDGE form of the tile kernel up to ~320 columns -- 260 atoms 9.1
-  // against ~17 ms, 360 atoms 18.6 against 12.5; four tiles: the tile kernel in either in-place form is the faster one)
+  // against ~17 ms, 360 atoms 18.6 against 12.5; four tiles: the EDGE form wins
+  // from ~400 columns with float64 products -- 448 atoms 16.5 against 24.5 ms -- and from ~480 with float32 -- 400 atoms
+  // 19.6 against 13.2)
   const bool wide = wide_fits && (p->nt1 == 2 || (p->nt1 == 3 && (!p->direct || (p->edge && n_red <= 320))) ||
-                                  (p->nt1 == 4 && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512)));
+                                  (p->nt1 == 4 && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512)) ||
+                                  (p->nt1 == 4 && p->direct && p->edge && n_red <= (compute_dtype == AGGF_F64 ? 400 : 480)));
   p->parts = 1;
   p->wide256 = wide_fits && p->nt1 == 1 && n_red > 112 && !has_groups;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
