@@ -19,8 +19,8 @@ def rel(a, b):
     return float(np.max(np.abs(a - b)) / max(1e-300, np.max(np.abs(b))))
 
 
-def random_case(rng):
-    N = int(rng.integers(2, 400))
+def random_case(rng, n_max=400):
+    N = int(rng.integers(2, n_max))
     n_cg = int(rng.integers(1, min(N, 70) + 1))
     dt = rng.choice([np.float32, np.float64])
     # frames: enough for a well-posed problem most of the time, sometimes few (then l2 > 0)
@@ -62,7 +62,7 @@ def main():
     worst = {"W": 0.0, "mf": 0.0, "mc": 0.0, "res": 0.0}
     done = skipped = infeasible_ok = 0
     while done < n_cases:
-        c = random_case(rng)
+        c = random_case(rng, int(sys.argv[3]) if len(sys.argv) > 3 else 400)
         if c is None:
             continue
         if c.get("infeasible"):
