@@ -27,6 +27,8 @@ _vp, _i32, _i64, _u64, _dbl, _sz = C.c_void_p, C.c_int32, C.c_int64, C.c_uint64,
 PROTOTYPES = {
     "aggf_version": (C.c_int, []),
     "aggf_last_error": (C.c_char_p, []),
+    "aggf_coverage_dump": (_sz, [C.c_char_p, _sz]),
+    "aggf_coverage_reset": (C.c_int, []),
     "aggf_device_info": (C.c_int, [C.POINTER(_i32), C.POINTER(_sz), C.POINTER(_sz)]),
     "aggf_gram_workspace_bytes": (_sz, [_i64, _i32, _i32, C.c_int, C.c_int, C.c_int]),
     "aggf_gram": (C.c_int, [_vp, _i64, _i32, C.c_int, C.c_int, _vp, _vp, _i32, _vp, C.c_int, _vp, _sz, _vp]),
@@ -123,6 +125,21 @@ def lib() -> C.CDLL:
             "there is no CPU fallback for the force-map hot path."
         )
     return l
+
+
+def coverage(names: bool = False) -> dict:
+    """Mangled kernel name -> launches by this process since the last ``aggf_coverage_reset`` (every kernel the
+    process has ever launched is listed, with 0 if not since the reset).  ``names=True``: -> (demangled name, launches),
+    the demangled name being the string rocprofv3 prints for the kernel."""
+    l = load()
+    need = l.aggf_coverage_dump(None, 0)
+    buf = C.create_string_buffer(need + 1)
+    l.aggf_coverage_dump(buf, need + 1)
+    out = {}
+    for line in buf.value.decode().splitlines():
+        mangled, pretty, cnt = line.split("\t")
+        out[mangled] = (pretty, int(cnt)) if names else int(cnt)
+    return out
 
 
 def check(rc: int, what: str = "") -> None:

@@ -564,14 +564,14 @@ static int apply_small_launch(const void* P, int64_t T, int32_t N, const void* M
     }
   }
   if (rep)
-    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, true, KB, NBLK>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
+    AGGF_LAUNCH((apply_small_kernel<TIn, TC, true, KB, NBLK>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
                        (const TIn*)P, T, N, (const TC*)Mx, n_cg, (TC)nan_fill, raw_bytes, n_pad, (TC*)out, partials, nan_seen);
   else
-    hipLaunchKernelGGL((apply_small_kernel<TIn, TC, false, KB, NBLK>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
+    AGGF_LAUNCH((apply_small_kernel<TIn, TC, false, KB, NBLK>), dim3((unsigned)nwg), dim3(AS_THREADS), lds, stream,
                        (const TIn*)P, T, N, (const TC*)Mx, n_cg, (TC)0, raw_bytes, n_pad, (TC*)out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nwg, sumsq);
+    AGGF_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nwg, sumsq);
     AGGF_LAUNCH_OK();
   }
   return AGGF_OK;
@@ -610,16 +610,16 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
     }
   }
   if (nan_mode == AGGF_NAN_REPLACE)
-    hipLaunchKernelGGL((apply_kernel<TIn, TC, true, THREADS, TCB, WFR>), dim3((unsigned)nblocks), dim3(THREADS), lds,
+    AGGF_LAUNCH((apply_kernel<TIn, TC, true, THREADS, TCB, WFR>), dim3((unsigned)nblocks), dim3(THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)nan_fill, p_vec_ok,
                        m_vec_ok, (TC*)out, partials, nan_seen);
   else
-    hipLaunchKernelGGL((apply_kernel<TIn, TC, false, THREADS, TCB, WFR>), dim3((unsigned)nblocks), dim3(THREADS), lds,
+    AGGF_LAUNCH((apply_kernel<TIn, TC, false, THREADS, TCB, WFR>), dim3((unsigned)nblocks), dim3(THREADS), lds,
                        stream, (const TIn*)P, T, N, (const TC*)Mx, n_cg, ncb, (TC)0, p_vec_ok,
                        m_vec_ok, (TC*)out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, sumsq);
+    AGGF_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nblocks, sumsq);
     AGGF_LAUNCH_OK();
   }
   return AGGF_OK;
@@ -866,11 +866,11 @@ static int apply_dma_launch(const double* P, int64_t T, int32_t N, const double*
                                     (int)lds));
     done = true;
   }
-  hipLaunchKernelGGL((apply_dma_kernel<MODE, TF, NBUF>), dim3((unsigned)nblocks), dim3(TF * 16), lds, stream, P, T, N, Mx,
+  AGGF_LAUNCH((apply_dma_kernel<MODE, TF, NBUF>), dim3((unsigned)nblocks), dim3(TF * 16), lds, stream, P, T, N, Mx,
                      n_cg, ncb, nfb, out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
-    hipLaunchKernelGGL(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nfb * ncb, sumsq);
+    AGGF_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nfb * ncb, sumsq);
     AGGF_LAUNCH_OK();
   }
   return AGGF_OK;
@@ -973,13 +973,13 @@ extern "C" int aggf_slice_gather(const void* P, int64_t T, int32_t N, int in_dty
   if (gx < 1) gx = 1;
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out, nan_seen, lanes);
+    AGGF_LAUNCH((slice_gather_kernel<double, double>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (double*)out, nan_seen, lanes);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out, nan_seen, lanes);
+    AGGF_LAUNCH((slice_gather_kernel<float, double>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (double*)out, nan_seen, lanes);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out, nan_seen, lanes);
+    AGGF_LAUNCH((slice_gather_kernel<float, float>), grid, block, 0, stream, (const float*)P, T, N, idx, n_cg, (float*)out, nan_seen, lanes);
   else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out, nan_seen, lanes);
+    AGGF_LAUNCH((slice_gather_kernel<double, float>), grid, block, 0, stream, (const double*)P, T, N, idx, n_cg, (float*)out, nan_seen, lanes);
   else
     return fail(AGGF_ERR_ARG, "aggf_slice_gather: unsupported dtype combination");
   AGGF_LAUNCH_OK();

@@ -188,7 +188,7 @@ static int augment_typed(const void* coords, const void* forces, int64_t T, int3
   if (lds > 64000) return fail(AGGF_ERR_ARG, "aggf_condnormal_augment: n_cg too large");
   const int64_t nblocks = ceil_div(T, fb);
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "augment grid too large");
-  hipLaunchKernelGGL((augment_kernel<TIn, TA, TOut>), dim3((unsigned)nblocks), dim3(256), lds, stream,
+  AGGF_LAUNCH((augment_kernel<TIn, TA, TOut>), dim3((unsigned)nblocks), dim3(256), lds, stream,
                      (const TIn*)coords, (const TIn*)forces, T, N, mt_ptr, mt_idx, (const TA*)mt_val, n_cg,
                      (const TA*)mean, (const TA*)noise, seed, frame_offset, (TA)var, (TA)kbt, fb,
                      (TOut*)out_coords, (TOut*)out_forces);
@@ -329,11 +329,11 @@ extern "C" int aggf_condnormal_sites(const void* mean, const void* noise, uint64
   if (g > 16384) g = 16384;
   const dim3 grid((unsigned)g), block(256);
   if (aug_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((noise_sites_kernel<float, float>), grid, block, 0, stream, (const float*)mean, (const float*)noise, seed, frame_offset, T, n_cg, (float)var, (float)kbt, (float*)out_y, (float*)out_f);
+    AGGF_LAUNCH((noise_sites_kernel<float, float>), grid, block, 0, stream, (const float*)mean, (const float*)noise, seed, frame_offset, T, n_cg, (float)var, (float)kbt, (float*)out_y, (float*)out_f);
   else if (aug_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((noise_sites_kernel<float, double>), grid, block, 0, stream, (const float*)mean, (const float*)noise, seed, frame_offset, T, n_cg, (float)var, (float)kbt, (double*)out_y, (double*)out_f);
+    AGGF_LAUNCH((noise_sites_kernel<float, double>), grid, block, 0, stream, (const float*)mean, (const float*)noise, seed, frame_offset, T, n_cg, (float)var, (float)kbt, (double*)out_y, (double*)out_f);
   else if (aug_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((noise_sites_kernel<double, double>), grid, block, 0, stream, (const double*)mean, (const double*)noise, seed, frame_offset, T, n_cg, var, kbt, (double*)out_y, (double*)out_f);
+    AGGF_LAUNCH((noise_sites_kernel<double, double>), grid, block, 0, stream, (const double*)mean, (const double*)noise, seed, frame_offset, T, n_cg, var, kbt, (double*)out_y, (double*)out_f);
   else
     return fail(AGGF_ERR_ARG, "aggf_condnormal_sites: bad dtype (out must be the augmenter's dtype or float64)");
   AGGF_LAUNCH_OK();
@@ -355,9 +355,9 @@ extern "C" int aggf_augmented_gram(const double* Gx, int32_t N, int32_t n2, cons
   int64_t g1 = ceil_div((int64_t)N * n2, 256), g2 = ceil_div(((int64_t)N + n2) * ((int64_t)N + n2), 256);
   if (g1 > 65535) g1 = 65535;
   if (g2 > 65535) g2 = 65535;
-  hipLaunchKernelGGL(auggram_h_kernel, dim3((unsigned)g1), dim3(256), 0, stream, Gx, N, n2, c_ptr, c_idx, c_val, H);
+  AGGF_LAUNCH(auggram_h_kernel, dim3((unsigned)g1), dim3(256), 0, stream, Gx, N, n2, c_ptr, c_idx, c_val, H);
   AGGF_LAUNCH_OK();
-  hipLaunchKernelGGL(auggram_kernel, dim3((unsigned)g2), dim3(256), 0, stream, Gx, N, n2, c_ptr, c_idx, c_val, H, G_aug);
+  AGGF_LAUNCH(auggram_kernel, dim3((unsigned)g2), dim3(256), 0, stream, Gx, N, n2, c_ptr, c_idx, c_val, H, G_aug);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -370,7 +370,7 @@ extern "C" int aggf_sym_group_reduce(const double* G, int32_t n, const int32_t* 
   if (G == G_red) return fail(AGGF_ERR_ARG, "aggf_sym_group_reduce: in-place reduction is not supported");
   int64_t g = ceil_div((int64_t)n_red * n_red, 256);
   if (g > 65535) g = 65535;
-  hipLaunchKernelGGL(sym_group_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, G, n, grp_ptr, grp_atoms, n_red, G_red);
+  AGGF_LAUNCH(sym_group_reduce_kernel, dim3((unsigned)g), dim3(256), 0, stream, G, n, grp_ptr, grp_atoms, n_red, G_red);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -386,7 +386,7 @@ extern "C" int aggf_residual_over_var(const void* gen, int gen_dtype, const void
   if (g > 16384) g = 16384;
   const dim3 grid((unsigned)g), block(256);
 #define AGGF_ROV(TG, TM, TO)                                                                                         \
-  hipLaunchKernelGGL((residual_over_var_kernel<TG, TM, TO>), grid, block, 0, stream, (const TG*)gen, (const TM*)mean, \
+  AGGF_LAUNCH((residual_over_var_kernel<TG, TM, TO>), grid, block, 0, stream, (const TG*)gen, (const TM*)mean, \
                      count, (TO)var, (TO*)out_pos, (TO*)out_neg)
   if (gen_dtype == AGGF_F32 && mean_dtype == AGGF_F32 && out_dtype == AGGF_F32) AGGF_ROV(float, float, float);
   else if (gen_dtype == AGGF_F32 && mean_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_ROV(float, float, double);
@@ -410,10 +410,10 @@ extern "C" int aggf_frames_matmul(const void* X, const void* S, int64_t T, int32
   if (gx > 0x7fffffffLL || gy > 65535) return fail(AGGF_ERR_ARG, "aggf_frames_matmul: grid too large");
   const dim3 grid((unsigned)gx, (unsigned)gy), block(256);
   if (dtype == AGGF_F32)
-    hipLaunchKernelGGL((frames_matmul_kernel<float>), grid, block, 0, stream, (const float*)X, (const float*)S, T, K,
+    AGGF_LAUNCH((frames_matmul_kernel<float>), grid, block, 0, stream, (const float*)X, (const float*)S, T, K,
                        (const float*)B, J, (const float*)add, (float)alpha, (float*)out);
   else if (dtype == AGGF_F64)
-    hipLaunchKernelGGL((frames_matmul_kernel<double>), grid, block, 0, stream, (const double*)X, (const double*)S, T, K,
+    AGGF_LAUNCH((frames_matmul_kernel<double>), grid, block, 0, stream, (const double*)X, (const double*)S, T, K,
                        (const double*)B, J, (const double*)add, alpha, (double*)out);
   else
     return fail(AGGF_ERR_ARG, "aggf_frames_matmul: bad dtype");
@@ -433,7 +433,7 @@ extern "C" int aggf_augment_concat(const void* coords, const void* forces, int t
   if (g > 32768) g = 32768;
   const dim3 grid((unsigned)g), block(256);
 #define AGGF_CAT(TX, TY, TO)                                                                                       \
-  hipLaunchKernelGGL((augment_concat_kernel<TX, TY, TO>), grid, block, 0, stream, (const TX*)coords,               \
+  AGGF_LAUNCH((augment_concat_kernel<TX, TY, TO>), grid, block, 0, stream, (const TX*)coords,               \
                      (const TX*)forces, (const TY*)gen, (const TY*)corr, (const TY*)lgrad, T, N, n_aug, (TO)kbt,   \
                      (TO*)out_coords, (TO*)out_forces)
   if (traj_dtype == AGGF_F32 && aug_dtype == AGGF_F32) AGGF_CAT(float, float, float);

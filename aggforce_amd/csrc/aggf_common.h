@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <string.h>
 #include <string>
 
 #include "../../include/aggf.h"
@@ -27,6 +28,16 @@ int fail(int code, const char* fmt, ...);
     if (_e != hipSuccess)                                                         \
       return ::aggf::fail(AGGF_ERR_HIP, "kernel launch failed: %s (%s:%d)",       \
                           hipGetErrorString(_e), __FILE__, __LINE__);             \
+  } while (0)
+
+// ---- launch coverage (aggf_coverage_dump): every kernel launch of the library goes through AGGF_LAUNCH, which counts
+// the launch under the kernel's host handle -- the set of template instantiations a process actually executed, resolved
+// to symbol names on request.  tests/test_gpu_zz_coverage.py compares it with the kernels the library contains.
+void cover_hit(const void* kernel_handle);
+#define AGGF_LAUNCH(kernel, ...)                                   \
+  do {                                                             \
+    ::aggf::cover_hit(reinterpret_cast<const void*>(kernel));      \
+    hipLaunchKernelGGL(kernel, __VA_ARGS__);                       \
   } while (0)
 
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }

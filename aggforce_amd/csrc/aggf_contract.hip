@@ -387,7 +387,7 @@ extern "C" int aggf_trjdot_frames(const void* points, int p_dtype, const void* f
   const int vec_ok = !(ff && !pf) && (N % vf == 0) && (((uintptr_t)factor & 15) == 0) &&
                      (((uintptr_t)points & 15) == 0) && (((int64_t)N * 3 * (pf ? 8 : 4)) % 16 == 0);
 #define AGGF_TRJ(TFa, TP, TO)                                                                                    \
-  hipLaunchKernelGGL((trjdot_frames_kernel<TFa, TP, TO>), grid, block, 0, stream, (const TP*)points,               \
+  AGGF_LAUNCH((trjdot_frames_kernel<TFa, TP, TO>), grid, block, 0, stream, (const TP*)points,               \
                      (const TFa*)factor, T, N, n_cg, (const TO*)trans, (TO*)out, vec_ok)
   if (!pf && !ff) AGGF_TRJ(float, float, float);
   else if (pf && !ff) AGGF_TRJ(float, double, double);
@@ -410,7 +410,7 @@ extern "C" int aggf_feat_contract(const void* forces, int f_dtype, const void* f
   if (of != (ff || xf)) return fail(AGGF_ERR_ARG, "aggf_feat_contract: out dtype must be the promoted dtype");
   const dim3 grid = stream_grid(T * ceil_div(ld, 256)), block(256);
 #define AGGF_FC(TX, TF, TO)                                                                                      \
-  hipLaunchKernelGGL((feat_contract_kernel<TX, TF, TO>), grid, block, 0, stream, (const TF*)forces,               \
+  AGGF_LAUNCH((feat_contract_kernel<TX, TF, TO>), grid, block, 0, stream, (const TF*)forces,               \
                      (const TX*)feat, (const TX*)div, alpha, T, N, n_feat, ld, (TO*)out)
   if (!xf && !ff) AGGF_FC(float, float, float);
   else if (!xf && ff) AGGF_FC(float, double, double);
@@ -431,9 +431,9 @@ extern "C" int aggf_feat_constraint_rows(const void* feat, int x_dtype, int64_t 
   const dim3 grid((unsigned)ceil_div(n_feat, 64), (unsigned)ceil_div(n_cg, 16), (unsigned)S), block(256);
   if (grid.y > 65535) return fail(AGGF_ERR_ARG, "aggf_feat_constraint_rows: too many cg sites");
   if (x_dtype == AGGF_F32)
-    hipLaunchKernelGGL(feat_rows_kernel<float>, grid, block, 0, stream, (const float*)feat, N, n_feat, frame_idx, M, n_cg, site, A, b);
+    AGGF_LAUNCH(feat_rows_kernel<float>, grid, block, 0, stream, (const float*)feat, N, n_feat, frame_idx, M, n_cg, site, A, b);
   else if (x_dtype == AGGF_F64)
-    hipLaunchKernelGGL(feat_rows_kernel<double>, grid, block, 0, stream, (const double*)feat, N, n_feat, frame_idx, M, n_cg, site, A, b);
+    AGGF_LAUNCH(feat_rows_kernel<double>, grid, block, 0, stream, (const double*)feat, N, n_feat, frame_idx, M, n_cg, site, A, b);
   else
     return fail(AGGF_ERR_ARG, "aggf_feat_constraint_rows: bad dtype");
   AGGF_LAUNCH_OK();
@@ -444,7 +444,7 @@ extern "C" int aggf_gb_group_overlap(const double* Mg, int32_t n_cg, int32_t G, 
   hipStream_t stream = (hipStream_t)stream_v;
   if (!Mg || !M2) return fail(AGGF_ERR_ARG, "aggf_gb_group_overlap: NULL pointer");
   if (n_cg <= 0 || G <= 0) return fail(AGGF_ERR_ARG, "aggf_gb_group_overlap: bad shape");
-  hipLaunchKernelGGL(gb_overlap_kernel, stream_grid(ceil_div((int64_t)G * G, 256)), dim3(256), 0, stream, Mg, n_cg, G, M2);
+  AGGF_LAUNCH(gb_overlap_kernel, stream_grid(ceil_div((int64_t)G * G, 256)), dim3(256), 0, stream, Mg, n_cg, G, M2);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -462,10 +462,10 @@ extern "C" int aggf_gb_constraint_gram(const double* M2, const void* gauss, int 
   if (nt > 65535) return fail(AGGF_ERR_ARG, "aggf_gb_constraint_gram: too many columns");
   const dim3 grid(nt, nt), block(256);
   if (g_dtype == AGGF_F32)
-    hipLaunchKernelGGL(gb_ata_kernel<float>, grid, block, 0, stream, M2, (const float*)gauss, S, G, n_id, n_ch, n_basis,
+    AGGF_LAUNCH(gb_ata_kernel<float>, grid, block, 0, stream, M2, (const float*)gauss, S, G, n_id, n_ch, n_basis,
                        cols, n_cols, ld, AtA);
   else if (g_dtype == AGGF_F64)
-    hipLaunchKernelGGL(gb_ata_kernel<double>, grid, block, 0, stream, M2, (const double*)gauss, S, G, n_id, n_ch,
+    AGGF_LAUNCH(gb_ata_kernel<double>, grid, block, 0, stream, M2, (const double*)gauss, S, G, n_id, n_ch,
                        n_basis, cols, n_cols, ld, AtA);
   else
     return fail(AGGF_ERR_ARG, "aggf_gb_constraint_gram: bad dtype");
@@ -485,10 +485,10 @@ extern "C" int aggf_gb_constraint_rows(const double* Mg, const void* gauss, int 
     return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: bad shape");
   const int64_t total = (int64_t)S * n_cg * ld;
   if (g_dtype == AGGF_F32)
-    hipLaunchKernelGGL(gb_rows_kernel<float>, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg,
+    AGGF_LAUNCH(gb_rows_kernel<float>, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg,
                        (const float*)gauss, S, n_cg, G, n_id, n_ch, n_basis, cols, n_cols, ld, site, A, b);
   else if (g_dtype == AGGF_F64)
-    hipLaunchKernelGGL(gb_rows_kernel<double>, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg,
+    AGGF_LAUNCH(gb_rows_kernel<double>, stream_grid(ceil_div(total, 256)), dim3(256), 0, stream, Mg,
                        (const double*)gauss, S, n_cg, G, n_id, n_ch, n_basis, cols, n_cols, ld, site, A, b);
   else
     return fail(AGGF_ERR_ARG, "aggf_gb_constraint_rows: bad feature dtype");
@@ -504,9 +504,9 @@ extern "C" int aggf_feat_weights(const void* feat, int x_dtype, int64_t T, int32
   const dim3 grid = stream_grid(ceil_div(T * N, 4)), block(256);
   const int vec_ok = (((uintptr_t)feat & 15) == 0) && (n_feat % (x_dtype == AGGF_F64 ? 2 : 4) == 0);
   if (x_dtype == AGGF_F32)
-    hipLaunchKernelGGL(feat_weights_kernel<float>, grid, block, 0, stream, (const float*)feat, T, N, n_feat, coef, ld_t, w, vec_ok);
+    AGGF_LAUNCH(feat_weights_kernel<float>, grid, block, 0, stream, (const float*)feat, T, N, n_feat, coef, ld_t, w, vec_ok);
   else if (x_dtype == AGGF_F64)
-    hipLaunchKernelGGL(feat_weights_kernel<double>, grid, block, 0, stream, (const double*)feat, T, N, n_feat, coef, ld_t, w, vec_ok);
+    AGGF_LAUNCH(feat_weights_kernel<double>, grid, block, 0, stream, (const double*)feat, T, N, n_feat, coef, ld_t, w, vec_ok);
   else
     return fail(AGGF_ERR_ARG, "aggf_feat_weights: bad dtype");
   AGGF_LAUNCH_OK();

@@ -445,13 +445,13 @@ extern "C" int aggf_group_reduce(const void* X, int64_t T, int32_t N, int in_dty
   if (T <= 0 || N <= 0 || n_groups <= 0) return fail(AGGF_ERR_ARG, "aggf_group_reduce: empty problem");
   const dim3 grid((unsigned)(T < 8192 ? T : 8192)), block(256);
   if (in_dtype == AGGF_F32 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((group_reduce_kernel<float, float>), grid, block, 0, stream, (const float*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (float*)out);
+    AGGF_LAUNCH((group_reduce_kernel<float, float>), grid, block, 0, stream, (const float*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (float*)out);
   else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((group_reduce_kernel<double, double>), grid, block, 0, stream, (const double*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (double*)out);
+    AGGF_LAUNCH((group_reduce_kernel<double, double>), grid, block, 0, stream, (const double*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (double*)out);
   else if (in_dtype == AGGF_F64 && out_dtype == AGGF_F32)
-    hipLaunchKernelGGL((group_reduce_kernel<double, float>), grid, block, 0, stream, (const double*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (float*)out);
+    AGGF_LAUNCH((group_reduce_kernel<double, float>), grid, block, 0, stream, (const double*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (float*)out);
   else if (in_dtype == AGGF_F32 && out_dtype == AGGF_F64)
-    hipLaunchKernelGGL((group_reduce_kernel<float, double>), grid, block, 0, stream, (const float*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (double*)out);
+    AGGF_LAUNCH((group_reduce_kernel<float, double>), grid, block, 0, stream, (const float*)X, T, N, grp_ptr, grp_atoms, n_groups, mean, (double*)out);
   else
     return fail(AGGF_ERR_ARG, "aggf_group_reduce: bad dtype");
   AGGF_LAUNCH_OK();
@@ -470,10 +470,10 @@ extern "C" int aggf_gb_channels(const void* Pg, const void* cg, int g_dtype, int
   if (rc) return rc;
   if (g_dtype == AGGF_F32) {
     GbParams<float> gp{(const float*)centers, n_basis, (float)width, (float)clip};
-    hipLaunchKernelGGL(gb_channels_kernel<float>, feat_grid(T * n_ch), dim3(256), 0, stream, (const float*)Pg, (const float*)cg, T, G, n_cg, site, sizes, n_ch, gp, (float*)gauss, (float*)grad);
+    AGGF_LAUNCH(gb_channels_kernel<float>, feat_grid(T * n_ch), dim3(256), 0, stream, (const float*)Pg, (const float*)cg, T, G, n_cg, site, sizes, n_ch, gp, (float*)gauss, (float*)grad);
   } else if (g_dtype == AGGF_F64) {
     GbParams<double> gp{(const double*)centers, n_basis, width, clip};
-    hipLaunchKernelGGL(gb_channels_kernel<double>, feat_grid(T * n_ch), dim3(256), 0, stream, (const double*)Pg, (const double*)cg, T, G, n_cg, site, sizes, n_ch, gp, (double*)gauss, (double*)grad);
+    AGGF_LAUNCH(gb_channels_kernel<double>, feat_grid(T * n_ch), dim3(256), 0, stream, (const double*)Pg, (const double*)cg, T, G, n_cg, site, sizes, n_ch, gp, (double*)gauss, (double*)grad);
   } else {
     return fail(AGGF_ERR_ARG, "aggf_gb_channels: bad feature dtype");
   }
@@ -515,7 +515,7 @@ extern "C" int aggf_gb_regmat(const void* Fg, int f_dtype, const void* Pg, const
   if (rc) return rc;
   const dim3 grid = feat_grid(T * (n_id + n_ch));
   AGGF_GB_DISPATCH("aggf_gb_regmat",
-                   hipLaunchKernelGGL((gb_regmat_kernel<TF, TG, TO>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                   AGGF_LAUNCH((gb_regmat_kernel<TF, TG, TO>), grid, dim3(256), 0, stream, (const TF*)Fg,
                                       (const TG*)Pg, (const TG*)cg, T, G, n_cg, site, sizes, n_id, n_ch, gp, kbt,
                                       ld_feat, (TO*)R3));
   AGGF_LAUNCH_OK();
@@ -536,7 +536,7 @@ extern "C" int aggf_gb_apply(const void* Fg, int f_dtype, const void* Pg, const 
   const dim3 grid = feat_grid(((T + GB_FR - 1) / GB_FR) * n_cg * 64);
   const int out_dtype = AGGF_F64;
   AGGF_GB_DISPATCH("aggf_gb_apply",
-                   hipLaunchKernelGGL((gb_apply_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                   AGGF_LAUNCH((gb_apply_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
                                       (const TG*)Pg, (const TG*)cg, T, G, n_cg, sizes, n_id, n_ch, gp, coef, n_feat,
                                       out));
   AGGF_LAUNCH_OK();
@@ -557,7 +557,7 @@ extern "C" int aggf_gb_apply_cols(const void* Fg, int f_dtype, const void* Pg, c
   const dim3 grid = feat_grid(((T + GB_FR - 1) / GB_FR) * n_cg * 64);
   const int out_dtype = AGGF_F64;
   AGGF_GB_DISPATCH("aggf_gb_apply_cols",
-                   hipLaunchKernelGGL((gb_apply_cols_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                   AGGF_LAUNCH((gb_apply_cols_kernel<TF, TG>), grid, dim3(256), 0, stream, (const TF*)Fg,
                                       (const TG*)Pg, (const TG*)cg, T, G, n_cg, sizes, n_id, coef_id, col_ptr, col_idx,
                                       col_val, gp, out));
   AGGF_LAUNCH_OK();
@@ -573,7 +573,7 @@ extern "C" int aggf_gb_distance_range(const float* Pg, const float* cg, int64_t 
   int64_t slices = ceil_div(T, 256);
   if (slices > 256) slices = 256;
   const dim3 grid((unsigned)ceil_div(n_ch, 256), (unsigned)n_cg, (unsigned)slices);
-  hipLaunchKernelGGL(gb_range_kernel, grid, dim3(256), 0, stream, Pg, cg, T, G, n_cg, n_ch, rmin, rmax);
+  AGGF_LAUNCH(gb_range_kernel, grid, dim3(256), 0, stream, Pg, cg, T, G, n_cg, n_ch, rmin, rmax);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -593,7 +593,7 @@ extern "C" int aggf_gb_regmat_cols(const void* Fg, int f_dtype, const void* Pg, 
   if (rc) return rc;
   const dim3 grid = feat_grid(T * (n_id + n_cols));
   AGGF_GB_DISPATCH("aggf_gb_regmat_cols",
-                   hipLaunchKernelGGL((gb_regmat_cols_kernel<TF, TG, TO>), grid, dim3(256), 0, stream, (const TF*)Fg,
+                   AGGF_LAUNCH((gb_regmat_cols_kernel<TF, TG, TO>), grid, dim3(256), 0, stream, (const TF*)Fg,
                                       (const TG*)Pg, (const TG*)cg, T, G, n_cg, site, sizes, n_id, cols, n_cols, gp, kbt,
                                       ld_feat, (TO*)R3));
   AGGF_LAUNCH_OK();

@@ -1114,14 +1114,14 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     attr_done = true;
   }
-  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, p.first_tile);
+  AGGF_LAUNCH(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, p.first_tile);
   AGGF_LAUNCH_OK();
   const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
-  hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE>), dim3((unsigned)round_up(nblk, 512)),
+  AGGF_LAUNCH((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE>), dim3((unsigned)round_up(nblk, 512)),
                      dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs,
                      (const T*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0));
   AGGF_LAUNCH_OK();
-  hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
+  AGGF_LAUNCH((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                      slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
@@ -1193,7 +1193,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
         attr_done = true;                                                                                            \
       }                                                                                                              \
     }                                                                                                                \
-    hipLaunchKernelGGL((gram_small_kernel<TIn, TC, NVC, KBC, NWC, WC, CC>), dim3((unsigned)p.ksplit, (unsigned)p.parts), \
+    AGGF_LAUNCH((gram_small_kernel<TIn, TC, NVC, KBC, NWC, WC, CC>), dim3((unsigned)p.ksplit, (unsigned)p.parts), \
                        dim3(64 * NWC), lds, stream, reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms,      \
                        n_red, p.frames_per_split, (int32_t)raw_bytes, slabs);                                        \
   } while (0)
@@ -1241,13 +1241,13 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
 #undef AGGF_SMALL
     AGGF_LAUNCH_OK();
     if (width == 4 * TILE)
-      hipLaunchKernelGGL((gram_reduce_small_kernel<TC, 4 * TILE>), dim3(4 * TILE), dim3(1024), 0, stream, slabs, p.ksplit,
+      AGGF_LAUNCH((gram_reduce_small_kernel<TC, 4 * TILE>), dim3(4 * TILE), dim3(1024), 0, stream, slabs, p.ksplit,
                          n_red, accumulate, G, p.parts);
     else if (width > TILE)
-      hipLaunchKernelGGL((gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
+      AGGF_LAUNCH((gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
                          n_red, accumulate, G, 1);
     else
-      hipLaunchKernelGGL((gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
+      AGGF_LAUNCH((gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
                          accumulate, G, 1);
     AGGF_LAUNCH_OK();
     return AGGF_OK;
@@ -1310,10 +1310,10 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     }
     if (gy > rows) gy = rows;
     if (st != stream)
-      hipLaunchKernelGGL((pack_groups_kernel<TIn, TC, true>), dim3(gx, (unsigned)gy), dim3(256), 0, st,
+      AGGF_LAUNCH((pack_groups_kernel<TIn, TC, true>), dim3(gx, (unsigned)gy), dim3(256), 0, st,
                          F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad, dst);
     else
-      hipLaunchKernelGGL((pack_groups_kernel<TIn, TC>), dim3(gx, (unsigned)gy), dim3(256), 0, st,
+      AGGF_LAUNCH((pack_groups_kernel<TIn, TC>), dim3(gx, (unsigned)gy), dim3(256), 0, st,
                          F + t0 * (int64_t)N * 3, rows, N, grp_ptr, grp_atoms, n_red, p.n_pad, dst);
   };
   int acc = accumulate;
@@ -1424,15 +1424,15 @@ static int gram_pair_typed(const T* F, const T* F2, int64_t rows, int32_t N, int
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     attr_done = true;
   }
-  hipLaunchKernelGGL(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, 0);
+  AGGF_LAUNCH(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, 0);
   AGGF_LAUNCH_OK();
   const int64_t nblk = (int64_t)ksplit * p.n_tiles;
   if (nblk > 0x7fffff00LL) return fail(AGGF_ERR_ARG, "gram grid too large");
-  hipLaunchKernelGGL((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, true>), dim3((unsigned)round_up(nblk, 512)),
+  AGGF_LAUNCH((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, true>), dim3((unsigned)round_up(nblk, 512)),
                      dim3(512), lds3, stream, F, rows, (int64_t)N * 3, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs, F2,
                      (int64_t)N2 * 3, N / TILE);
   AGGF_LAUNCH_OK();
-  hipLaunchKernelGGL((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit,
+  AGGF_LAUNCH((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit,
                      N + N2, accumulate, G, 0);
   AGGF_LAUNCH_OK();
   return AGGF_OK;

@@ -195,14 +195,14 @@ static int pair_moments_impl(const void* X, int64_t T, int32_t N, int dtype, dou
   double* slabs = reinterpret_cast<double*>(ws);
   const dim3 grid((unsigned)((int64_t)n_tiles * ksplit));
   if (dtype == AGGF_F64) {
-    hipLaunchKernelGGL(pair_stats_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, T, N, nt1, n_tiles, fps, slabs);
+    AGGF_LAUNCH(pair_stats_kernel<double>, grid, dim3(256), 0, stream, (const double*)X, T, N, nt1, n_tiles, fps, slabs);
     AGGF_LAUNCH_OK();
-    hipLaunchKernelGGL(pair_var_kernel<double>, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var,
+    AGGF_LAUNCH(pair_var_kernel<double>, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var,
                        (const double*)X, mean);
   } else if (dtype == AGGF_F32) {
-    hipLaunchKernelGGL(pair_stats_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, T, N, nt1, n_tiles, fps, slabs);
+    AGGF_LAUNCH(pair_stats_kernel<float>, grid, dim3(256), 0, stream, (const float*)X, T, N, nt1, n_tiles, fps, slabs);
     AGGF_LAUNCH_OK();
-    hipLaunchKernelGGL(pair_var_kernel<float>, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var,
+    AGGF_LAUNCH(pair_var_kernel<float>, dim3(n_tiles), dim3(256), 0, stream, slabs, nt1, ksplit, N, T, var,
                        (const float*)X, mean);
   } else {
     return fail(AGGF_ERR_ARG, "%s: bad dtype", who);
@@ -229,7 +229,7 @@ extern "C" int aggf_pair_pool_term(const double* var_r, const double* mean_r, co
   if (n <= 0) return AGGF_OK;
   int64_t g = ceil_div(n, 256);
   if (g > 4096) g = 4096;
-  hipLaunchKernelGGL(pair_pool_kernel, dim3((unsigned)g), dim3(256), 0, stream, var_r, mean_r, mean, weight, n, out);
+  AGGF_LAUNCH(pair_pool_kernel, dim3((unsigned)g), dim3(256), 0, stream, var_r, mean_r, mean, weight, n, out);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }

@@ -796,12 +796,12 @@ static void gemm(Ctx& c, int M, int N, int K, double alpha, Mat A, Mat B, double
         c.rc = fail(AGGF_ERR_HIP, "gemm LDS attribute failed");
       done = true;
     }
-    hipLaunchKernelGGL((gemm_tile_kernel<TA, TB, 128, 128, 64, 32>),
+    AGGF_LAUNCH((gemm_tile_kernel<TA, TB, 128, 128, 64, 32>),
                        dim3((unsigned)ceil_div(N, 128), (unsigned)ceil_div(M, 128), (unsigned)gz), dim3(512), lds, c.stream, M,
                        N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, lower_only, bt);
   } else {
     constexpr size_t lds = (size_t)2 * (64 + 64) * GS * sizeof(double);
-    hipLaunchKernelGGL((gemm_tile_kernel<TA, TB, 64, 64, 32, 32>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), lds,
+    AGGF_LAUNCH((gemm_tile_kernel<TA, TB, 64, 64, 32, 32>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), lds,
                        c.stream, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, lower_only, bt);
   }
   if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "gemm launch failed");
@@ -844,7 +844,7 @@ static void build_big_inverses(Ctx& c, Mat L, int npad, Mat Dinv) {
   if (nbig <= 0 || c.rc) return;
   const Mat Dbig = dbig_of(Dinv, npad);
   double* Tp = Dbig.p + (size_t)nbig * BIG * BIG;
-  hipLaunchKernelGGL(dbig_init_kernel, flat_grid((int64_t)nbig * BIG * BIG, c.nprob), dim3(256), 0, c.stream, Dinv.p,
+  AGGF_LAUNCH(dbig_init_kernel, flat_grid((int64_t)nbig * BIG * BIG, c.nprob), dim3(256), 0, c.stream, Dinv.p,
                      Dbig.p, nbig, Dinv.ps);
   if (hipGetLastError() != hipSuccess) { c.rc = fail(AGGF_ERR_HIP, "dbig_init launch failed"); return; }
   const int64_t l_o = (int64_t)BIG * npad + BIG, d_o = (int64_t)BIG * BIG, t_o = (int64_t)(BIG / 2) * (BIG / 2);
@@ -907,12 +907,12 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
       if (one_launch) {
         const int nrb = rem / NB;
         const int gx = nrb < 1 ? 1 : (nrb < gx_max ? nrb : gx_max);
-        hipLaunchKernelGGL(chol_step_kernel, dim3((unsigned)gx, (unsigned)c.nprob), dim3(256), STEP_LDS, c.stream, P.p,
+        AGGF_LAUNCH(chol_step_kernel, dim3((unsigned)gx, (unsigned)c.nprob), dim3(256), STEP_LDS, c.stream, P.p,
                            P.ld, k, k - k0, nrb, Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
         if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "chol_step launch failed");
         continue;
       }
-      hipLaunchKernelGGL(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, P.ld,
+      AGGF_LAUNCH(potrf_diag_mfma_kernel, dim3(c.nprob), dim3(256), POTRF3_LDS, c.stream, Akk.p, P.ld,
                          Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
       if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "potrf launch failed");
       if (rem <= 0) break;
@@ -1063,14 +1063,14 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   const int64_t r0 = (int64_t)(ob0 < npad / BIG ? ob0 : npad / BIG) * BIG;
   const int first_big = (int)(r0 / BIG);
 
-  hipLaunchKernelGGL(init_stats_kernel, dim3((unsigned)ceil_div(4 * np, 64)), dim3(64), 0, st, stats, 4 * np);
-  hipLaunchKernelGGL(max_diag_kernel, dim3(1, np), dim3(256), 0, st, G, n, g_ps, l2, l2_diag, scal, (int64_t)4);
-  hipLaunchKernelGGL(copy_scalar_kernel, dim3(np), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
-  hipLaunchKernelGGL(build_pt_kernel, flat_grid((int64_t)npad * npad, np), dim3(256), 0, st, G, n, g_ps, npad, l2,
+  AGGF_LAUNCH(init_stats_kernel, dim3((unsigned)ceil_div(4 * np, 64)), dim3(64), 0, st, stats, 4 * np);
+  AGGF_LAUNCH(max_diag_kernel, dim3(1, np), dim3(256), 0, st, G, n, g_ps, l2, l2_diag, scal, (int64_t)4);
+  AGGF_LAUNCH(copy_scalar_kernel, dim3(np), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
+  AGGF_LAUNCH(build_pt_kernel, flat_grid((int64_t)npad * npad, np), dim3(256), 0, st, G, n, g_ps, npad, l2,
                      l2_diag, scal, (int64_t)4, AtA, perm, Pt.p, Pt.ps);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad, np), dim3(256), 0, st, A, m, n, a_ps, 0, Ap.p,
+  AGGF_LAUNCH(pad_copy_kernel, flat_grid((int64_t)mpad * npad, np), dim3(256), 0, st, A, m, n, a_ps, 0, Ap.p,
                      mpad, npad, Ap.ps, perm);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * rpad, np), dim3(256), 0, st, B,
+  AGGF_LAUNCH(pad_copy_kernel, flat_grid((int64_t)mpad * rpad, np), dim3(256), 0, st, B,
                      B ? m : (m < nrhs ? m : nrhs), nrhs, b_ps, 0, Bp.p, mpad, rpad, Bp.ps);
   AGGF_LAUNCH_OK();
   // P~ = P/s + A'A  (the factorisation reads the lower triangle only); a caller that knows the structure of its
@@ -1078,13 +1078,13 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   if (!AtA) gemm<true, false>(c, npad, npad, mpad, 1.0, Ap, Ap, 1.0, Pt, 1);
   cholesky(c, Pt, npad, Dinv, stats, 0);
   // Y = L^-1 A'
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * mpad, np), dim3(256), 0, st, A, m, n, a_ps, 1, Bw_m.p,
+  AGGF_LAUNCH(pad_copy_kernel, flat_grid((int64_t)npad * mpad, np), dim3(256), 0, st, A, m, n, a_ps, 1, Bw_m.p,
                      npad, mpad, Bw_m.ps, perm);
   solve_lower(c, Pt, npad, Dinv, Bw_m, Y, mpad, first_big);
   // S = Y'Y (identity on the padding), factor it; rows of Y above r0 are zero (and were never written)
   gemm<true, false>(c, mpad, mpad, npad - (int)r0, 1.0, Y.at(r0, 0), Y.at(r0, 0), 0.0, S, 1);
-  if (mpad > m) hipLaunchKernelGGL(fix_pad_diag_kernel, dim3(1, np), dim3(64), 0, st, S.p, m, mpad, S.ps);
-  if (schur_reg > 0.0) hipLaunchKernelGGL(schur_reg_kernel, dim3(1, np), dim3(256), 0, st, S.p, m, mpad, S.ps, schur_reg);
+  if (mpad > m) AGGF_LAUNCH(fix_pad_diag_kernel, dim3(1, np), dim3(64), 0, st, S.p, m, mpad, S.ps);
+  if (schur_reg > 0.0) AGGF_LAUNCH(schur_reg_kernel, dim3(1, np), dim3(256), 0, st, S.p, m, mpad, S.ps, schur_reg);
   cholesky(c, S, mpad, DinvS, stats, n);
   // Lam = S^-1 Bp ; Xt = L^-T (Y Lam)
   auto schur_solve = [&](Mat rhs, Mat out) {
@@ -1107,8 +1107,8 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
   const unsigned resid_blocks = (unsigned)(rb < 1 ? 1 : rb > 64 ? 64 : rb);
   for (int it = 0; it < n_refine; ++it) {
     gemm<false, false>(c, mpad, rpad, npad - (int)r0, 1.0, Ap.at(0, r0), Xt.at(r0, 0), 0.0, Lam);
-    if (it > 0) hipLaunchKernelGGL(zero_scalar_kernel, dim3(np), dim3(1), 0, st, scal + 1, (int64_t)4);
-    hipLaunchKernelGGL(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps,
+    if (it > 0) AGGF_LAUNCH(zero_scalar_kernel, dim3(np), dim3(1), 0, st, scal + 1, (int64_t)4);
+    AGGF_LAUNCH(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps,
                        it == 0 ? stats + 2 : scal + 1, (int64_t)4);
     // padded rows/cols of A Xt - Bp are exact zeros, so the padded residual needs no masking.
     // Bw's storage is reused as the (mpad x rpad) scratch for S^-1 R: per problem it holds at least
@@ -1117,13 +1117,13 @@ static int eq_qp_solve_impl(const double* G, int32_t n, double l2, const double*
     schur_solve(Lam, SR);
     y_times(SR);
     solve_lower_t(c, Pt, npad, Dinv, Z, X2, rpad);
-    hipLaunchKernelGGL(axpy_kernel, flat_grid((int64_t)np * l.e_nr), dim3(256), 0, st, Xt.p, X2.p, -1.0,
+    AGGF_LAUNCH(axpy_kernel, flat_grid((int64_t)np * l.e_nr), dim3(256), 0, st, Xt.p, X2.p, -1.0,
                        (int64_t)np * (int64_t)l.e_nr);
   }
   gemm<false, false>(c, mpad, rpad, npad - (int)r0, 1.0, Ap.at(0, r0), Xt.at(r0, 0), 0.0, Lam);
-  hipLaunchKernelGGL(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps, stats + 1,
+  AGGF_LAUNCH(resid_kernel, dim3(resid_blocks, np), dim3(256), 0, st, Lam.p, Bp.p, m, nrhs, rpad, Lam.ps, stats + 1,
                      (int64_t)4);
-  hipLaunchKernelGGL(crop_transpose_kernel, flat_grid((int64_t)nrhs * n, np), dim3(256), 0, st, Xt.p, rpad, Xt.ps, n,
+  AGGF_LAUNCH(crop_transpose_kernel, flat_grid((int64_t)nrhs * n, np), dim3(256), 0, st, Xt.p, rpad, Xt.ps, n,
                      nrhs, X, perm);
   AGGF_LAUNCH_OK();
   return c.rc;
@@ -1318,12 +1318,12 @@ extern "C" int aggf_gram_quadform(const double* G, int32_t n, const double* X, i
   double* Y = Xp + (size_t)mpad * npad;
   Ctx c;
   c.stream = st;
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * npad), dim3(256), 0, st, G, n, n, (int64_t)0, 0, Gp, npad, npad, (int64_t)0);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)mpad * npad), dim3(256), 0, st, X, m, n, (int64_t)0, 0, Xp, mpad, npad, (int64_t)0);
+  AGGF_LAUNCH(pad_copy_kernel, flat_grid((int64_t)npad * npad), dim3(256), 0, st, G, n, n, (int64_t)0, 0, Gp, npad, npad, (int64_t)0);
+  AGGF_LAUNCH(pad_copy_kernel, flat_grid((int64_t)mpad * npad), dim3(256), 0, st, X, m, n, (int64_t)0, 0, Xp, mpad, npad, (int64_t)0);
   AGGF_LAUNCH_OK();
   gemm<false, false>(c, mpad, npad, npad, 1.0, Mat{Xp, npad, 0}, Mat{Gp, npad, 0}, 0.0, Mat{Y, npad, 0});  // Y = X G
   if (c.rc) return c.rc;
-  hipLaunchKernelGGL(rowdot_kernel, dim3(m), dim3(256), 0, st, Xp, (int64_t)npad, Y, (int64_t)npad, n, q);
+  AGGF_LAUNCH(rowdot_kernel, dim3(m), dim3(256), 0, st, Xp, (int64_t)npad, Y, (int64_t)npad, n, q);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -1333,7 +1333,7 @@ extern "C" int aggf_daxpby(int64_t n, double a, const double* x, double b, const
   hipStream_t st = (hipStream_t)stream_v;
   if (!x || !y || !out) return fail(AGGF_ERR_ARG, "aggf_daxpby: NULL pointer");
   if (n <= 0) return AGGF_OK;
-  hipLaunchKernelGGL(axpby_kernel, flat_grid(n), dim3(256), 0, st, n, a, x, b, y, out);
+  AGGF_LAUNCH(axpby_kernel, flat_grid(n), dim3(256), 0, st, n, a, x, b, y, out);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -1391,20 +1391,20 @@ extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, co
   double* scal = reinterpret_cast<double*>(w + l.off_scal);
   int32_t* free_idx = reinterpret_cast<int32_t*>(w + l.off_idx);
   int32_t* mark = free_idx + n;
-  hipLaunchKernelGGL(init_stats_kernel, dim3(1), dim3(64), 0, st, stats, 4);
-  hipLaunchKernelGGL(pinned_free_list_kernel, dim3(1), dim3(256), 0, st, pin_idx, m, n, mark, free_idx, stats);
-  hipLaunchKernelGGL(max_diag_kernel, dim3(1, 1), dim3(256), 0, st, G, n, (int64_t)0, l2, l2_diag, scal, (int64_t)4);
-  hipLaunchKernelGGL(copy_scalar_kernel, dim3(1), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
-  hipLaunchKernelGGL(pinned_build_kernel, flat_grid((int64_t)(npad + rpad) * npad), dim3(256), 0, st, G, n, free_idx, nf,
+  AGGF_LAUNCH(init_stats_kernel, dim3(1), dim3(64), 0, st, stats, 4);
+  AGGF_LAUNCH(pinned_free_list_kernel, dim3(1), dim3(256), 0, st, pin_idx, m, n, mark, free_idx, stats);
+  AGGF_LAUNCH(max_diag_kernel, dim3(1, 1), dim3(256), 0, st, G, n, (int64_t)0, l2, l2_diag, scal, (int64_t)4);
+  AGGF_LAUNCH(copy_scalar_kernel, dim3(1), dim3(1), 0, st, scal, (int64_t)4, stats + 3, (int64_t)4);
+  AGGF_LAUNCH(pinned_build_kernel, flat_grid((int64_t)(npad + rpad) * npad), dim3(256), 0, st, G, n, free_idx, nf,
                      pin_idx, m, npad, rpad, l2, l2_diag, scal, Pt.p, stats);
   AGGF_LAUNCH_OK();
   // the rows below the matrix leave the factorisation as Y' = B' L^-T: no forward solve of its own
   cholesky(c, Pt, npad, Dinv, stats, 0, rpad);
-  hipLaunchKernelGGL(pad_copy_kernel, flat_grid((int64_t)npad * rpad), dim3(256), 0, st, Pt.p + (int64_t)npad * npad, rpad, npad,
+  AGGF_LAUNCH(pad_copy_kernel, flat_grid((int64_t)npad * rpad), dim3(256), 0, st, Pt.p + (int64_t)npad * npad, rpad, npad,
                      (int64_t)0, 1, Z.p, npad, rpad, (int64_t)0);
   AGGF_LAUNCH_OK();
   solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
-  hipLaunchKernelGGL(pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
+  AGGF_LAUNCH(pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
                      n, X, stats);
   AGGF_LAUNCH_OK();
   return c.rc;

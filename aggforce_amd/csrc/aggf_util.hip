@@ -1,10 +1,89 @@
 // Error plumbing, small streaming kernels (NaN scan, allclose, sum of squares, map
 // expansion) and the counter-based synthetic trajectory generator.
+#include <cxxabi.h>
+#include <dlfcn.h>
 #include <stdarg.h>
+#include <stdlib.h>
+
+#include <atomic>
 
 #include "aggf_common.h"
 
 namespace aggf {
+
+// ---- launch coverage: a fixed open-addressing table kernel handle -> launch count, lock-free (a launch costs two
+// atomic operations).  A process that has AGGF_COVERAGE_FILE set appends its table to that file when the library is
+// unloaded (one line per kernel: label <tab> mangled name <tab> count; the label is AGGF_COVERAGE_LABEL at that moment):
+// the test session collects the launches of its child processes that way.
+constexpr int COVER_SLOTS = 4096;  // power of two, ~10x the kernels of the library
+static std::atomic<const void*> g_cover_key[COVER_SLOTS];
+static std::atomic<uint64_t> g_cover_cnt[COVER_SLOTS];
+
+void cover_hit(const void* h) {
+  size_t i = ((uintptr_t)h >> 3) * 0x9E3779B97F4A7C15ull >> 52;
+  for (int probe = 0; probe < COVER_SLOTS; ++probe, i = (i + 1) & (COVER_SLOTS - 1)) {
+    const void* k = g_cover_key[i].load(std::memory_order_relaxed);
+    if (k == nullptr) {
+      const void* expected = nullptr;
+      if (g_cover_key[i].compare_exchange_strong(expected, h, std::memory_order_relaxed)) k = h; else k = expected;
+    }
+    if (k == h) {
+      g_cover_cnt[i].fetch_add(1, std::memory_order_relaxed);
+      return;
+    }
+  }
+}
+
+// "mangled name<tab>demangled name<tab>count<newline>" per executed kernel into buf (always NUL-terminated when
+// n > 0), with `label<tab>` in front of every line if given; returns the bytes the full text needs (without the NUL)
+static size_t cover_dump(char* buf, size_t n, const char* label) {
+  size_t need = 0;
+  if (n > 0) buf[0] = 0;
+  for (int i = 0; i < COVER_SLOTS; ++i) {
+    const void* k = g_cover_key[i].load(std::memory_order_relaxed);
+    if (!k) continue;
+    Dl_info info;
+    char addr[32];
+    const char* name = nullptr;
+    if (dladdr(k, &info) && info.dli_sname && info.dli_saddr == k) name = info.dli_sname;
+    if (!name) {
+      snprintf(addr, sizeof(addr), "?%p", k);
+      name = addr;
+    }
+    int status = 1;
+    char* pretty = name[0] == '_' ? abi::__cxa_demangle(name, nullptr, nullptr, &status) : nullptr;
+    std::string line;
+    if (label) line.append(label).append("\t");
+    line.append(name).append("\t").append(status == 0 && pretty ? pretty : name).append("\t");
+    line.append(std::to_string((unsigned long long)g_cover_cnt[i].load())).append("\n");
+    free(pretty);
+    if (need + line.size() < n) {
+      memcpy(buf + need, line.data(), line.size());
+      buf[need + line.size()] = 0;
+    }
+    need += line.size();
+  }
+  return need;
+}
+
+namespace {
+struct CoverAtExit {
+  ~CoverAtExit() {
+    const char* path = getenv("AGGF_COVERAGE_FILE");
+    if (!path || !path[0]) return;
+    const char* label = getenv("AGGF_COVERAGE_LABEL");
+    const size_t need = cover_dump(nullptr, 0, label ? label : "-");
+    if (need == 0) return;
+    std::string text(need + 1, '\0');
+    cover_dump(&text[0], need + 1, label ? label : "-");
+    FILE* f = fopen(path, "a");  // O_APPEND: one write per process, whole lines
+    if (!f) return;
+    fwrite(text.data(), 1, need, f);
+    fclose(f);
+  }
+};
+static CoverAtExit g_cover_at_exit;
+}  // namespace
 
 static thread_local std::string g_last_error;
 
@@ -231,6 +310,13 @@ extern "C" int aggf_version(void) { return AGGF_VERSION; }
 
 extern "C" const char* aggf_last_error(void) { return aggf::g_last_error.c_str(); }
 
+extern "C" size_t aggf_coverage_dump(char* buf, size_t buf_bytes) { return aggf::cover_dump(buf, buf_bytes, nullptr); }
+
+extern "C" int aggf_coverage_reset(void) {
+  for (int i = 0; i < aggf::COVER_SLOTS; ++i) aggf::g_cover_cnt[i].store(0);
+  return AGGF_OK;
+}
+
 extern "C" int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes) {
   int dev = 0, n = 0;
   AGGF_HIP_OK(hipGetDevice(&dev));
@@ -248,9 +334,9 @@ extern "C" int aggf_has_nan(const void* x, int64_t count, int dtype, int32_t* fl
   if (!x || !flag) return fail(AGGF_ERR_ARG, "aggf_has_nan: NULL pointer");
   if (count <= 0) return AGGF_OK;
   if (dtype == AGGF_F64)
-    hipLaunchKernelGGL(has_nan_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)x, count, flag);
+    AGGF_LAUNCH(has_nan_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)x, count, flag);
   else if (dtype == AGGF_F32)
-    hipLaunchKernelGGL(has_nan_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)x, count, flag);
+    AGGF_LAUNCH(has_nan_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)x, count, flag);
   else
     return fail(AGGF_ERR_ARG, "aggf_has_nan: bad dtype");
   AGGF_LAUNCH_OK();
@@ -263,9 +349,9 @@ extern "C" int aggf_not_close(const void* a, const void* b, int64_t count, int d
   if (!a || !b || !flag) return fail(AGGF_ERR_ARG, "aggf_not_close: NULL pointer");
   if (count <= 0) return AGGF_OK;
   if (dtype == AGGF_F64)
-    hipLaunchKernelGGL(not_close_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)a, (const double*)b, count, rtol, atol, flag);
+    AGGF_LAUNCH(not_close_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)a, (const double*)b, count, rtol, atol, flag);
   else if (dtype == AGGF_F32)
-    hipLaunchKernelGGL(not_close_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)a, (const float*)b, count, rtol, atol, flag);
+    AGGF_LAUNCH(not_close_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)a, (const float*)b, count, rtol, atol, flag);
   else
     return fail(AGGF_ERR_ARG, "aggf_not_close: bad dtype");
   AGGF_LAUNCH_OK();
@@ -282,13 +368,13 @@ extern "C" int aggf_sumsq(const void* x, int64_t count, int dtype, double* out, 
   if (count < 0) return fail(AGGF_ERR_ARG, "aggf_sumsq: negative count");
   double* part = (double*)ws;
   if (dtype == AGGF_F64)
-    hipLaunchKernelGGL(sumsq_kernel<double>, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, (const double*)x, count, part);
+    AGGF_LAUNCH(sumsq_kernel<double>, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, (const double*)x, count, part);
   else if (dtype == AGGF_F32)
-    hipLaunchKernelGGL(sumsq_kernel<float>, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, (const float*)x, count, part);
+    AGGF_LAUNCH(sumsq_kernel<float>, dim3(SUMSQ_BLOCKS), dim3(256), 0, stream, (const float*)x, count, part);
   else
     return fail(AGGF_ERR_ARG, "aggf_sumsq: bad dtype");
   AGGF_LAUNCH_OK();
-  hipLaunchKernelGGL(sum_fixed_kernel, dim3(1), dim3(256), 0, stream, part, SUMSQ_BLOCKS, out);
+  AGGF_LAUNCH(sum_fixed_kernel, dim3(1), dim3(256), 0, stream, part, SUMSQ_BLOCKS, out);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -336,7 +422,7 @@ extern "C" int aggf_sym_pack_upper(const double* G, int32_t n, int32_t batch, do
   if (!G || !packed) return fail(AGGF_ERR_ARG, "aggf_sym_pack_upper: NULL pointer");
   if (n <= 0 || batch <= 0 || batch > 65535 || n > 65535) return fail(AGGF_ERR_ARG, "aggf_sym_pack_upper: bad size");
   const int64_t per = (int64_t)n * (n + 1) / 2;
-  hipLaunchKernelGGL(sym_pack_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)batch), dim3(256), 0, stream,
+  AGGF_LAUNCH(sym_pack_kernel, dim3((unsigned)((n + 255) / 256), (unsigned)n, (unsigned)batch), dim3(256), 0, stream,
                      G, n, (int64_t)n * n, packed, per);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
@@ -348,7 +434,7 @@ extern "C" int aggf_sym_unpack_upper(const double* packed, int32_t n, int32_t ba
   if (n <= 0 || batch <= 0 || batch > 65535 || n > 65535 * 32) return fail(AGGF_ERR_ARG, "aggf_sym_unpack_upper: bad size");
   const int64_t per = (int64_t)n * (n + 1) / 2;
   const unsigned nt = (unsigned)((n + 31) / 32);
-  hipLaunchKernelGGL(sym_unpack_kernel, dim3(nt, nt, (unsigned)batch), dim3(256), 0, stream, packed, n, per, G,
+  AGGF_LAUNCH(sym_unpack_kernel, dim3(nt, nt, (unsigned)batch), dim3(256), 0, stream, packed, n, per, G,
                      (int64_t)n * n);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
@@ -359,7 +445,7 @@ extern "C" int aggf_expand_map(const double* X, int32_t n_rows, int32_t n_red,
   hipStream_t stream = (hipStream_t)stream_v;
   if (!X || !group_of_atom || !W) return fail(AGGF_ERR_ARG, "aggf_expand_map: NULL pointer");
   if (n_rows <= 0 || n_red <= 0 || N <= 0) return fail(AGGF_ERR_ARG, "aggf_expand_map: empty problem");
-  hipLaunchKernelGGL(expand_map_kernel, stream_grid((int64_t)n_rows * N), dim3(256), 0, stream, X, n_rows, n_red, group_of_atom, N, W);
+  AGGF_LAUNCH(expand_map_kernel, stream_grid((int64_t)n_rows * N), dim3(256), 0, stream, X, n_rows, n_red, group_of_atom, N, W);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -373,9 +459,9 @@ extern "C" int aggf_synth_normal(void* out, int64_t T, int32_t N, int dtype, uin
   const int64_t quads = T * (int64_t)N * 3 / 4 + 2;
   dim3 grid = stream_grid(quads);
   if (dtype == AGGF_F64)
-    hipLaunchKernelGGL(synth_normal_kernel<double>, grid, dim3(256), 0, stream, (double*)out, T, N, seed, frame_offset, mean, sigma, lattice);
+    AGGF_LAUNCH(synth_normal_kernel<double>, grid, dim3(256), 0, stream, (double*)out, T, N, seed, frame_offset, mean, sigma, lattice);
   else if (dtype == AGGF_F32)
-    hipLaunchKernelGGL(synth_normal_kernel<float>, grid, dim3(256), 0, stream, (float*)out, T, N, seed, frame_offset, mean, sigma, lattice);
+    AGGF_LAUNCH(synth_normal_kernel<float>, grid, dim3(256), 0, stream, (float*)out, T, N, seed, frame_offset, mean, sigma, lattice);
   else
     return fail(AGGF_ERR_ARG, "aggf_synth_normal: bad dtype");
   AGGF_LAUNCH_OK();
@@ -393,9 +479,9 @@ extern "C" int aggf_take_frames(const void* src, int64_t n_src, int64_t row_elem
   const int vec_ok = (((uintptr_t)src | (uintptr_t)out) & 15) == 0 && (row_elems * es) % 16 == 0;
   int64_t g = n < 8192 ? n : 8192;
   if (dtype == AGGF_F64)
-    hipLaunchKernelGGL(take_frames_kernel<double>, dim3((unsigned)g), dim3(256), 0, stream, (const double*)src, n_src, row_elems, idx, n, vec_ok, (double*)out);
+    AGGF_LAUNCH(take_frames_kernel<double>, dim3((unsigned)g), dim3(256), 0, stream, (const double*)src, n_src, row_elems, idx, n, vec_ok, (double*)out);
   else
-    hipLaunchKernelGGL(take_frames_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n_src, row_elems, idx, n, vec_ok, (float*)out);
+    AGGF_LAUNCH(take_frames_kernel<float>, dim3((unsigned)g), dim3(256), 0, stream, (const float*)src, n_src, row_elems, idx, n, vec_ok, (float*)out);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
 }
@@ -409,7 +495,7 @@ extern "C" int aggf_concat_sites(const void* a, int32_t Na, int a_dtype, const v
   const int64_t ra = (int64_t)Na * 3, rb = (int64_t)Nb * 3;
   const dim3 grid = stream_grid(T * (ra + rb)), block(256);
 #define AGGF_CC(TA_, TB_, TO_) \
-  hipLaunchKernelGGL((concat_sites_kernel<TA_, TB_, TO_>), grid, block, 0, stream, (const TA_*)a, ra, (const TB_*)b, rb, T, (TO_*)out)
+  AGGF_LAUNCH((concat_sites_kernel<TA_, TB_, TO_>), grid, block, 0, stream, (const TA_*)a, ra, (const TB_*)b, rb, T, (TO_*)out)
   if (a_dtype == AGGF_F32 && b_dtype == AGGF_F32 && out_dtype == AGGF_F32) AGGF_CC(float, float, float);
   else if (a_dtype == AGGF_F64 && b_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_CC(double, double, double);
   else if (a_dtype == AGGF_F32 && b_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_CC(float, double, double);
@@ -427,9 +513,9 @@ extern "C" int aggf_scale(const void* x, int64_t count, int dtype, double alpha,
   if (count < 0) return fail(AGGF_ERR_ARG, "aggf_scale: negative count");
   if (count == 0) return AGGF_OK;
   if (dtype == AGGF_F64)
-    hipLaunchKernelGGL(scale_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)x, count, alpha, (double*)out);
+    AGGF_LAUNCH(scale_kernel<double>, stream_grid(count), dim3(256), 0, stream, (const double*)x, count, alpha, (double*)out);
   else if (dtype == AGGF_F32)
-    hipLaunchKernelGGL(scale_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)x, count, (float)alpha, (float*)out);
+    AGGF_LAUNCH(scale_kernel<float>, stream_grid(count), dim3(256), 0, stream, (const float*)x, count, (float)alpha, (float*)out);
   else
     return fail(AGGF_ERR_ARG, "aggf_scale: bad dtype");
   AGGF_LAUNCH_OK();

@@ -6,6 +6,7 @@ single all-reduce (RCCL over xGMI through ``torch.distributed`` backend "nccl"; 
 CPU tensors in the unit tests), and every rank then runs the identical, replicated solve
 (K2) -- no broadcast is needed -- and maps its own frames (K3).
 """
+import threading
 from typing import Tuple
 
 import torch
@@ -52,6 +53,7 @@ def all_reduce_sum_(t: torch.Tensor, comm) -> torch.Tensor:
     if dist.get_world_size(group) > 1:
         _run_overlap_hooks()
         with _stage(t):
+            _count(t)
             dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return t
 
@@ -60,24 +62,52 @@ def all_reduce_sum_(t: torch.Tensor, comm) -> torch.Tensor:
 # slice-map gather of the coordinates here (HBM-bound, a side stream), so the Gram all-reduce -- link-bound, the
 # compute units idle -- hides behind it instead of standing alone between K1 and K2.  Each hook runs once, in front of
 # the first multi-rank collective after it was registered.
-_overlap_hooks: list = []
+# (per host thread: a hook registered by one thread's fit must not be consumed by another thread's collective)
+_tls = threading.local()
+
+
+def _hooks() -> list:
+    if not hasattr(_tls, "hooks"):
+        _tls.hooks = []
+    return _tls.hooks
 
 
 def overlap_with_next_collective(thunk) -> None:
-    _overlap_hooks.append(thunk)
+    _hooks().append(thunk)
 
 
 def cancel_overlap(thunk) -> bool:
     """Remove a hook that no collective has consumed; True if it was still waiting."""
-    if thunk in _overlap_hooks:
-        _overlap_hooks.remove(thunk)
+    hooks = _hooks()
+    if thunk in hooks:
+        hooks.remove(thunk)
         return True
     return False
 
 
 def _run_overlap_hooks() -> None:
-    while _overlap_hooks:
-        _overlap_hooks.pop(0)()
+    hooks = _hooks()
+    while hooks:
+        hooks.pop(0)()
+
+
+# payload bytes of the sum all-reduces since reset_collective_stats() (bench.py: bytes on the wire and bus bandwidth of
+# the Gram all-reduce next to its measured time)
+_collective = {"allreduce_bytes": 0, "allreduce_calls": 0}
+
+
+def reset_collective_stats() -> None:
+    _collective["allreduce_bytes"] = 0
+    _collective["allreduce_calls"] = 0
+
+
+def collective_stats() -> dict:
+    return dict(_collective)
+
+
+def _count(t: torch.Tensor) -> None:
+    _collective["allreduce_bytes"] += t.numel() * t.element_size()
+    _collective["allreduce_calls"] += 1
 
 
 def _stage(t: torch.Tensor):
@@ -117,6 +147,7 @@ def all_reduce_sum_sym_(G: torch.Tensor, comm) -> torch.Tensor:
     _run_overlap_hooks()
     with _stage(G):
         packed = K.sym_pack_upper(G)
+        _count(packed)
         dist.all_reduce(packed, op=dist.ReduceOp.SUM, group=group)
         return K.sym_unpack_upper(packed, G)
 

@@ -212,13 +212,35 @@ def profiled_mfma_busy(workload, world):
 
 
 def blas_threads():
+    """BLAS threads the CPU baseline runs on: every logical core of the host is ASKED for (threadpoolctl); the
+    library grants at most the thread count it was built for (NumPy's bundled OpenBLAS: 64), and what it granted is
+    what the line reports."""
     try:
-        from threadpoolctl import threadpool_info
+        from threadpoolctl import threadpool_info, threadpool_limits
 
+        threadpool_limits(limits=os.cpu_count() or 1, user_api="blas")
         n = [i["num_threads"] for i in threadpool_info() if i.get("user_api") == "blas"]
         return max(n) if n else 1
     except Exception:
         return 1
+
+
+def gram_kernel_name(launched, family):
+    """The Gram kernel of the timed steps, named by the library's own launch table (aggf_coverage_dump): the
+    instantiation of `family` with the most launches since the reset -- the string rocprofv3 prints, minus the
+    argument list."""
+    best = max(((cnt, pretty) for pretty, cnt in launched.values() if family in pretty and cnt > 0), default=None)
+    if best is None:
+        return None
+    name = best[1]
+    depth = 0
+    for i, ch in enumerate(name):  # cut the parameter list: the first '(' outside the template brackets
+        depth += ch == "<"
+        depth -= ch == ">"
+        if ch == "(" and depth == 0:
+            name = name[:i]
+            break
+    return name.replace("void ", "").strip()
 
 
 def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores, cmat=None, constraints=None, l2=0.0, zeronet=False,
@@ -253,8 +275,9 @@ def cpu_baseline(N, n_cg, np_dtype, T_total, T_cpu, cores, cmat=None, constraint
         "cores": cores,
         "kind": "port",
         "passes_frames_per_s": values,
-        "sample": (f"{T_cpu} of {T_total} frames x {N} atoms on the host ({os.cpu_count()} logical cores, BLAS threads "
-                   f"= cores field; the einsum apply is single-threaded as in the reference), faster of two passes: "
+        "sample": (f"{T_cpu} of {T_total} frames x {N} atoms on the host ({os.cpu_count()} logical cores; every one was asked "
+                   f"for, BLAS threads granted = cores field -- the thread count NumPy's OpenBLAS is built for; the einsum apply "
+                   f"is single-threaded as in the reference), faster of two passes: "
                    + (f"augment {t_aug:.2f}s, " if noised is not None else "")
                    + f"gram {gram_s:.2f}s (n_red {n_red_cpu}), "
                    f"solve {solve_s:.2f}s (exact direct solve instead of {n_cg} OSQP runs), "
@@ -449,6 +472,11 @@ def main():
         out = None
         out = step()
     barrier()
+    from aggforce_amd import _lib
+    from aggforce_amd import distributed as D
+
+    _lib.load().aggf_coverage_reset()   # the launch table then names the kernels of the timed steps only
+    D.reset_collective_stats()
     K.start_timers()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -457,6 +485,8 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t0
     stages = K.stop_timers()
+    launched = _lib.coverage(names=True)  # mangled -> (name as rocprofv3 prints it, launches in the timed region)
+    coll = D.collective_stats()
     if comm is not None:
         import torch.distributed as dist
 
@@ -514,7 +544,7 @@ def main():
             # HBM-bound: algorithmic bytes of the Gram pass = one read of the forces (3 N s per frame)
             algo_bytes = 3.0 * N * s_bytes * T_local
             achieved = algo_bytes / (gram_ms * 1e-3) / 1e9
-            roof = {"kernel": "aggf_gram = gram_small_kernel<double, double, 5, 8, 8> (fused group sums, one pass over F) + gram_reduce_small_kernel",
+            roof = {"kernel": f"aggf_gram = {gram_kernel_name(launched, 'gram_small_kernel')} (fused group sums, one pass over F) + gram_reduce_small_kernel",
                     "bound": "hbm", "co_limited_by": "hbm+mfma+lds: per frame and CU 403 cycles of HBM, 336 of MFMA (28 upper-triangle "
                     "16x16 blocks), ~230 of LDS; ablations in profiles/r04_small_ablate.jsonl (no MFMA phase 2.86 ms, no loads "
                     "4.05, no group sums 3.73, complete 4.79)",
@@ -523,12 +553,13 @@ def main():
                     "flops_per_launch": flops, "mfma_tflops": flops / (gram_ms * 1e-3) / 1e12}
         else:
             achieved = flops / (gram_ms * 1e-3) / 1e12
-            # the full template name, as rocprofv3 prints it: <T, ABL, NBUF, WPS, NW, SPREAD_DMA, ES, ES_DMA_AFTER, TWO>
-            kname = "gram_tile_dma_kernel<%s, 0, 3, 2, 8, true, 1, true, %s> (+ gram_reduce_kernel) = %s" % (
-                "double" if gdt == "f64" else "float", "true" if args.workload == "c5" else "false",
+            # the full template name as rocprofv3 prints it, read from the library's launch table of the timed steps
+            kname = "%s (+ gram_reduce_kernel) = %s" % (
+                gram_kernel_name(launched, "gram_tile_dma_kernel") or gram_kernel_name(launched, "gram_small_kernel"),
                 "aggf_gram_pair" if args.workload == "c5" else "aggf_gram")
-            if args.variant == "pairs":
-                kname = "pack_groups_kernel (constraint-group sums) + " + kname
+            packer = gram_kernel_name(launched, "pack_groups_kernel")
+            if packer:  # constraint-group sums / conversion / padding in front of the tile kernel
+                kname = packer + " + " + kname
             roof = {"kernel": kname, "bound": "mfma", "achieved": achieved, "peak": PEAK_TFLOPS[gdt], "unit": "TFLOP/s",
                     "frac": achieved / PEAK_TFLOPS[gdt], "traffic": profiled_traffic(args.workload, world),
                     "traffic_source": profile_label() if profiled_traffic(args.workload, world) is not None else None,
@@ -563,6 +594,13 @@ def main():
                 # number of GPUs (gram, apply, gather, ...), what does not (the replicated solve + the host time between
                 # the stages: wall minus every stage of the main stream) and the collective (pack + all-reduce + unpack)
                 "allreduce_ms_per_step": per_step.get("allreduce", 0.0 if comm is None else None),
+                # payload of the sum all-reduces per step (the packed upper triangle of G + scalars) and the ring's bus
+                # bandwidth 2 (N - 1) / N x bytes / time, to read against xGMI's ~153 GB/s per link
+                "allreduce_bytes_per_step": coll["allreduce_bytes"] / args.steps,
+                "allreduce_calls_per_step": coll["allreduce_calls"] / args.steps,
+                "allreduce_bus_GBps": (2.0 * (world - 1) / world * coll["allreduce_bytes"] / args.steps
+                                       / (per_step["allreduce"] * 1e-3) / 1e9
+                                       if world > 1 and per_step.get("allreduce") else None),
                 "replicated_ms_per_step": per_step.get("solve", 0.0) + max(0.0, 1e3 * elapsed / args.steps - sum(
                     v for k, v in per_step.items() if k != "gather")),
                 "constraint_residual": cons_resid,

@@ -45,6 +45,14 @@ extern "C" {
 
 int aggf_version(void);
 const char* aggf_last_error(void);
+/* Launch coverage (no reference counterpart: test infrastructure of the dispatch tables).  Every kernel launch of the
+ * library is counted under its template instantiation.  aggf_coverage_dump writes "mangled kernel name <tab> demangled name
+ * <tab> launches <newline>" for every kernel this process has launched (counts since the last reset; kernels launched before a reset
+ * stay listed with count 0) into buf, NUL-terminated, and returns the bytes the full text needs (call with buf_bytes = 0
+ * to size the buffer).  A process with AGGF_COVERAGE_FILE set appends the same lines with "label <tab>" in front to that
+ * file when the library is unloaded (label = AGGF_COVERAGE_LABEL): tests/test_gpu_zz_coverage.py. */
+size_t aggf_coverage_dump(char* buf, size_t buf_bytes);
+int aggf_coverage_reset(void);
 /* number of compute units of the current device; free/total HBM bytes */
 int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes);
 

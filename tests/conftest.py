@@ -10,8 +10,53 @@ if ROOT not in sys.path:
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 
+# ---- launch coverage of the dispatch tables (tests/test_gpu_zz_coverage.py) ------------------------------------
+# kernel (mangled handle name) -> node ids of the tests during which this process, or a child process it started,
+# launched it.  The library counts every launch under its template instantiation (aggf_coverage_dump); the hooks below
+# attribute the launches to the test that was running.
+COVERAGE = {"by_kernel": {}, "last": {}, "children_file": None, "gpu_items_run": 0, "gpu_items_collected": 0}
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    import tempfile
+
+    COVERAGE["children_file"] = os.path.join(tempfile.mkdtemp(prefix="aggf_cov_"), "children.tsv")
+    os.environ["AGGF_COVERAGE_FILE"] = COVERAGE["children_file"]
+
+
+def pytest_unconfigure(config):
+    # (this process's own launches are read in-process; it must not append itself to the children's file at exit)
+    os.environ.pop("AGGF_COVERAGE_FILE", None)
+    os.environ.pop("AGGF_COVERAGE_LABEL", None)
+
+
+def pytest_collection_modifyitems(config, items):
+    # the coverage test judges the whole session: it runs last
+    last = [it for it in items if "test_gpu_zz_coverage" in it.nodeid]
+    rest = [it for it in items if "test_gpu_zz_coverage" not in it.nodeid]
+    items[:] = rest + last
+    COVERAGE["gpu_items_collected"] = sum(1 for it in rest if it.get_closest_marker("gpu"))
+
+
+def pytest_runtest_setup(item):
+    os.environ["AGGF_COVERAGE_LABEL"] = item.nodeid
+
+
+def pytest_runtest_teardown(item):
+    if not item.get_closest_marker("gpu") or "test_gpu_zz_coverage" in item.nodeid:
+        return
+    COVERAGE["gpu_items_run"] += 1
+    try:
+        from aggforce_amd import _lib
+
+        now = _lib.coverage()
+    except Exception:  # library not built: the tests themselves say so
+        return
+    for name, cnt in now.items():
+        if cnt > COVERAGE["last"].get(name, 0):
+            COVERAGE["by_kernel"].setdefault(name, set()).add(item.nodeid)
+    COVERAGE["last"] = now
 
 
 @pytest.fixture(scope="session")

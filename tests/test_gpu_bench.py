@@ -63,7 +63,10 @@ def test_bench_variants_of_the_linear_workload(variant):
     assert line["roofline"]["frac"] > 0 and line["roofline"]["traffic"] is None
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["value"] > 0
     if variant == "pairs":
-        assert "n_red 171" in line["cpu_baseline"]["sample"] and "pack_groups_kernel" in line["roofline"]["kernel"]
+        # 171 reduced columns: the streaming kernel sums the groups on the way through LDS -- no pack pass, and the label
+        # (read from the launch table) says so
+        assert "n_red 171" in line["cpu_baseline"]["sample"]
+        assert "gram_small_kernel<" in line["roofline"]["kernel"] and "pack_groups_kernel" not in line["roofline"]["kernel"]
 
 
 def test_bench_under_torchrun_one_rank_uses_rccl():
@@ -90,3 +93,34 @@ def test_bench_under_torchrun_one_rank_uses_rccl():
     assert line["n_gpus"] == 1 and cfg["backend"] == "nccl (RCCL)" and cfg["world_size_seen"] == 1
     assert "RCCL all-reduce" in cfg["collective"] and cfg["replicated_solve_max_abs_diff_across_ranks"] == 0.0
     assert cfg["constraint_residual"] < 1e-8 and line["value"] > 0
+
+
+def test_bench_kernel_label_is_the_string_rocprofv3_prints(tmp_path):
+    """`roofline.kernel` is read from the library's own launch table (aggf_coverage_dump), not typed into bench.py: under
+    rocprofv3's kernel trace of the same command the label must be the name of a kernel the profiler saw, template
+    arguments included (round 4's hand-written label was one template argument short)."""
+    import glob
+    import shutil
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        pytest.skip("rocprofv3 not installed")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env["TMPDIR"] = str(tmp_path)
+    for workload, family in (("tiny", "gram_small_kernel"), ("c2", "gram_tile_dma_kernel")):
+        out_dir = tmp_path / workload
+        proc = subprocess.run([rocprof, "--kernel-trace", "--stats", "-d", str(out_dir), "--", sys.executable,
+                               os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
+                               "--no-cpu-baseline"] + (["--frames", "20000"] if workload == "c2" else []),
+                              stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=str(tmp_path))
+        assert proc.returncode == 0, proc.stderr.decode(errors="replace")[-3000:]
+        lines = [ln for ln in proc.stdout.decode().splitlines() if ln.strip().startswith('{"metric"')]
+        assert len(lines) == 1, proc.stdout.decode()[-2000:]
+        label = json.loads(lines[0])["roofline"]["kernel"]
+        name = label.split(" = ")[-1] if label.startswith("aggf_gram = ") else label
+        name = name.split(" (")[0].strip()
+        assert family in name, label
+        stats = glob.glob(str(out_dir / "**" / "*kernel_stats.csv"), recursive=True)
+        assert stats, "rocprofv3 wrote no kernel_stats.csv"
+        seen = [row.split('","')[0].strip('"') for f in stats for row in open(f).read().splitlines()[1:]]
+        assert any(s.startswith("void " + name + "(") for s in seen), (name, [s for s in seen if family in s])

@@ -467,3 +467,24 @@ def test_host_sanitizer_build_of_the_c_abi():
     tail = (run.stdout + run.stderr)[-3000:]
     assert run.returncode == 0, tail
     assert "0 unexpected statuses" in run.stdout and "ERROR: AddressSanitizer" not in tail and "runtime error" not in tail
+
+
+def test_no_test_module_defines_a_name_twice():
+    """A second `def test_x` in one module rebinds the name and pytest silently collects only the last one (round 4:
+    the stage-size cases of the few-sites apply never ran).  Every top-level function / class name of every test
+    module, and every method name inside a test class, must be unique."""
+    import ast
+    import glob
+
+    dups = []
+    for path in sorted(glob.glob(os.path.join(ROOT, "tests", "*.py"))):
+        tree = ast.parse(open(path).read(), path)
+        scopes = [("", tree.body)] + [(n.name + ".", n.body) for n in tree.body if isinstance(n, ast.ClassDef)]
+        for prefix, body in scopes:
+            seen = {}
+            for node in body:
+                if isinstance(node, (ast.FunctionDef, ast.AsyncFunctionDef, ast.ClassDef)):
+                    if node.name in seen:
+                        dups.append(f"{os.path.basename(path)}: {prefix}{node.name} at lines {seen[node.name]} and {node.lineno}")
+                    seen[node.name] = node.lineno
+    assert not dups, "duplicate definitions shadow tests:\n" + "\n".join(dups)
