@@ -663,16 +663,25 @@ def sym_group_reduce(G: torch.Tensor, grp_ptr: torch.Tensor, grp_atoms: torch.Te
 
 def take_frames(x: torch.Tensor, idx) -> torch.Tensor:
     """x[idx] along the frame axis as one gather kernel (aggf_take_frames); ``idx``: integer array-like or tensor."""
-    if not isinstance(idx, torch.Tensor):
-        idx = torch.from_numpy(np.ascontiguousarray(np.asarray(idx, dtype=np.int64)))
-    idx = idx.to(device=x.device, dtype=torch.int64).contiguous()
-    n = idx.numel()
     x = x.contiguous()
     n_src = x.shape[0]
-    if n and (int(idx.min()) < -n_src or int(idx.max()) >= n_src):
-        raise IndexError(f"frame index out of range for {n_src} frames")
-    if n and int(idx.min()) < 0:
-        idx = torch.where(idx < 0, idx + n_src, idx)
+    if not isinstance(idx, torch.Tensor) or not idx.is_cuda:
+        # host index array (the fold bookkeeping of the cross-validation): validated and wrapped on the host, where it
+        # lies -- no device min / max, no synchronisation inside the fold loops
+        host = np.asarray(idx.numpy() if isinstance(idx, torch.Tensor) else idx, dtype=np.int64).reshape(-1)
+        if host.size and (host.min() < -n_src or host.max() >= n_src):
+            raise IndexError(f"frame index out of range for {n_src} frames")
+        if host.size and host.min() < 0:
+            host = np.where(host < 0, host + n_src, host)
+        idx = torch.from_numpy(np.ascontiguousarray(host)).to(x.device)
+    else:
+        idx = idx.to(dtype=torch.int64).contiguous()
+        lo, hi = (int(v) for v in torch.stack([idx.min(), idx.max()]).tolist()) if idx.numel() else (0, 0)  # one sync
+        if idx.numel() and (lo < -n_src or hi >= n_src):
+            raise IndexError(f"frame index out of range for {n_src} frames")
+        if idx.numel() and lo < 0:
+            idx = torch.where(idx < 0, idx + n_src, idx)
+    n = idx.numel()
     out = torch.empty((n,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
     if n and n_src:
         row = int(np.prod(x.shape[1:])) if x.dim() > 1 else 1

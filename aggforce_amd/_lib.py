@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libaggf.so")
+# AGGF_LIB_PATH: tests only -- the adversarial-dispatch-order build of the same sources (tests/test_gpu_order.py)
+LIB_PATH = os.environ.get("AGGF_LIB_PATH") or os.path.join(_HERE, "libaggf.so")
 
 F32, F64 = 0, 1
 NAN_PROPAGATE, NAN_REPLACE = 0, 1

@@ -40,6 +40,83 @@ void cover_hit(const void* kernel_handle);
     hipLaunchKernelGGL(kernel, __VA_ARGS__);                       \
   } while (0)
 
+// ---- adversarial dispatch order (TEST-ONLY build: `make order` -> build_order/libaggf_order.so, compiled with
+// -DAGGF_ORDER_TEST; the shipped library contains none of this).  Launches that read and write one buffer from several
+// workgroups (K2's step / panel / trailing / back-substitution products, the slab sums with `accumulate`, the triangle
+// unpack, the pinned scatter: DESIGN.md section 5b lists them) are made through AGGF_LAUNCH_GATED; in the test build
+// their workgroups then run STRICTLY ONE AFTER THE OTHER, in ascending (AGGF_ORDER=forward) or descending
+// (AGGF_ORDER=reverse) block order: a result that depends on which workgroup runs first differs between the two
+// orders and from the oracle -- deterministically, in one run, instead of once in a thousand.  A workgroup waits for
+// its turn on a device counter (bounded spin: a grid larger than `limit` -- what is surely resident at once -- is
+// not gated, a spin that runs out is counted and reported), the launch is followed by a synchronise + read-back of
+// the time-outs.  aggf_order_note() (aggf_util.hip) keeps the process totals and prints them when the library unloads.
+#ifdef AGGF_ORDER_TEST
+struct OrderGate {
+  unsigned int done, mode, timeouts, pad;
+};
+void order_note(int gated, int timeouts, const char* kernel);
+int order_mode();  // 0 off, 1 forward, 2 reverse (AGGF_ORDER)
+static __device__ OrderGate g_order_gate;  // one per translation unit (no relocatable device code)
+static __global__ void order_arm_kernel(unsigned int mode) {
+  g_order_gate.done = 0;
+  g_order_gate.mode = mode;
+  g_order_gate.timeouts = 0;
+}
+__device__ __forceinline__ void order_enter() {
+  const unsigned mode = g_order_gate.mode;
+  if (mode == 0) return;
+  const unsigned nb = gridDim.x * gridDim.y * gridDim.z;
+  const unsigned lin = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+  const unsigned turn = mode == 1 ? lin : nb - 1 - lin;
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    unsigned spins = 0;
+    while (__hip_atomic_load(&g_order_gate.done, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != turn) {
+      __builtin_amdgcn_s_sleep(8);
+      if (++spins > (1u << 20)) {  // ~0.25 s: never hang the GPU
+        atomicAdd(&g_order_gate.timeouts, 1u);
+        break;
+      }
+    }
+  }
+  __syncthreads();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void order_exit() {
+  if (g_order_gate.mode == 0) return;
+  __syncthreads();
+  if (threadIdx.x == 0 && threadIdx.y == 0 && threadIdx.z == 0) {
+    __threadfence();
+    atomicAdd(&g_order_gate.done, 1u);
+  }
+}
+static inline void order_arm(hipStream_t stream, dim3 grid, unsigned limit) {
+  const uint64_t nb = (uint64_t)grid.x * grid.y * grid.z;
+  const unsigned mode = nb <= limit ? (unsigned)order_mode() : 0u;
+  hipLaunchKernelGGL(order_arm_kernel, dim3(1), dim3(1), 0, stream, mode);
+}
+static inline void order_collect(hipStream_t stream, dim3 grid, unsigned limit, const char* kernel) {
+  const uint64_t nb = (uint64_t)grid.x * grid.y * grid.z;
+  OrderGate g = {0, 0, 0, 0};
+  if (order_mode() == 0) return;
+  if (hipStreamSynchronize(stream) == hipSuccess) (void)hipMemcpyFromSymbol(&g, HIP_SYMBOL(g_order_gate), sizeof(g));
+  order_note(nb <= limit ? 1 : 0, (int)g.timeouts, kernel);
+}
+// the kernel's body between the two macros runs as a lambda so that its early `return`s still reach the exit
+#define AGGF_GATED_BODY_BEGIN ::aggf::order_enter(); [&]() {
+#define AGGF_GATED_BODY_END }(); ::aggf::order_exit();
+#define AGGF_LAUNCH_GATED(limit, kernel, grid, block, lds, stream, ...)      \
+  do {                                                                       \
+    const dim3 og_ = (grid);                                                 \
+    ::aggf::order_arm(stream, og_, (limit));                                 \
+    AGGF_LAUNCH(kernel, og_, block, lds, stream, __VA_ARGS__);               \
+    ::aggf::order_collect(stream, og_, (limit), #kernel);                    \
+  } while (0)
+#else
+#define AGGF_GATED_BODY_BEGIN
+#define AGGF_GATED_BODY_END
+#define AGGF_LAUNCH_GATED(limit, kernel, ...) AGGF_LAUNCH(kernel, __VA_ARGS__)
+#endif
+
 static inline int64_t round_up(int64_t x, int64_t m) { return (x + m - 1) / m * m; }
 static inline int64_t ceil_div(int64_t x, int64_t m) { return (x + m - 1) / m; }
 int device_cu_count();

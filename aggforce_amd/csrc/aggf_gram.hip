@@ -558,6 +558,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
                                                           int32_t nt1, int32_t ksplit,
                                                           int32_t n_red, int accumulate,
                                                           double* __restrict__ G, int32_t first_tile = 0) {
+  AGGF_GATED_BODY_BEGIN
   int tile = blockIdx.x;
   const int tile_lin = tile;
   int ti = 0;
@@ -592,6 +593,7 @@ __global__ __launch_bounds__(256) void gram_reduce_kernel(const T* __restrict__ 
       }
     }
   }
+  AGGF_GATED_BODY_END
 }
 
 // ---------------------------------------------------------------------------
@@ -887,6 +889,7 @@ __global__ __launch_bounds__(2 * WT > 1024 ? 1024 : 2 * WT) void gram_reduce_sma
                                                                                       double* __restrict__ G, int32_t parts) {
   constexpr int HALVES = 2 * WT > 1024 ? 1 : 2;
   __shared__ double part_sum[HALVES][WT];
+  AGGF_GATED_BODY_BEGIN
   const int row = blockIdx.x, col = threadIdx.x & (WT - 1), half = threadIdx.x / WT;
   // the slab that holds entry (row, col): the workgroup whose share of the block list contains block (row / 16, col / 16)
   int owner = 0;
@@ -909,6 +912,7 @@ __global__ __launch_bounds__(2 * WT > 1024 ? 1024 : 2 * WT) void gram_reduce_sma
       *q = accumulate ? *q + tot : tot;
     }
   }
+  AGGF_GATED_BODY_END
 }
 
 // ---------------------------------------------------------------------------
@@ -1121,7 +1125,7 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
                      dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs,
                      (const T*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0));
   AGGF_LAUNCH_OK();
-  AGGF_LAUNCH((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
+  AGGF_LAUNCH_GATED(1024, (gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                      slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
   AGGF_LAUNCH_OK();
   return AGGF_OK;
@@ -1241,13 +1245,13 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
 #undef AGGF_SMALL
     AGGF_LAUNCH_OK();
     if (width == 4 * TILE)
-      AGGF_LAUNCH((gram_reduce_small_kernel<TC, 4 * TILE>), dim3(4 * TILE), dim3(1024), 0, stream, slabs, p.ksplit,
+      AGGF_LAUNCH_GATED(256, (gram_reduce_small_kernel<TC, 4 * TILE>), dim3(4 * TILE), dim3(1024), 0, stream, slabs, p.ksplit,
                          n_red, accumulate, G, p.parts);
     else if (width > TILE)
-      AGGF_LAUNCH((gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
+      AGGF_LAUNCH_GATED(256, (gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
                          n_red, accumulate, G, 1);
     else
-      AGGF_LAUNCH((gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
+      AGGF_LAUNCH_GATED(256, (gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
                          accumulate, G, 1);
     AGGF_LAUNCH_OK();
     return AGGF_OK;
@@ -1432,7 +1436,7 @@ static int gram_pair_typed(const T* F, const T* F2, int64_t rows, int32_t N, int
                      dim3(512), lds3, stream, F, rows, (int64_t)N * 3, p.nt1, p.n_tiles, ksplit, tile_table, fps, slabs, F2,
                      (int64_t)N2 * 3, N / TILE);
   AGGF_LAUNCH_OK();
-  AGGF_LAUNCH((gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit,
+  AGGF_LAUNCH_GATED(1024, (gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream, slabs, p.nt1, ksplit,
                      N + N2, accumulate, G, 0);
   AGGF_LAUNCH_OK();
   return AGGF_OK;

@@ -49,6 +49,7 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), 2) void gemm_tile_kerne
                                                                                  const double* B, int64_t ldb,
                                                                                  double beta, double* C, int64_t ldc,
                                                                                  int lower_only, GemmBatch bt) {
+  AGGF_GATED_BODY_BEGIN
   using MF = Mfma<double>;
   typedef double __attribute__((ext_vector_type(2))) d2;
   constexpr int NWN = TN / WN, NW = (TM / WM) * NWN, THREADS = 64 * NW;
@@ -183,6 +184,7 @@ __global__ __launch_bounds__(64 * (TM / WM) * (TN / WN), 2) void gemm_tile_kerne
         if (beta != 0.0) v += beta * C[row * ldc + col];
         C[row * ldc + col] = v;
       }
+  AGGF_GATED_BODY_END
 }
 
 // Factor one 64x64 diagonal block: A_kk = L L' (lower), and Linv = L^-1.
@@ -469,6 +471,7 @@ constexpr int STEP_LDS = 4 * NB * (NB + 1) * (int)sizeof(double);
 __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, int64_t ld, int k, int j, int nrb,
                                                        double* __restrict__ Linv, double* __restrict__ info,
                                                        int pivot_base, int64_t p_ps, int64_t linv_ps, int64_t info_ps) {
+  AGGF_GATED_BODY_BEGIN
   using MF = Mfma<double>;
   extern __shared__ __attribute__((aligned(16))) char step_smem[];
   double (*a)[NB + 1] = reinterpret_cast<double (*)[NB + 1]>(step_smem);            // diagonal block, then its factor
@@ -577,6 +580,7 @@ __global__ __launch_bounds__(256) void chol_step_kernel(double* __restrict__ P, 
 #pragma unroll
       for (int r = 0; r < 4; ++r) P[(r0 + wave * 16 + MF::row(lane, r)) * ld + kr + t * 16 + li] = out[t][r];
   }
+  AGGF_GATED_BODY_END
 }
 
 // Helper kernels of the solve.  blockIdx.y = problem of a batched solve; every array argument comes
@@ -773,6 +777,13 @@ template <bool TA, bool TB>
 static void gemm(Ctx& c, int M, int N, int K, double alpha, Mat A, Mat B, double beta, Mat C, int lower_only = 0,
                  int nbatch = 1, GemmBatch bt = GemmBatch{1, 0, 0, 0, 0, 0, 0}) {
   if (c.rc || M <= 0 || N <= 0 || nbatch <= 0) return;
+  // In place (C == A): sound only while a workgroup reads exactly the rows it writes -- A not transposed and ONE column
+  // tile (N <= 64 keeps the 64 x 64 shape: 128-wide tiles are chosen for N >= 128 only), the panel products of the
+  // three-launch factorisation.  C == B never is.
+  if ((C.p == A.p && (TA || N > NB)) || C.p == B.p) {
+    c.rc = fail(AGGF_ERR_ARG, "gemm: in-place product with more than one column tile (workgroups would read what others write)");
+    return;
+  }
   bt.per_prob = nbatch;
   bt.a_p = A.ps;
   bt.b_p = B.ps;
@@ -796,12 +807,12 @@ static void gemm(Ctx& c, int M, int N, int K, double alpha, Mat A, Mat B, double
         c.rc = fail(AGGF_ERR_HIP, "gemm LDS attribute failed");
       done = true;
     }
-    AGGF_LAUNCH((gemm_tile_kernel<TA, TB, 128, 128, 64, 32>),
+    AGGF_LAUNCH_GATED(384, (gemm_tile_kernel<TA, TB, 128, 128, 64, 32>),
                        dim3((unsigned)ceil_div(N, 128), (unsigned)ceil_div(M, 128), (unsigned)gz), dim3(512), lds, c.stream, M,
                        N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, lower_only, bt);
   } else {
     constexpr size_t lds = (size_t)2 * (64 + 64) * GS * sizeof(double);
-    AGGF_LAUNCH((gemm_tile_kernel<TA, TB, 64, 64, 32, 32>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), lds,
+    AGGF_LAUNCH_GATED(512, (gemm_tile_kernel<TA, TB, 64, 64, 32, 32>), dim3(N / 64, M / 64, (unsigned)gz), dim3(256), lds,
                        c.stream, M, N, K, alpha, A.p, A.ld, B.p, B.ld, beta, C.p, C.ld, lower_only, bt);
   }
   if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "gemm launch failed");
@@ -907,7 +918,7 @@ static void cholesky(Ctx& c, Mat P, int npad, Mat Dinv, double* info, int pivot_
       if (one_launch) {
         const int nrb = rem / NB;
         const int gx = nrb < 1 ? 1 : (nrb < gx_max ? nrb : gx_max);
-        AGGF_LAUNCH(chol_step_kernel, dim3((unsigned)gx, (unsigned)c.nprob), dim3(256), STEP_LDS, c.stream, P.p,
+        AGGF_LAUNCH_GATED(256, chol_step_kernel, dim3((unsigned)gx, (unsigned)c.nprob), dim3(256), STEP_LDS, c.stream, P.p,
                            P.ld, k, k - k0, nrb, Dk.p, info, pivot_base + k * NB, P.ps, Dinv.ps, (int64_t)4);
         if (hipGetLastError() != hipSuccess) c.rc = fail(AGGF_ERR_HIP, "chol_step launch failed");
         continue;
@@ -1215,6 +1226,7 @@ __global__ __launch_bounds__(256) void pinned_scatter_kernel(const double* __res
                                                              const int32_t* __restrict__ free_idx, int nf,
                                                              const int32_t* __restrict__ pin, int m, int n,
                                                              double* __restrict__ X, const double* __restrict__ stats) {
+  AGGF_GATED_BODY_BEGIN
   const int64_t total = (int64_t)m * n;
   if (stats[0] < 0.0) {  // bad pins: no scatter through them; X = 0
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) X[e] = 0.0;
@@ -1225,6 +1237,7 @@ __global__ __launch_bounds__(256) void pinned_scatter_kernel(const double* __res
     if (k < nf) X[(int64_t)c * n + free_idx[k]] = Xt[(int64_t)k * rpad + c];
     else X[(int64_t)c * n + pin[k - nf]] = (k - nf == c) ? 1.0 : 0.0;
   }
+  AGGF_GATED_BODY_END
 }
 
 }  // namespace aggf
@@ -1404,7 +1417,7 @@ extern "C" int aggf_eq_qp_solve_pinned(const double* G, int32_t n, double l2, co
                      (int64_t)0, 1, Z.p, npad, rpad, (int64_t)0);
   AGGF_LAUNCH_OK();
   solve_lower_t(c, Pt, npad, Dinv, Z, Xt, rpad);
-  AGGF_LAUNCH(pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
+  AGGF_LAUNCH_GATED(1024, pinned_scatter_kernel, flat_grid((int64_t)m * n), dim3(256), 0, st, Xt.p, rpad, free_idx, nf, pin_idx, m,
                      n, X, stats);
   AGGF_LAUNCH_OK();
   return c.rc;

@@ -34,6 +34,32 @@ void cover_hit(const void* h) {
   }
 }
 
+#ifdef AGGF_ORDER_TEST
+// process totals of the adversarial-order test build (aggf_common.h), printed when the library unloads
+static std::atomic<int> g_order_gated{0}, g_order_ungated{0}, g_order_timeouts{0};
+int order_mode() {
+  const char* e = getenv("AGGF_ORDER");  // read per launch: a test may switch between the orders
+  if (!e) return 0;
+  return e[0] == 'f' ? 1 : e[0] == 'r' ? 2 : 0;
+}
+void order_note(int gated, int timeouts, const char* kernel) {
+  (gated ? g_order_gated : g_order_ungated).fetch_add(1);
+  if (timeouts > 0) {
+    g_order_timeouts.fetch_add(timeouts);
+    fprintf(stderr, "AGGF_ORDER: %d workgroup(s) of %s gave up waiting for their turn\n", timeouts, kernel);
+  }
+}
+namespace {
+struct OrderAtExit {
+  ~OrderAtExit() {
+    fprintf(stderr, "AGGF_ORDER_SUMMARY mode=%d gated=%d ungated=%d timeouts=%d\n", order_mode(), g_order_gated.load(),
+            g_order_ungated.load(), g_order_timeouts.load());
+  }
+};
+static OrderAtExit g_order_at_exit;
+}  // namespace
+#endif
+
 // "mangled name<tab>demangled name<tab>count<newline>" per executed kernel into buf (always NUL-terminated when
 // n > 0), with `label<tab>` in front of every line if given; returns the bytes the full text needs (without the NUL)
 static size_t cover_dump(char* buf, size_t n, const char* label) {
@@ -270,7 +296,10 @@ __global__ __launch_bounds__(256) void take_frames_kernel(const T* __restrict__ 
   typedef T __attribute__((ext_vector_type(V))) vec_t;
   for (int64_t i = blockIdx.x; i < n; i += gridDim.x) {
     const int64_t r = idx[i];
-    if (r < 0 || r >= n_src) continue;  // (the host checks the range; never read outside the array)
+    if (r < 0 || r >= n_src) {  // (the host checks the range; a bypassed check shows as NaN rows, never as a read outside the array)
+      for (int64_t e = threadIdx.x; e < row_elems; e += blockDim.x) out[i * row_elems + e] = (T)NAN;
+      continue;
+    }
     const T* s = src + r * row_elems;
     T* o = out + i * row_elems;
     if (vec_ok) {
@@ -394,6 +423,7 @@ __global__ __launch_bounds__(256) void sym_pack_kernel(const double* __restrict_
 __global__ __launch_bounds__(256) void sym_unpack_kernel(const double* __restrict__ packed, int32_t n, int64_t p_ps,
                                                          double* __restrict__ G, int64_t g_ps) {
   __shared__ double tile[32][33];
+  AGGF_GATED_BODY_BEGIN
   const int ti = blockIdx.y, tj = blockIdx.x;
   if (tj < ti) return;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -415,6 +445,7 @@ __global__ __launch_bounds__(256) void sym_unpack_kernel(const double* __restric
     const int64_t i = (int64_t)tj * 32 + r, j = (int64_t)ti * 32 + tx;  // element (i, j) of the mirrored tile
     if (i < n && j < n) Gb[i * n + j] = tile[tx][r];
   }
+  AGGF_GATED_BODY_END
 }
 
 extern "C" int aggf_sym_pack_upper(const double* G, int32_t n, int32_t batch, double* packed, void* stream_v) {
@@ -434,7 +465,7 @@ extern "C" int aggf_sym_unpack_upper(const double* packed, int32_t n, int32_t ba
   if (n <= 0 || batch <= 0 || batch > 65535 || n > 65535 * 32) return fail(AGGF_ERR_ARG, "aggf_sym_unpack_upper: bad size");
   const int64_t per = (int64_t)n * (n + 1) / 2;
   const unsigned nt = (unsigned)((n + 31) / 32);
-  AGGF_LAUNCH(sym_unpack_kernel, dim3(nt, nt, (unsigned)batch), dim3(256), 0, stream, packed, n, per, G,
+  AGGF_LAUNCH_GATED(1024, sym_unpack_kernel, dim3(nt, nt, (unsigned)batch), dim3(256), 0, stream, packed, n, per, G,
                      (int64_t)n * n);
   AGGF_LAUNCH_OK();
   return AGGF_OK;

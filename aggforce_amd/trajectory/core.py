@@ -47,20 +47,25 @@ def _concat_sites(parts):
 
 
 def _augment_concat(coords, forces, aug_coords, real_corr, aug_lgrad, kbt):
-    """([x ; y], [F + kbt d/dx ; kbt d/dy]) of the general Augmenter protocol (reference trajectory/core.py:384-390) in
-    one pass (``aggf_augment_concat``: the two scaled sums ride along with the concatenating copy)."""
+    """([x ; y], [F + kbt d/dx ; kbt d/dy]) of the general Augmenter protocol (reference trajectory/core.py:384-390).
+    Dtypes follow NumPy's promotion as in the reference: coordinates come out in promote(x, y), forces in
+    promote(F, d/dx, d/dy) -- float64 forces stay float64 beside float32 coordinates.  When the coordinates and forces
+    share a dtype (every configuration of BASELINE.json) both arrays leave ONE pass (``aggf_augment_concat``: the two
+    scaled sums ride along with the concatenating copy); otherwise the coordinates are concatenated by
+    ``aggf_concat_sites`` and the forces by a second call of the fused kernel on the forces alone."""
+    import torch
+
     from .. import _kernels as K
 
-    c = K.as_device(coords)
-    f = K.as_device(forces, c.dtype)
-    y = K.as_device(aug_coords)
-    adt = y.dtype
-    for other in (real_corr, aug_lgrad):
-        if K.as_device(other).dtype != adt:
-            import torch
-
-            adt = torch.float64
-    oc, of = K.augment_concat(c, f, K.as_device(y, adt), K.as_device(real_corr, adt), K.as_device(aug_lgrad, adt), kbt)
+    c, f, y = K.as_device(coords), K.as_device(forces), K.as_device(aug_coords)
+    corr, lg = K.as_device(real_corr), K.as_device(aug_lgrad)
+    gdt = torch.promote_types(corr.dtype, lg.dtype)
+    if c.dtype == f.dtype and y.dtype == gdt:
+        oc, of = K.augment_concat(c, f, y, corr.to(gdt), lg.to(gdt), kbt)
+    else:
+        oc = K.concat_sites(c, y)
+        # (the kernel's coordinate half is given the forces and the gradient: its first output is dropped)
+        _, of = K.augment_concat(f, f, lg.to(gdt), corr.to(gdt), lg.to(gdt), kbt)
     return K.like_input(oc, coords), K.like_input(of, coords)
 
 

@@ -313,13 +313,21 @@ class CondNormal(Augmenter):
     def augment_trajectory(self, coords, forces, kbt: float) -> Tuple:
         """Fused K5 pass: returns ([x; y], [F + kbt M' r; -kbt r]) with r = cov^-1 (y - M x)."""
         c, M, mean = self._device_mean(coords)
-        f = K.as_device(forces, c.dtype)
+        f = K.as_device(forces)
         noise = self._next_noise(c.device)
-        if self._cov_matrix is not None:
-            y = self._full_sample(mean, noise)
+        if self._cov_matrix is not None or f.dtype != c.dtype:
+            # full covariance, or forces wider / narrower than the coordinates (NumPy promotion as in the reference's
+            # trajectory/core.py:384-390: float64 forces are not demoted to float32 coordinates' dtype): the general
+            # concatenation
+            from .core import _augment_concat
+
+            if self._cov_matrix is not None:
+                y = self._full_sample(mean, noise)
+            else:
+                y, _ = K.condnormal_sites(mean, self.var, 0.0, noise, self._next_stream(), self.frame_offset,
+                                          K.torch_dtype(self.dtype))
             d_src, d_gen = self._log_gradient_dev(c, M, mean, y)
-            oc, of = K.augment_concat(c, f, y, d_src, d_gen, kbt)
-            return K.like_input(oc, coords), K.like_input(of, coords)
+            return _augment_concat(coords, forces, y, d_src, d_gen, kbt)
         cols = K.premap_columns(self._correction_matrix(M), K.torch_dtype(self.dtype), c.device)
         oc, of = K.condnormal_augment(c, f, cols, M.shape[0], mean, self.var, kbt, noise, self._next_stream(),
                                       self.frame_offset)

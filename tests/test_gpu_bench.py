@@ -109,7 +109,7 @@ def test_bench_kernel_label_is_the_string_rocprofv3_prints(tmp_path):
     env["TMPDIR"] = str(tmp_path)
     for workload, family in (("tiny", "gram_small_kernel"), ("c2", "gram_tile_dma_kernel")):
         out_dir = tmp_path / workload
-        proc = subprocess.run([rocprof, "--kernel-trace", "--stats", "-d", str(out_dir), "--", sys.executable,
+        proc = subprocess.run([rocprof, "--kernel-trace", "--stats", "--output-format", "csv", "-d", str(out_dir), "--", sys.executable,
                                os.path.join(ROOT, "bench.py"), "--workload", workload, "--steps", "2", "--warmup", "1",
                                "--no-cpu-baseline"] + (["--frames", "20000"] if workload == "c2" else []),
                               stdout=subprocess.PIPE, stderr=subprocess.PIPE, env=env, timeout=600, cwd=str(tmp_path))

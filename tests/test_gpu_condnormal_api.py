@@ -183,6 +183,31 @@ def test_general_augmenter_protocol_concatenates_like_the_reference(dt):
     assert at.n_aug_sites == 3 and np.array_equal(at.real_forces, forces)
 
 
+def test_augmenter_protocol_promotes_forces_like_numpy():
+    """float64 forces beside float32 coordinates (reference trajectory/core.py:384-390: `forces + kbt * real_corr`,
+    then concatenate -- NumPy promotion): the forces stay float64, the coordinates float32; through the general
+    protocol and through CondNormal's own concatenation."""
+    coords, forces, _, _ = system(T=130, dt=np.float32)
+    forces = forces.astype(np.float64) * (1.0 + 1e-9)  # not representable in float32
+    eps = np.random.default_rng(2).standard_normal((130, 3, 3)).astype(np.float32)
+    aug = HostShiftAugmenter(0.7, eps)
+    at = AugmentedTrajectory.from_trajectory(t=Trajectory(coords=coords, forces=forces), augmenter=aug, kbt=KBT)
+    y = aug.sample(coords)
+    corr, lg = aug.log_gradient(coords, y)
+    want_c = np.concatenate([coords, y], axis=1)
+    want_f = np.concatenate([forces + KBT * corr, KBT * lg], axis=1)
+    assert at.coords.dtype == want_c.dtype == np.float32 and at.forces.dtype == want_f.dtype == np.float64
+    # (NumPy forms `KBT * corr` in float32 before the promotion, the kernel in float64: 1e-9 apart)
+    assert np.array_equal(at.coords, want_c) and rel(at.forces, want_f) < 1e-7
+    assert rel(at.forces[:, :coords.shape[1]] - KBT * corr, forces) < 1e-9  # the float64 forces were not demoted
+    cn = JCondNormal(0.05, premap=LinearMap([[0], [3], [6]], n_fg_sites=coords.shape[1]).flat_call, seed=5, dtype=np.float32)
+    oc, of = cn.augment_trajectory(coords, forces, KBT)
+    assert oc.dtype == np.float32 and of.dtype == np.float64
+    assert rel(of[:, :coords.shape[1]] - forces, (of[:, :coords.shape[1]] - forces).astype(np.float32)) < 1e-6
+    d_src, d_gen = cn.log_gradient(coords, oc[:, coords.shape[1]:])
+    assert rel(of, np.concatenate([forces + KBT * d_src, KBT * d_gen], axis=1)) < 1e-6
+
+
 def test_nan_flag_pool_survives_a_raised_coordinate_map():
     """the slice map's deferred NaN flag was handed back twice when result() raised (then discard() in
     project_forces' finally), so two later kernels shared one flag.  After the raise, a clean call passes and a call

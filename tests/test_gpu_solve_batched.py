@@ -132,3 +132,37 @@ def test_factorisation_forms_agree(monkeypatch):
         _, st = K.eq_qp_solve(Gbad, 0.0, None, A[:, :] * 0.0 + torch.eye(m, n, dtype=torch.float64, device="cuda"), B,
                               schur_reg=0.0, n_refine=0)
         assert float(st[0]) == 701.0, (env, st)
+
+
+def test_one_launch_step_is_bit_identical_for_any_workgroup_count(monkeypatch):
+    """The one-launch factorisation step (chol_step_kernel) must not depend on WHICH workgroup handles a row block or
+    on how many run at once: a 500-variable system stays in the one-launch form whether one workgroup walks all row
+    blocks (AGGF_SOLVE_WGS=1, strictly serial) or every row block has its own (default; the form that raced in round 4:
+    workgroup 0 overwrote the diagonal block late workgroups still read).  Same arithmetic per row block -> the solved
+    maps, the statistics and the pinned solve are BIT-identical; a dependence on dispatch order shows as a difference.
+    The replicated solve of the multi-GPU path (qp/qplinear.py:79-86 on every rank) relies on exactly this."""
+    rng = np.random.default_rng(17)
+    n, m = 500, 12
+    R = rng.standard_normal((3 * n, n))
+    G = torch.from_numpy(R.T @ R).cuda()
+    A = torch.from_numpy(rng.standard_normal((m, n))).cuda()
+    pins = torch.arange(0, n, n // m, dtype=torch.int32)[:m].cuda()
+
+    def solves():
+        X, st = K.eq_qp_solve(G, 1e-3, None, A, None, schur_reg=0.0, n_refine=1)
+        Xb, stb = K.eq_qp_solve_batched(torch.stack([G, 3.0 * G]), 1e-3, None, torch.stack([A, A]), None)
+        Xp, stp = K.eq_qp_solve_pinned(G, 1e-3, None, pins)
+        return [X, st, Xb, stb, Xp, stp]
+
+    results = {}
+    for wgs in (None, "1", "2", "5"):
+        if wgs is None:
+            monkeypatch.delenv("AGGF_SOLVE_WGS", raising=False)
+        else:
+            monkeypatch.setenv("AGGF_SOLVE_WGS", wgs)
+        results[wgs] = solves()
+    for wgs in ("1", "2", "5"):
+        for a, b in zip(results[None], results[wgs]):
+            assert torch.equal(a, b), f"AGGF_SOLVE_WGS={wgs} changes the result"
+    ref = orc.eq_qp_solve(G.cpu().numpy() + 1e-3 * np.eye(n), None, A.cpu().numpy(), np.eye(m))
+    assert np.max(np.abs(results[None][0].cpu().numpy().T - ref)) < 1e-8 * np.max(np.abs(ref))
