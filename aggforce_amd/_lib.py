@@ -128,18 +128,19 @@ def lib() -> C.CDLL:
     return l
 
 
-def coverage(names: bool = False) -> dict:
-    """Mangled kernel name -> launches by this process since the last ``aggf_coverage_reset`` (every kernel the
-    process has ever launched is listed, with 0 if not since the reset).  ``names=True``: -> (demangled name, launches),
-    the demangled name being the string rocprofv3 prints for the kernel."""
+def coverage(names: bool = False, total: bool = False) -> dict:
+    """Mangled kernel name -> launches by this process since the last ``aggf_coverage_reset`` (``total=True``: since
+    the library was loaded); every kernel the process has ever launched is listed.  ``names=True``: -> (demangled name,
+    launches), the demangled name being the string rocprofv3 prints for the kernel."""
     l = load()
     need = l.aggf_coverage_dump(None, 0)
     buf = C.create_string_buffer(need + 1)
     l.aggf_coverage_dump(buf, need + 1)
     out = {}
     for line in buf.value.decode().splitlines():
-        mangled, pretty, cnt = line.split("\t")
-        out[mangled] = (pretty, int(cnt)) if names else int(cnt)
+        mangled, pretty, cnt, tot = line.split("\t")
+        n = int(tot) if total else int(cnt)
+        out[mangled] = (pretty, n) if names else n
     return out
 
 

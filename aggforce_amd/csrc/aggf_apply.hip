@@ -410,7 +410,9 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
       for (int i = 0; i < AS_NV; ++i) {
         const int v = tid + AS_THREADS * i;
         v16_t x = {0.f, 0.f, 0.f, 0.f};
-        if (v < n_vec) x = *reinterpret_cast<const v16_t*>(src + (int64_t)v * 16);
+        // non-temporal: every byte of the trajectory is read once (tools/ldsdma_fill.hip: 6.8 against 6.1 TB/s for
+        // this load shape on a stream that is read once)
+        if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16_t*>(src + (int64_t)v * 16));
         hold[i] = x;
       }
     } else {

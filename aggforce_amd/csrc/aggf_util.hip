@@ -17,7 +17,8 @@ namespace aggf {
 // the test session collects the launches of its child processes that way.
 constexpr int COVER_SLOTS = 4096;  // power of two, ~10x the kernels of the library
 static std::atomic<const void*> g_cover_key[COVER_SLOTS];
-static std::atomic<uint64_t> g_cover_cnt[COVER_SLOTS];
+static std::atomic<uint64_t> g_cover_cnt[COVER_SLOTS];    // since the last aggf_coverage_reset
+static std::atomic<uint64_t> g_cover_total[COVER_SLOTS];  // since the library was loaded
 
 void cover_hit(const void* h) {
   size_t i = ((uintptr_t)h >> 3) * 0x9E3779B97F4A7C15ull >> 52;
@@ -29,6 +30,7 @@ void cover_hit(const void* h) {
     }
     if (k == h) {
       g_cover_cnt[i].fetch_add(1, std::memory_order_relaxed);
+      g_cover_total[i].fetch_add(1, std::memory_order_relaxed);
       return;
     }
   }
@@ -60,7 +62,7 @@ static OrderAtExit g_order_at_exit;
 }  // namespace
 #endif
 
-// "mangled name<tab>demangled name<tab>count<newline>" per executed kernel into buf (always NUL-terminated when
+// "mangled name<tab>demangled name<tab>launches since the last reset<tab>launches in all<newline>" per executed kernel into buf (always NUL-terminated when
 // n > 0), with `label<tab>` in front of every line if given; returns the bytes the full text needs (without the NUL)
 static size_t cover_dump(char* buf, size_t n, const char* label) {
   size_t need = 0;
@@ -81,7 +83,8 @@ static size_t cover_dump(char* buf, size_t n, const char* label) {
     std::string line;
     if (label) line.append(label).append("\t");
     line.append(name).append("\t").append(status == 0 && pretty ? pretty : name).append("\t");
-    line.append(std::to_string((unsigned long long)g_cover_cnt[i].load())).append("\n");
+    line.append(std::to_string((unsigned long long)g_cover_cnt[i].load())).append("\t");
+    line.append(std::to_string((unsigned long long)g_cover_total[i].load())).append("\n");
     free(pretty);
     if (need + line.size() < n) {
       memcpy(buf + need, line.data(), line.size());
@@ -531,7 +534,6 @@ extern "C" int aggf_concat_sites(const void* a, int32_t Na, int a_dtype, const v
   else if (a_dtype == AGGF_F64 && b_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_CC(double, double, double);
   else if (a_dtype == AGGF_F32 && b_dtype == AGGF_F64 && out_dtype == AGGF_F64) AGGF_CC(float, double, double);
   else if (a_dtype == AGGF_F64 && b_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_CC(double, float, double);
-  else if (a_dtype == AGGF_F32 && b_dtype == AGGF_F32 && out_dtype == AGGF_F64) AGGF_CC(float, float, double);
   else return fail(AGGF_ERR_ARG, "aggf_concat_sites: out_dtype must hold the promotion of the inputs");
 #undef AGGF_CC
   AGGF_LAUNCH_OK();

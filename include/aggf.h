@@ -47,8 +47,8 @@ int aggf_version(void);
 const char* aggf_last_error(void);
 /* Launch coverage (no reference counterpart: test infrastructure of the dispatch tables).  Every kernel launch of the
  * library is counted under its template instantiation.  aggf_coverage_dump writes "mangled kernel name <tab> demangled name
- * <tab> launches <newline>" for every kernel this process has launched (counts since the last reset; kernels launched before a reset
- * stay listed with count 0) into buf, NUL-terminated, and returns the bytes the full text needs (call with buf_bytes = 0
+ * <tab> launches since the last aggf_coverage_reset <tab> launches since the library was loaded <newline>" for every kernel
+ * this process has launched into buf, NUL-terminated, and returns the bytes the full text needs (call with buf_bytes = 0
  * to size the buffer).  A process with AGGF_COVERAGE_FILE set appends the same lines with "label <tab>" in front to that
  * file when the library is unloaded (label = AGGF_COVERAGE_LABEL): tests/test_gpu_zz_coverage.py. */
 size_t aggf_coverage_dump(char* buf, size_t buf_bytes);
@@ -488,9 +488,9 @@ int aggf_allreduce_sum(void* buf, int64_t count, int dtype, void* comm, void* st
 /* Frame-sized housekeeping of the host layer (the reference does it in NumPy on (n_frames, n_sites, 3) arrays):
  *   aggf_take_frames   out[i, :] = src[idx[i], :], whole frames of row_elems elements each (fold / sample selection:
  *                      agg.py:208-231 `coords[train_inds]`, featlinearmap.py:447-452); idx: int64 on the device, every
- *                      entry in [0, n_src) (entries outside are skipped: their output rows are left untouched);
+ *                      entry in [0, n_src) (the host validates; an entry outside gives a NaN row, never a read outside src);
  *   aggf_concat_sites  out[t] = [a[t] ; b[t]] along the site axis (np.concatenate(axis=1) of trajectory/core.py:388-390,
- *                      map/tmap.py:430-436), a: (T, Na, 3), b: (T, Nb, 3), out in the NumPy promotion of the two;
+ *                      map/tmap.py:430-436), a: (T, Na, 3), b: (T, Nb, 3), out_dtype = the NumPy promotion of the two (anything else is refused);
  *   aggf_scale         out = alpha x, elementwise in `dtype` (map/tmap.py:399-401 `fill_value * coords`: a product,
  *                      so NaN and 0 x inf behave as in NumPy). */
 int aggf_take_frames(const void* src, int64_t n_src, int64_t row_elems, int dtype, const int64_t* idx, int64_t n,

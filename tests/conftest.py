@@ -50,7 +50,7 @@ def pytest_runtest_teardown(item):
     try:
         from aggforce_amd import _lib
 
-        now = _lib.coverage()
+        now = _lib.coverage(total=True)  # (tests may reset the since-reset counters)
     except Exception:  # library not built: the tests themselves say so
         return
     for name, cnt in now.items():

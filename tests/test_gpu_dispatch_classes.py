@@ -199,15 +199,16 @@ def test_gb_regression_matrix_and_apply_dtype_triples(tf, tg, to):
         assert rel(np.swapaxes(R[:, :n_feat, :], 1, 2).reshape(-1, n_feat), reg_o) < 5e-6  # (the oracle's features are float32)
 
 
-def test_feat_contract_float64_forces_float32_features():
-    """aggf_feat_contract with float64 forces and float32 features (featlinearmap.py:361-369 under NumPy promotion)."""
+@pytest.mark.parametrize("fdt,xdt", [(np.float64, np.float32), (np.float32, np.float64)])
+def test_feat_contract_mixed_dtypes(fdt, xdt):
+    """aggf_feat_contract with forces and features of different dtypes (featlinearmap.py:361-369 under NumPy promotion)."""
     rng = np.random.default_rng(6)
     T, N, n_feat = 203, 11, 9
-    forces = rng.standard_normal((T, N, 3))
-    feat = rng.standard_normal((T, N, n_feat)).astype(np.float32)
-    div = rng.standard_normal((T, n_feat, 3)).astype(np.float32)
+    forces = rng.standard_normal((T, N, 3)).astype(fdt)
+    feat = rng.standard_normal((T, N, n_feat)).astype(xdt)
+    div = rng.standard_normal((T, n_feat, 3)).astype(xdt)
     got = K.feat_contract(dev(forces), dev(feat), dev(div), 0.6, 16)
-    want = np.einsum("taf,tad->tfd", feat.astype(np.float64), forces) + 0.6 * div
+    want = np.einsum("taf,tad->tfd", feat.astype(np.float64), forces.astype(np.float64)) + 0.6 * div
     assert got.dtype == torch.float64 and got.shape == (T, 16, 3)
     # (NumPy forms `0.6 * div` in float32 before the promotion, the kernel in float64: 1e-8 apart)
     assert rel(got[:, :n_feat].cpu().numpy(), want) < 1e-7 and float(got[:, n_feat:].abs().max()) == 0.0

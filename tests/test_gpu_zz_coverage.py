@@ -37,7 +37,7 @@ def test_every_compiled_kernel_was_launched_by_a_parity_test(request):
     children = COVERAGE["children_file"]
     if children and os.path.exists(children):
         for line in open(children):
-            label, name, _pretty, cnt = line.rstrip("\n").split("\t")
+            label, name, _pretty, _since_reset, cnt = line.rstrip("\n").split("\t")
             if int(cnt) > 0:
                 by_kernel.setdefault(name, set()).add(label + " [child]")
 
