@@ -692,20 +692,28 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
       // 13600 cycles per stage were spent "issuing" five loads)
       // non-temporal where every byte is read once (one workgroup per frame range; tools/ldsdma_fill.hip: 6.8 against
       // 6.1 TB/s for this load shape); with `parts` workgroups per frame range the siblings meet the frames in their L2
+      // Addresses: ONE 32-bit lane offset (tid x 16) beside a wave-uniform base per piece (scalar registers): the loads
+      // take the scalar-base form.  With a 64-bit address per piece (5-8 register pairs held across the stage) every
+      // instantiation of this kernel spilled at its 128-register cap, and a spill RELOAD is a scratch load: the
+      // `s_waitcnt vmcnt(0)` in front of its use also waited for every global load issued before it -- the loads of a
+      // stage went out one HBM latency apart (round 5: 2800 of 10300 cycles per stage at CLN025 "issuing" five loads).
+      const unsigned voff = (unsigned)tid * 16u;
       if (gridDim.y == 1) {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const int v = tid + SM_THREADS * i;
+          const char* base_i = src + (int64_t)i * (SM_THREADS * 16);
           v16_t x = {0.f, 0.f, 0.f, 0.f};
-          if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16_t*>(src + (int64_t)v * 16));
+          if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16_t*>(base_i + voff));
           hold[i] = x;
         }
       } else {
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
           const int v = tid + SM_THREADS * i;
+          const char* base_i = src + (int64_t)i * (SM_THREADS * 16);
           v16_t x = {0.f, 0.f, 0.f, 0.f};
-          if (v < n_vec) x = *reinterpret_cast<const v16_t*>(src + (int64_t)v * 16);
+          if (v < n_vec) x = *reinterpret_cast<const v16_t*>(base_i + voff);
           hold[i] = x;
         }
       }
@@ -1040,7 +1048,9 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
       return 2 * panel + 2 * raw + tab;
     };
     const size_t lds_max = 160 * 1024 - 512;
-    const bool ws_ok = n_red <= 512 && aligned && !tiles_only && first_col == 0 && N < 21000 && lds_need(4) <= lds_max;
+    // (a stage's frames travel through 12 x 16 B x 256 producer threads = 48 KB of registers at most)
+    auto stage_ok = [&](int kbs) { return lds_need(kbs) <= lds_max && (int64_t)kbs * 3 * N * (int64_t)s_in <= 12 * 256 * 16; };
+    const bool ws_ok = n_red <= 512 && aligned && !tiles_only && first_col == 0 && N < 21000 && stage_ok(4);
     const bool ws_on = ws_env ? atoi(ws_env) != 0 : false;
     if (ws_ok && ws_on && !no_small) {
       p->staging = STAGE_WS;
@@ -1048,7 +1058,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
       p->direct = true;
       p->chunk_frames = T;
       p->pack_bytes = 0;
-      p->ws_kbs = lds_need(8) <= lds_max ? 8 : 4;
+      p->ws_kbs = stage_ok(8) ? 8 : 4;
       const int nb16 = n16 / 16, n_blocks = nb16 * (nb16 + 1) / 2;
       const int max_c = compute_dtype == AGGF_F64 ? ws_max_c<double>() : ws_max_c<float>();
       p->parts = (int)ceil_div((int64_t)n_blocks, WS_CONS * max_c);

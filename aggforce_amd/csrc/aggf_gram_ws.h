@@ -23,10 +23,58 @@
 namespace aggf {
 
 constexpr int WS_PROD = 4, WS_CONS = 8, WS_THREADS = 64 * (WS_PROD + WS_CONS);
+
+// AGGF_WS_ABL (tools/ws_probe.hip only): one of the three activities removed -- 1 = no operand reads / MFMAs,
+// 2 = no global loads and no parking after the prologue, 3 = no group sums after the prologue
+#ifndef AGGF_WS_ABL
+#define AGGF_WS_ABL 0
+#endif
+#ifdef AGGF_WS_PROF
+// tools/ws_probe.hip: shader cycles per wave -- producers: [0] load issue, [1] group sums, [2] load wait + park, [3] barrier;
+// consumers: [4] operand reads + MFMAs, [5] barrier; [6] stages x producer waves, [7] stages x consumer waves
+__device__ unsigned long long aggf_ws_prof[8];
+#define AGGF_WP_T(x) const uint64_t x = __builtin_readcyclecounter()
+#else
+#define AGGF_WP_T(x)
+#endif
 // blocks per consumer wave: accumulators of at most 96 (float64: 12 blocks x 8) / 64 (float32: 16 x 4) registers of
 // the 168 a wave may hold at three waves per SIMD (14 and 16 float64 blocks spilled: -Rpass-analysis=kernel-resource-usage)
 template <typename TC>
 constexpr int ws_max_c() { return sizeof(TC) == 8 ? 12 : 16; }
+
+// LDS accesses of the PRODUCER waves beside their own pending LDS-DMAs.  The compiler's wait-count pass puts an
+// `s_waitcnt vmcnt(0)` in front of every LDS access it can see while an LDS-DMA of the same wave is in flight (it cannot
+// tell the two raw buffers apart), which would serialise "issue the next stage's DMAs, then sum the landed stage" into
+// one HBM latency per stage (measured: 7900 of 14000 cycles per stage "issuing" eight DMAs).  Inline assembly is
+// invisible to that pass: the group sums read and write LDS through these, and wait for their reads themselves
+// (ws_lds_wait).  Correctness is the kernel's own business: a buffer is read only after the vmcnt(0) + barrier that
+// followed its DMAs.
+__device__ __forceinline__ unsigned ws_lds_addr(const void* p) {
+  return (unsigned)(uintptr_t)(const __attribute__((address_space(3))) char*)p;
+}
+__device__ __forceinline__ float ws_lds_read(const float* p) {
+  float v;
+  asm volatile("ds_read_b32 %0, %1" : "=v"(v) : "v"(ws_lds_addr(p)));
+  return v;
+}
+__device__ __forceinline__ double ws_lds_read(const double* p) {
+  double v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(ws_lds_addr(p)));
+  return v;
+}
+__device__ __forceinline__ uint2 ws_lds_read(const uint2* p) {
+  unsigned long long v;
+  asm volatile("ds_read_b64 %0, %1" : "=v"(v) : "v"(ws_lds_addr(p)));
+  return make_uint2((unsigned)v, (unsigned)(v >> 32));
+}
+__device__ __forceinline__ void ws_lds_write(float* p, float v) { asm volatile("ds_write_b32 %0, %1" ::"v"(ws_lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void ws_lds_write(double* p, double v) { asm volatile("ds_write_b64 %0, %1" ::"v"(ws_lds_addr(p)), "v"(v) : "memory"); }
+__device__ __forceinline__ void ws_lds_wait() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+// a value read by ws_lds_read may be used only behind the wait: the empty statement (ordered behind the wait like every
+// volatile asm) redefines the value as far as the compiler knows, so no use of it can be scheduled in front
+__device__ __forceinline__ void ws_lds_ready(float& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void ws_lds_ready(double& v) { asm volatile("" : "+v"(v)); }
+__device__ __forceinline__ void ws_lds_ready(uint2& v) { asm volatile("" : "+v"(v.x), "+v"(v.y)); }
 
 // panel row stride (elements): 3 n16 + pad with stride % 32 == 16 -- the two frame rows a 32-lane half of an operand
 // read touches then hit disjoint banks (f64: 2 RS dwords = 32 mod 64; f32: RS dwords = 16 mod 32)
@@ -114,36 +162,74 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gram_ws_kernel(
   if (producer) {
     // =========================== PRODUCER =====================================================================
     const int pw = wave - WS_CONS;                         // 0..3
-    // stage s -> raw buffer s & 1 by LDS-DMA: one wave-instruction = 64 lanes x 16 B = 1 KiB, contiguous in LDS and in
-    // HBM (a stage is one contiguous run of KBS frames); the last stage of the trajectory may hold fewer frames: it goes
-    // through registers, element by element, with zeros behind the end
+    // The producers are the youngest waves of their SIMDs and lose every issue arbitration to the two consumers beside
+    // them (same priority: by age): eight global loads took 8000 cycles to issue, the group sums 3x their time alone
+    // (profiles/r05_ws_ablation.txt).  They issue a few hundred instructions per stage against the consumers' MFMA
+    // stream: at a higher priority they get them in at once and cost the consumers almost nothing.
+    __builtin_amdgcn_s_setprio(3);
+    // stage s -> registers (16-byte pieces of the contiguous run of KBS frames, all of them in flight at once) -> raw
+    // buffer s & 1.  (The first version filled the raw buffers by LDS-DMA: beside the consumers' operand reads an
+    // LDS-DMA instruction took ~960 cycles to issue -- 7900 cycles per stage at 175 atoms, 2.6 TB/s for the chip; a
+    // global load to registers issues at once, and the ds_write of the parked pieces is ordinary LDS traffic.)
+    constexpr int NVMAX = 12;                              // pieces per producer thread and stage (host: <= 48 KB per stage)
+    const int pt = pw * 64 + lane;
+    typedef float __attribute__((ext_vector_type(4))) v16_t;
+    v16_t hold[NVMAX];
+    bool hold_full = false;                                // (uniform) the held stage is a full one: park all pieces
+    int64_t hold_valid = 0;
     auto fetch = [&](int s) {
       const int64_t t0 = stage_t0(s);
-      char* dst = raw0 + (size_t)(s & 1) * raw_bytes;
-      if (t0 + KBS <= T) {
-        const char* src = reinterpret_cast<const char*>(F + t0 * row_in);
-        // non-temporal (aux = 2) where every byte is read once: 7.1 against 6.4 TB/s (profiles/r05_ldsdma_fill.jsonl);
-        // with `parts` workgroups per frame range the siblings meet the frames in their XCD's L2: default policy
+      const char* src = reinterpret_cast<const char*>(F + t0 * row_in);
+      hold_full = t0 + KBS <= T;
+      hold_valid = (T - t0 < KBS ? T - t0 : KBS) * row_in * (int64_t)sizeof(TIn);
+      if (hold_full) {
+        // non-temporal where every byte is read once (6.8 against 6.1 TB/s: profiles/r05_ldsdma_fill.jsonl); with
+        // `parts` workgroups per frame range the siblings meet the frames in their XCD's L2: default policy
         if (parts == 1) {
-          for (int v0 = pw * 64; v0 < n_vec; v0 += 64 * WS_PROD) {
-            if (v0 + lane < n_vec)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)(v0 + lane) * 16),
-                                               (__attribute__((address_space(3))) void*)(dst + (size_t)v0 * 16), 16, 0, 2);
+#pragma unroll
+          for (int i = 0; i < NVMAX; ++i) {
+            const int v = pt + 256 * i;
+            v16_t xv = {0.f, 0.f, 0.f, 0.f};
+            if (v < n_vec) xv = __builtin_nontemporal_load(reinterpret_cast<const v16_t*>(src + (int64_t)v * 16));
+            hold[i] = xv;
           }
         } else {
-          for (int v0 = pw * 64; v0 < n_vec; v0 += 64 * WS_PROD) {
-            if (v0 + lane < n_vec)
-              __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (int64_t)(v0 + lane) * 16),
-                                               (__attribute__((address_space(3))) void*)(dst + (size_t)v0 * 16), 16, 0, 0);
+#pragma unroll
+          for (int i = 0; i < NVMAX; ++i) {
+            const int v = pt + 256 * i;
+            v16_t xv = {0.f, 0.f, 0.f, 0.f};
+            if (v < n_vec) xv = *reinterpret_cast<const v16_t*>(src + (int64_t)v * 16);
+            hold[i] = xv;
           }
         }
       } else {
-        const int64_t valid = (T - t0) * row_in, all = (int64_t)KBS * row_in;
-        const TIn* src = F + t0 * row_in;
-        for (int64_t e = pw * 64 + lane; e < all; e += 64 * WS_PROD) reinterpret_cast<TIn*>(dst)[e] = e < valid ? src[e] : (TIn)0;
+        // the last stage of the trajectory holds fewer frames: element by element, zeros behind the end
+#pragma unroll
+        for (int i = 0; i < NVMAX; ++i) {
+          const int v = pt + 256 * i;
+          v16_t xv = {0.f, 0.f, 0.f, 0.f};
+          if (v < n_vec) {
+            const int64_t off = (int64_t)v * 16;
+            TIn tmp[16 / sizeof(TIn)];
+#pragma unroll
+            for (int k = 0; k < (int)(16 / sizeof(TIn)); ++k)
+              tmp[k] = off + (k + 1) * (int64_t)sizeof(TIn) <= hold_valid ? reinterpret_cast<const TIn*>(src + off)[k] : (TIn)0;
+            xv = *reinterpret_cast<v16_t*>(tmp);
+          }
+          hold[i] = xv;
+        }
       }
     };
-    // raw frames -> panel: wave pw takes frames pw, pw + 4 of the stage, a lane four columns 64 apart per pass
+    auto park = [&](int s) {
+      char* dst = raw0 + (size_t)(s & 1) * raw_bytes;
+#pragma unroll
+      for (int i = 0; i < NVMAX; ++i) {
+        const int v = pt + 256 * i;
+        if (v < n_vec) reinterpret_cast<v16_t*>(dst)[v] = hold[i];
+      }
+    };
+    // raw frames -> panel: wave pw takes frames pw, pw + 4 of the stage, a lane four columns 64 apart per pass.  Every
+    // LDS access goes through the ws_lds_* accessors (see there); the values of a pass are read, waited for, summed.
     auto sums = [&](const char* rawb, TC* panel) {
       const TIn* rw = reinterpret_cast<const TIn*>(rawb);
       for (int r = pw; r < KBS; r += WS_PROD) {
@@ -151,15 +237,18 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gram_ws_kernel(
         TC* prow = panel + r * RS;
         if (!grp_ptr) {
           for (int c0 = lane; c0 < RE; c0 += 256) {
-            TC v[4];
+            TIn v[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int c = c0 + 64 * u;
-              v[u] = (TC)rw[c < 3 * n_red ? base + c : zero_idx];
+              v[u] = ws_lds_read(rw + (c < 3 * n_red ? base + c : zero_idx));
             }
+            ws_lds_wait();
+#pragma unroll
+            for (int u = 0; u < 4; ++u) ws_lds_ready(v[u]);
 #pragma unroll
             for (int u = 0; u < 4; ++u)
-              if (c0 + 64 * u < RE) prow[c0 + 64 * u] = v[u];
+              if (c0 + 64 * u < RE) ws_lds_write(prow + c0 + 64 * u, (TC)v[u]);
           }
           continue;
         }
@@ -168,49 +257,88 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gram_ws_kernel(
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int c = c0 + 64 * u;
-            mem[u] = *reinterpret_cast<const uint2*>(memb_s + (c < RE ? c : 0) * 4);
+            mem[u] = ws_lds_read(reinterpret_cast<const uint2*>(memb_s + (c < RE ? c : 0) * 4));
           }
-          TC sum[4];
+          ws_lds_wait();
+#pragma unroll
+          for (int u = 0; u < 4; ++u) ws_lds_ready(mem[u]);
+          TIn v[4][4];
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
             const int o0 = mem[u].x & 0xFFFF, o1 = mem[u].x >> 16, o2 = mem[u].y & 0xFFFF, o3 = mem[u].y >> 16;
-            const TC v0 = (TC)rw[o0 == 0xFFFF ? zero_idx : base + o0], v1 = (TC)rw[o1 == 0xFFFF ? zero_idx : base + o1],
-                     v2 = (TC)rw[o2 == 0xFFFF ? zero_idx : base + o2], v3 = (TC)rw[o3 == 0xFFFF ? zero_idx : base + o3];
-            sum[u] = ((v0 + v1) + v2) + v3;  // members in CSR order, like the column sum of `@ con_mat`
+            v[u][0] = ws_lds_read(rw + (o0 == 0xFFFF ? zero_idx : base + o0));
+            v[u][1] = ws_lds_read(rw + (o1 == 0xFFFF ? zero_idx : base + o1));
+            v[u][2] = ws_lds_read(rw + (o2 == 0xFFFF ? zero_idx : base + o2));
+            v[u][3] = ws_lds_read(rw + (o3 == 0xFFFF ? zero_idx : base + o3));
           }
+          ws_lds_wait();
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ws_lds_ready(v[u][q]);
+          TC sum[4];
+#pragma unroll
+          for (int u = 0; u < 4; ++u)
+            sum[u] = (((TC)v[u][0] + (TC)v[u][1]) + (TC)v[u][2]) + (TC)v[u][3];  // members in CSR order, like the column sum of `@ con_mat`
           if (big_groups) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
               const int c = c0 + 64 * u;
               if (c >= RE) continue;
               const int g = c / 3, d = c - 3 * g;
-              for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) sum[u] += (TC)rw[base + 3 * atoms_s[j] + d];
+              for (int j = ptr_s[g] + SM_FAST_MEMBERS; j < ptr_s[g + 1]; ++j) {
+                TIn x = ws_lds_read(rw + base + 3 * atoms_s[j] + d);
+                ws_lds_wait();
+                ws_lds_ready(x);
+                sum[u] += (TC)x;
+              }
             }
           }
 #pragma unroll
           for (int u = 0; u < 4; ++u)
-            if (c0 + 64 * u < RE) prow[c0 + 64 * u] = sum[u];
+            if (c0 + 64 * u < RE) ws_lds_write(prow + c0 + 64 * u, sum[u]);
         }
       }
     };
-    auto landed = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); };
-
-    // prologue: stage 0 -> panel0, stage 1 on its way
-    if (n_it > 0) fetch(0);
-    landed();
+    // prologue: stage 0 -> panel0, stage 1 parked
+    if (n_it > 0) {
+      fetch(0);
+      park(0);
+    }
     __syncthreads();                                       // (P1) raw[0] = stage 0, from every producer wave
     if (n_it > 1) fetch(1);
     if (n_it > 0) sums(raw0, panel0);
-    landed();
+    if (n_it > 1) park(1);
+    ws_lds_wait();
     __syncthreads();                                       // (P2) panel0 = stage 0, raw[1] = stage 1
+#ifdef AGGF_WS_PROF
+    uint64_t pf[4] = {0, 0, 0, 0};
+#endif
     for (int s = 0; s < n_it; ++s) {
-      // the consumers multiply stage s (panel s & 1); stage s + 2 leaves HBM for raw[s & 1] (whose frames -- stage s --
-      // were summed one stage ago), stage s + 1 (raw[(s + 1) & 1], landed before the last barrier) becomes the other panel
-      if (s + 2 < n_it) fetch(s + 2);
-      if (s + 1 < n_it) sums(raw0 + (size_t)((s + 1) & 1) * raw_bytes, (s & 1) ? panel0 : panel1);
-      landed();
+      // the consumers multiply stage s (panel s & 1).  Stage s + 2 leaves HBM for the registers; stage s + 1
+      // (raw[(s + 1) & 1], parked before the last barrier) becomes the other panel; then the registers are parked in
+      // raw[s & 1], whose frames -- stage s -- were summed one stage ago.
+      AGGF_WP_T(q0);
+      if (AGGF_WS_ABL != 2 && s + 2 < n_it) fetch(s + 2);
+      AGGF_WP_T(q1);
+      if (AGGF_WS_ABL != 3 && s + 1 < n_it) sums(raw0 + (size_t)((s + 1) & 1) * raw_bytes, (s & 1) ? panel0 : panel1);
+      ws_lds_wait();
+      AGGF_WP_T(q2);
+      if (AGGF_WS_ABL != 2 && s + 2 < n_it) park(s + 2);
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+      AGGF_WP_T(q3);
       __syncthreads();
+#ifdef AGGF_WS_PROF
+      const uint64_t q4 = __builtin_readcyclecounter();
+      pf[0] += q1 - q0; pf[1] += q2 - q1; pf[2] += q3 - q2; pf[3] += q4 - q3;
+#endif
     }
+#ifdef AGGF_WS_PROF
+    if (lane == 0) {
+      for (int i = 0; i < 4; ++i) atomicAdd(&aggf_ws_prof[i], (unsigned long long)pf[i]);
+      atomicAdd(&aggf_ws_prof[6], (unsigned long long)n_it);
+    }
+#endif
     return;
   }
 
@@ -242,9 +370,13 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gram_ws_kernel(
   const int off = (lane >> 4) * RS + 3 * (lane & 15);
   __syncthreads();                                         // (P1)
   __syncthreads();                                         // (P2)
+#ifdef AGGF_WS_PROF
+  uint64_t cf[2] = {0, 0};
+#endif
   for (int s = 0; s < n_it; ++s) {
     const TC* panel = (s & 1) ? panel1 : panel0;
-    if (mfma_wave) {
+    AGGF_WP_T(c0);
+    if (AGGF_WS_ABL != 1 && mfma_wave) {
 #pragma unroll
       for (int kk = 0; kk < KBS / 4; ++kk)
 #pragma unroll
@@ -260,8 +392,20 @@ __global__ __launch_bounds__(WS_THREADS, 3) void gram_ws_kernel(
         }
     }
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // every operand read of this stage has returned
+    AGGF_WP_T(c1);
     __syncthreads();
+#ifdef AGGF_WS_PROF
+    const uint64_t c2 = __builtin_readcyclecounter();
+    cf[0] += c1 - c0; cf[1] += c2 - c1;
+#endif
   }
+#ifdef AGGF_WS_PROF
+  if (lane == 0) {
+    atomicAdd(&aggf_ws_prof[4], (unsigned long long)cf[0]);
+    atomicAdd(&aggf_ws_prof[5], (unsigned long long)cf[1]);
+    atomicAdd(&aggf_ws_prof[7], (unsigned long long)n_it);
+  }
+#endif
   TC* slab = slabs + ((int64_t)x * parts + part) * ((int64_t)slab_edge * slab_edge);
 #pragma unroll
   for (int k = 0; k < C; ++k)
