@@ -935,12 +935,8 @@ __global__ __launch_bounds__(2 * WT > 1024 ? 1024 : 2 * WT) void gram_reduce_sma
   AGGF_GATED_BODY_END
 }
 
-}  // namespace aggf
-#include "aggf_gram_ws.h"
-namespace aggf {
-
 // ---------------------------------------------------------------------------
-enum GramStaging { STAGE_DMA8 = 3, STAGE_SMALL = 4, STAGE_WS = 5 };  // 8-wave LDS-DMA tile kernel / single-tile streaming kernel / producer-consumer streaming kernel
+enum GramStaging { STAGE_DMA8 = 3, STAGE_SMALL = 4 };  // 8-wave LDS-DMA tile kernel / single-tile streaming kernel
 
 struct GramPlan {
   int32_t n_pad, nt1, n_tiles;
@@ -952,7 +948,6 @@ struct GramPlan {
   bool edge = false;     // tile kernel reads rows that are not padded to whole panels (N % 128 != 0, in place)
   bool wide256 = false;  // small-system kernel: 113-128 columns on the 256-column panel (16 waves, 3 blocks per wave)
   int parts = 1;       // small-system kernel above 256 columns: workgroups that share a frame range and split the block list
-  int ws_kbs = 0, ws_c = 0;  // producer-consumer kernel: frames per stage, blocks per consumer wave
   int64_t frames_per_split;
   int64_t chunk_frames;  // frames per pack chunk (direct: T)
   size_t slab_bytes, pack_bytes;
@@ -1034,53 +1029,6 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
                                   (p->nt1 == 4 && p->direct && p->edge && n_red <= (compute_dtype == AGGF_F64 ? 400 : 480)));
   p->parts = 1;
   p->wide256 = wide_fits && p->nt1 == 1 && n_red > 112 && !has_groups;
-  // The producer-consumer streaming kernel (aggf_gram_ws.h): up to 512 reduced columns, whatever the layout, when two
-  // panel buffers and two stages of raw frames fit the LDS.  AGGF_GRAM_WS: 0 = never, 1 = wherever it fits
-  // (measurement); default: the routing table below.
-  {
-    const char* ws_env = getenv("AGGF_GRAM_WS");  // (read per call: tests and tools compare the two kernels in one process)
-    const int n16 = (int)round_up(n_red, 16);
-    const size_t s_in = dtype_size(in_dtype), s_c = dtype_size(compute_dtype);
-    auto lds_need = [&](int kbs) {
-      const size_t panel = (size_t)kbs * ws_row_stride(n16) * s_c;
-      const size_t raw = (size_t)round_up(round_up((int64_t)kbs * 3 * N * (int64_t)s_in, 16) + 16, 1024);
-      const size_t tab = (size_t)round_up(((int64_t)N + n16 + 1) * 4, 16) + (size_t)3 * n16 * 4 * 2;
-      return 2 * panel + 2 * raw + tab;
-    };
-    const size_t lds_max = 160 * 1024 - 512;
-    // (a stage's frames travel through 12 x 16 B x 256 producer threads = 48 KB of registers at most)
-    auto stage_ok = [&](int kbs) { return lds_need(kbs) <= lds_max && (int64_t)kbs * 3 * N * (int64_t)s_in <= 12 * 256 * 16; };
-    const bool ws_ok = n_red <= 512 && aligned && !tiles_only && first_col == 0 && N < 21000 && stage_ok(4);
-    const bool ws_on = ws_env ? atoi(ws_env) != 0 : false;
-    if (ws_ok && ws_on && !no_small) {
-      p->staging = STAGE_WS;
-      p->n_entries = 1;
-      p->direct = true;
-      p->chunk_frames = T;
-      p->pack_bytes = 0;
-      p->ws_kbs = stage_ok(8) ? 8 : 4;
-      const int nb16 = n16 / 16, n_blocks = nb16 * (nb16 + 1) / 2;
-      const int max_c = compute_dtype == AGGF_F64 ? ws_max_c<double>() : ws_max_c<float>();
-      p->parts = (int)ceil_div((int64_t)n_blocks, WS_CONS * max_c);
-      const int per_part = (int)ceil_div((int64_t)n_blocks, p->parts);
-      p->ws_c = (int)round_up(ceil_div((int64_t)per_part, WS_CONS), 2);  // (instantiated for even C)
-      int64_t nwg = device_cu_count() / p->parts;
-      if (nwg < 1) nwg = 1;
-      const int64_t n_stage_all = ceil_div(T, p->ws_kbs);
-      if (nwg > n_stage_all) nwg = n_stage_all;
-      const int64_t edge = n16 <= TILE ? TILE : (n16 <= 2 * TILE ? 2 * TILE : 4 * TILE);
-      const size_t slab1s = (size_t)p->parts * edge * edge * s_c;
-      if (!query) {
-        if (ws_bytes < table_bytes(*p) + slab1s + 512) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small");
-        const int64_t max_splits = (int64_t)((ws_bytes - table_bytes(*p) - 512) / slab1s);
-        if (nwg > max_splits) nwg = max_splits;
-      }
-      p->frames_per_split = 0;
-      p->ksplit = (int)nwg;
-      p->slab_bytes = (size_t)p->ksplit * slab1s;
-      return AGGF_OK;
-    }
-  }
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
   if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide || p->wide256) && !no_small && !tiles_only && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
@@ -1233,54 +1181,6 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   int32_t* tile_table = reinterpret_cast<int32_t*>(ws);
   ws += table_bytes(p);
   TC* slabs = reinterpret_cast<TC*>(ws);
-  if (p.staging == STAGE_WS) {
-    const WsLds l = ws_lds<TIn, TC>(N, n_red, p.ws_kbs);
-    const int n16 = (int)round_up(n_red, 16);
-    const int edge = n16 <= TILE ? TILE : (n16 <= 2 * TILE ? 2 * TILE : 4 * TILE);
-    const unsigned grid = (unsigned)(p.ksplit * p.parts);
-#define AGGF_WS(KBC, CC)                                                                                             \
-  do {                                                                                                               \
-    static thread_local PerDeviceOnce attr_once;                                                                     \
-    bool& attr_done = *attr_once.flag();                                                                             \
-    if (!attr_done) {                                                                                                \
-      AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_ws_kernel<TIn, TC, KBC, CC>,                                 \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));                      \
-      attr_done = true;                                                                                              \
-    }                                                                                                                \
-    AGGF_LAUNCH((gram_ws_kernel<TIn, TC, KBC, CC>), dim3(grid), dim3(WS_THREADS), l.total, stream,                   \
-                reinterpret_cast<const TIn*>(Fv), T, N, grp_ptr, grp_atoms, n_red, (int32_t)p.ksplit, (int32_t)p.parts,  \
-                (int32_t)edge, (int32_t)l.raw_bytes, slabs);                                                         \
-  } while (0)
-#define AGGF_WS_C(KBC)                                                                                               \
-  do {                                                                                                               \
-    switch (p.ws_c) {                                                                                                \
-      case 2: AGGF_WS(KBC, 2); break;                                                                                \
-      case 4: AGGF_WS(KBC, 4); break;                                                                                \
-      case 6: AGGF_WS(KBC, 6); break;                                                                                \
-      case 8: AGGF_WS(KBC, 8); break;                                                                                \
-      case 10: AGGF_WS(KBC, 10); break;                                                                              \
-      case 12: AGGF_WS(KBC, 12); break;                                                                              \
-      case 14: if constexpr (ws_max_c<TC>() >= 14) { AGGF_WS(KBC, 14); break; }                                     \
-      case 16: if constexpr (ws_max_c<TC>() >= 16) { AGGF_WS(KBC, 16); break; }                                     \
-      default: return fail(AGGF_ERR_ARG, "aggf_gram: producer-consumer kernel: bad block count");                    \
-    }                                                                                                                \
-  } while (0)
-    if (p.ws_kbs == 8) AGGF_WS_C(8); else AGGF_WS_C(4);
-#undef AGGF_WS_C
-#undef AGGF_WS
-    AGGF_LAUNCH_OK();
-    if (edge == 4 * TILE)
-      AGGF_LAUNCH_GATED(256, (gram_reduce_small_kernel<TC, 4 * TILE>), dim3(4 * TILE), dim3(1024), 0, stream, slabs, p.ksplit,
-                        n_red, accumulate, G, p.parts);
-    else if (edge == 2 * TILE)
-      AGGF_LAUNCH_GATED(256, (gram_reduce_small_kernel<TC, 2 * TILE>), dim3(2 * TILE), dim3(4 * TILE), 0, stream, slabs, p.ksplit,
-                        n_red, accumulate, G, p.parts);
-    else
-      AGGF_LAUNCH_GATED(256, (gram_reduce_small_kernel<TC, TILE>), dim3(TILE), dim3(2 * TILE), 0, stream, slabs, p.ksplit, n_red,
-                        accumulate, G, p.parts);
-    AGGF_LAUNCH_OK();
-    return AGGF_OK;
-  }
   if (p.staging == STAGE_SMALL) {
     constexpr int threads = 512;
     // panel width 32 / 64 / 128 reduced columns with 32 / 16 / 8 frames per stage (see gram_small_kernel); the wider
