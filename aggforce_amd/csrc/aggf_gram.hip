@@ -15,6 +15,7 @@
 #include <stdlib.h>
 
 #include "aggf_common.h"
+#include "aggf_routing.h"
 
 #include <type_traits>
 
@@ -1024,13 +1025,20 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   // against ~17 ms, 360 atoms 18.6 against 12.5; four tiles: the EDGE form wins
   // from ~400 columns with float64 products -- 448 atoms 16.5 against 24.5 ms -- and from ~480 with float32 -- 400 atoms
   // 19.6 against 13.2)
-  const bool wide = wide_fits && (p->nt1 == 2 || (p->nt1 == 3 && (!p->direct || (p->edge && n_red <= 320))) ||
-                                  (p->nt1 == 4 && !p->direct && n_red <= (compute_dtype == AGGF_F64 ? 480 : 512)) ||
-                                  (p->nt1 == 4 && p->direct && p->edge && n_red <= (compute_dtype == AGGF_F64 ? 400 : 480)));
+  // The thresholds are the constants of aggf_routing.h, generated from profiles/r05_routing.json (the measured crossovers;
+  // tools/routing_sweep.py re-measures them).  AGGF_GRAM_ROUTE (measurement; read per call): "stream" = the streaming
+  // kernel wherever it can run, "tile" = never.
+  const char* route = getenv("AGGF_GRAM_ROUTE");
+  const bool force_stream = route && route[0] == 's', force_tile = route && route[0] == 't';
+  const bool f64p = compute_dtype == AGGF_F64;
+  const bool wide = wide_fits && (p->nt1 == 2 || (force_stream && p->nt1 <= 4) ||
+                                  (p->nt1 == 3 && (!p->direct || (p->edge && n_red <= routing::stream_edge3_max_cols))) ||
+                                  (p->nt1 == 4 && !p->direct && n_red <= (f64p ? routing::stream_pack4_max_cols_f64 : routing::stream_pack4_max_cols_f32)) ||
+                                  (p->nt1 == 4 && p->direct && p->edge && n_red <= (f64p ? routing::stream_edge4_max_cols_f64 : routing::stream_edge4_max_cols_f32)));
   p->parts = 1;
-  p->wide256 = wide_fits && p->nt1 == 1 && n_red > 112 && !has_groups;
+  p->wide256 = wide_fits && p->nt1 == 1 && n_red > routing::wide256_min_cols && !has_groups;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
-  if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide || p->wide256) && !no_small && !tiles_only && N < 21000 && aligned) {
+  if (((p->nt1 == 1 && raw_small <= (size_t)SM_MAXVEC * 64 * 8 * 16) || wide || p->wide256) && !no_small && !force_tile && !tiles_only && N < 21000 && aligned) {
     // one output tile: the fused streaming kernel (group sums + conversion on the way into LDS, upper
     // triangle blocks only); one slab per workgroup, 2 workgroups per CU over the frame axis
     p->staging = STAGE_SMALL;
@@ -1308,7 +1316,7 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   // (up to 1024 columns the tile kernel is short against the pack pass and the throttled pack beside it loses: 700 atoms
   // 31.0 against 27.1 ms, 1000 atoms 32.9 against 31.4 -- serial there; the min-frames hook still reaches the pipeline)
   bool overlap = !(pack_env && pack_env[0] == 's') && T >= 2 * PACK_MIN_FRAMES && p.chunk_frames / 2 >= PACK_MIN_FRAMES &&
-                 (p.n_pad > 1024 || min_env);
+                 (p.n_pad > routing::pack_overlap_min_pad || min_env);
   const bool same_stream = pack_env && pack_env[0] == 'c';  // (measurement: the overlapped form's chunks, one stream)
   PackPipe* pipe = overlap ? pack_pipe() : nullptr;
   if (overlap && !pipe) overlap = false;  // no side stream: the serial form

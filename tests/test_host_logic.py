@@ -488,3 +488,17 @@ def test_no_test_module_defines_a_name_twice():
                         dups.append(f"{os.path.basename(path)}: {prefix}{node.name} at lines {seen[node.name]} and {node.lineno}")
                     seen[node.name] = node.lineno
     assert not dups, "duplicate definitions shadow tests:\n" + "\n".join(dups)
+
+
+def test_routing_header_is_generated_from_the_committed_table():
+    """make_plan's thresholds (which kernel a system takes) are constants generated from profiles/r05_routing.json, the
+    table tools/routing_sweep.py measures -- not numbers typed into the planner."""
+    import subprocess
+
+    rc = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_routing.py"), "--check"], stdout=subprocess.PIPE)
+    assert rc.returncode == 0, rc.stdout.decode()
+    src = open(os.path.join(ROOT, "aggforce_amd", "csrc", "aggf_gram.hip")).read()
+    import json
+
+    for name in json.load(open(os.path.join(ROOT, "profiles", "r05_routing.json")))["thresholds"]:
+        assert f"routing::{name}" in src, name

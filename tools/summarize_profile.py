@@ -43,7 +43,7 @@ if stats:
              "avg_ms": float(r["AverageNs"]) / 1e6, "pct": float(r["Percentage"])} for r in rows]
     keep.sort(key=lambda x: -x["total_ms"])
     summary["kernel_stats"] = keep[:25]
-for name in ("fetch", "write", "dram", "mfma"):
+for name in ("fetch", "write", "dram", "mfma", "insts"):
     f = find(name, "*counter_collection.csv")
     if not f:
         continue
