@@ -781,8 +781,12 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
   //         register-staged kernel: 105.4-105.8) -- the staging was never the limiter; what the DMA form buys is the
   //         single fetch of P: rocprofv3 FETCH_SIZE x 2 = 109.5 GB per launch against 202.3 GB (98.3 GB algorithmic).
   const int bar_kk = (MODE == 2 && wave >= NW / 2) ? 1 : 3;
-  for (int it = 0; it < n_stage; ++it) {
-    const double* buf = smem + (it % NBUF) * BUF;
+  // One stage.  SLOT (the ring slot, a compile-time constant in the three-slot form below) puts the slot's base into the
+  // immediate offset of the LDS reads.  The operand offsets are lane-dependent in a way no single base covers (the
+  // rotated chunks), i.e. 16 address registers; with the slot base added at run time every read cost a vector add --
+  // 20 of the 1.7 non-MFMA vector instructions per MFMA of this kernel (rocprofv3: SQ_INSTS_VALU / MFMA = 2.7 against
+  // 1.6 in K1), and float64 MFMAs share their SIMD's vector datapath with them.
+  auto stage = [&](int it, const double* buf) {
     const bool issue_now = it + 2 < n_stage;
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -809,6 +813,19 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], bq[n], acc[n][d]);
     }
+  };
+  if constexpr (NBUF == 3) {
+    // three stages per pass: the slot of each is a constant
+    int it = 0;
+    for (; it + 2 < n_stage; it += 3) {
+      stage(it, smem);
+      stage(it + 1, smem + BUF);
+      stage(it + 2, smem + 2 * BUF);
+    }
+    if (it < n_stage) stage(it, smem);
+    if (it + 1 < n_stage) stage(it + 1, smem + BUF);
+  } else {
+    for (int it = 0; it < n_stage; ++it) stage(it, smem + (it % NBUF) * BUF);
   }
 
   double ss = 0.0;

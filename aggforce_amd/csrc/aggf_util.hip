@@ -468,6 +468,13 @@ extern "C" int aggf_sym_unpack_upper(const double* packed, int32_t n, int32_t ba
   if (n <= 0 || batch <= 0 || batch > 65535 || n > 65535 * 32) return fail(AGGF_ERR_ARG, "aggf_sym_unpack_upper: bad size");
   const int64_t per = (int64_t)n * (n + 1) / 2;
   const unsigned nt = (unsigned)((n + 31) / 32);
+  {
+    // every workgroup reads its part of `packed` and writes two tiles of G: the buffers must not overlap (unpacking a
+    // triangle into its own storage would let one workgroup overwrite what another still reads)
+    const uintptr_t p0 = (uintptr_t)packed, p1 = p0 + (uintptr_t)batch * per * 8, g0 = (uintptr_t)G,
+                    g1 = g0 + (uintptr_t)batch * n * n * 8;
+    if (p0 < g1 && g0 < p1) return fail(AGGF_ERR_ARG, "aggf_sym_unpack_upper: packed and G overlap");
+  }
   AGGF_LAUNCH_GATED(1024, sym_unpack_kernel, dim3(nt, nt, (unsigned)batch), dim3(256), 0, stream, packed, n, per, G,
                      (int64_t)n * n);
   AGGF_LAUNCH_OK();
