@@ -825,7 +825,13 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
     if (it < n_stage) stage(it, smem);
     if (it + 1 < n_stage) stage(it + 1, smem + BUF);
   } else {
-    for (int it = 0; it < n_stage; ++it) stage(it, smem + (it % NBUF) * BUF);
+    static_assert(NBUF == 2, "ring of two or three slots");
+    int it = 0;
+    for (; it + 1 < n_stage; it += 2) {
+      stage(it, smem);
+      stage(it + 1, smem + BUF);
+    }
+    if (it < n_stage) stage(it, smem);
   }
 
   double ss = 0.0;
