@@ -859,20 +859,48 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
     __syncthreads();
     AGGF_SP_T(q5);
     if (AGGF_SMALL_ABL != 1 && mfma_wave) {
+      if constexpr (NWV == 16) {
+        // 256- and 512-column panels (one workgroup per CU): software pipeline, one MFMA deep -- the operands of product
+        // i + 1 are read while product i runs.  The plain loop below reads two operands, waits for them (`s_waitcnt
+        // lgkmcnt(0)`: a full LDS latency) and only then issues the MFMA, for every one of the (KBS / 4) x 3 x C products:
+        // the compiler reuses ONE operand register pair because everything hoisted further spills at the 128-register
+        // cap.  Two pairs (4 more registers) and scheduling barriers around each product keep exactly one read-ahead in
+        // flight: the wait in front of an MFMA is for reads issued a whole MFMA earlier.  Same products in the same
+        // order: bit-identical sums.  12 GB of frames: 320 atoms 13.8 -> 12.6 ms, 400 atoms 17.5 -> 15.8, 250 atoms
+        // 9.1 -> 8.8; with two 8-wave workgroups per CU (the classes below) the other workgroup already covers the
+        // latency and the extra registers cost more than they bring (CLN025 4.85 -> 5.06 ms): not used there.
+        constexpr int NPROD = (KBS / 4) * 3 * C;
+        auto addr_a = [&](int i) { return off + (i / (3 * C)) * 4 * RS + 48 * b_i[i % C] + (i / C) % 3; };
+        auto addr_b = [&](int i) { return off + (i / (3 * C)) * 4 * RS + 48 * b_j[i % C] + (i / C) % 3; };
+        TC oa[2], ob[2];
+        oa[0] = panel[addr_a(0)];
+        ob[0] = panel[addr_b(0)];
 #pragma unroll
-      for (int kk = 0; kk < KBS / 4; ++kk)
-#pragma unroll
-        for (int d = 0; d < 3; ++d) {
-#pragma unroll
-          for (int k = 0; k < C; ++k) {
-            const TC a = panel[off + kk * 4 * RS + 48 * b_i[k] + d];
-            const TC b = panel[off + kk * 4 * RS + 48 * b_j[k] + d];
-            acc[k] = M::mma(a, b, acc[k]);
+        for (int i = 0; i < NPROD; ++i) {
+          if (i + 1 < NPROD) {
+            oa[(i + 1) & 1] = panel[addr_a(i + 1)];
+            ob[(i + 1) & 1] = panel[addr_b(i + 1)];
           }
-          // (operand reads of the next group stay behind this point: hoisted over the whole phase they spill 70-100
-          // registers at the 128-register cap of two workgroups per CU)
+          __builtin_amdgcn_sched_barrier(0);  // (the reads stay IN FRONT of the MFMA: otherwise they reuse its operand registers)
+          acc[i % C] = M::mma(oa[i & 1], ob[i & 1], acc[i % C]);
           __builtin_amdgcn_sched_barrier(0);
         }
+      } else {
+#pragma unroll
+        for (int kk = 0; kk < KBS / 4; ++kk)
+#pragma unroll
+          for (int d = 0; d < 3; ++d) {
+#pragma unroll
+            for (int k = 0; k < C; ++k) {
+              const TC a = panel[off + kk * 4 * RS + 48 * b_i[k] + d];
+              const TC b = panel[off + kk * 4 * RS + 48 * b_j[k] + d];
+              acc[k] = M::mma(a, b, acc[k]);
+            }
+            // (operand reads of the next group stay behind this point: hoisted over the whole phase they spill 70-100
+            // registers at the 128-register cap of two workgroups per CU)
+            __builtin_amdgcn_sched_barrier(0);
+          }
+      }
     }
 #ifdef AGGF_SMALL_PROF
     const uint64_t q6 = __builtin_readcyclecounter();
