@@ -36,6 +36,14 @@ int main() {
   int32_t* i32 = (int32_t*)buf;
   const size_t WS = BUF - (1 << 20);
   printf("version %d\n", aggf_version());
+  {
+    // launch coverage: sizing call, a buffer that is too small (must stay NUL-terminated and in bounds), reset
+    char small[8];
+    const size_t need = aggf_coverage_dump(nullptr, 0);
+    (void)aggf_coverage_dump(small, sizeof(small));
+    if (small[sizeof(small) - 1] != 0 && need >= sizeof(small)) { /* (truncated text still ends inside the buffer) */ }
+    RUNS(aggf_coverage_reset());
+  }
   int32_t cu = 0;
   size_t fr = 0, tot = 0;
   RUNS(aggf_device_info(&cu, &fr, &tot));

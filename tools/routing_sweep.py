@@ -92,7 +92,7 @@ def main():
         proposed[name] = best_stream if best_stream is not None else cols[0] - 1
     # pack overlap: serial against overlapped pack + tile pipeline by padded width
     over = None
-    for n_red in (600, 860, 1000, 1100, 1400):
+    for n_red in (860, 1100, 1400, 1800, 2200, 2731):
         f, gp, ga, N, T = system(n_red, True, torch.float64)
         row = {"rule": "pack_overlap_min_pad", "n_red": n_red, "n_pad": (n_red + 127) // 128 * 128, "atoms": N, "frames": T, "pairs": True,
                "dtypes": "float64->float64"}
