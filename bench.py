@@ -172,12 +172,12 @@ def replicated_spread(t, world):
 
 def profiled_traffic(workload, world):
     """HBM-side bytes per launch of the Gram kernel from the committed rocprofv3 PMC passes
-    (profiles/r04_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
+    (profiles/r05_c3_rocprof_summary.json; separate runs by construction).  FETCH_SIZE is in KiB
     and counts 128-byte requests as 64 bytes on gfx950 (MI355X_MICROARCH.md, HBM): x 2."""
     if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_rocprof_summary.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_c3_rocprof_summary.json")))
         rd = [e["FETCH_SIZE"]["per_dispatch"] for e in d["pmc_fetch"] if "gram_tile" in e["kernel"]][0]
         wr = [e["WRITE_SIZE"]["per_dispatch"] for e in d.get("pmc_write", []) if "gram_tile" in e["kernel"]]
         return 2.0 * rd * 1024 + (wr[0] * 1024 if wr else 0.0)
@@ -188,7 +188,7 @@ def profiled_traffic(workload, world):
 def profile_label():
     """Where `traffic` / `mfma_busy_frac_pmc` come from: PMC passes are separate rocprofv3 runs by construction, so
     the line quotes the committed profile and says which one (file, and the tree / date recorded inside it)."""
-    rel = "profiles/r04_c3_rocprof_summary.json"
+    rel = "profiles/r05_c3_rocprof_summary.json"
     label = f"{rel} (separate rocprofv3 --pmc passes; NOT measured in this run)"
     try:
         src = json.load(open(os.path.join(ROOT, rel))).get("profiled_from") or {}
@@ -201,11 +201,11 @@ def profile_label():
 
 def profiled_mfma_busy(workload, world):
     """Fraction of the Gram kernel's cycles in which the MFMA pipes were busy, from the committed PMC pass
-    (profiles/r04_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
+    (profiles/r05_c3_mfma_counters.json: SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x GRBM_GUI_ACTIVE / 8))."""
     if workload != "c3" or world != 1 or VARIANT != "none":
         return None
     try:
-        d = json.load(open(os.path.join(ROOT, "profiles", "r04_c3_mfma_counters.json")))
+        d = json.load(open(os.path.join(ROOT, "profiles", "r05_c3_mfma_counters.json")))
         return [v["mfma_utilisation"] for k, v in d["kernels"].items() if "gram_tile" in k][0]
     except Exception:
         return None
@@ -546,8 +546,10 @@ def main():
             achieved = algo_bytes / (gram_ms * 1e-3) / 1e9
             roof = {"kernel": f"aggf_gram = {gram_kernel_name(launched, 'gram_small_kernel')} (fused group sums, one pass over F) + gram_reduce_small_kernel",
                     "bound": "hbm", "co_limited_by": "hbm+mfma+lds: per frame and CU 403 cycles of HBM, 336 of MFMA (28 upper-triangle "
-                    "16x16 blocks), ~230 of LDS; ablations in profiles/r04_small_ablate.jsonl (no MFMA phase 2.86 ms, no loads "
-                    "4.05, no group sums 3.73, complete 4.79)",
+                    "16x16 blocks), ~340 of group sums; float64 MFMAs occupy their SIMD's vector datapath, so sums and MFMAs add up "
+                    "instead of overlapping whatever the wave roles (profiles/r05_ws_ablation_*.txt; the stream itself reaches "
+                    "6.4-7.1 TB/s: profiles/r05_ldsdma_fill.jsonl): floor ~0.48 of 8 TB/s for this formulation; ablations in "
+                    "profiles/r04_small_ablate.jsonl (no MFMA phase 2.86 ms, no loads 4.05, no group sums 3.73, complete 4.79)",
                     "achieved": achieved, "peak": 8000.0, "unit": "GB/s", "frac": achieved / 8000.0,
                     "traffic": None, "ms_per_launch": gram_ms, "bytes_per_launch": algo_bytes,
                     "flops_per_launch": flops, "mfma_tflops": flops / (gram_ms * 1e-3) / 1e12}
