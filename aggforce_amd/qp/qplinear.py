@@ -67,15 +67,19 @@ def _one_hot_rows(A: np.ndarray):
     return cols if len(np.unique(cols)) == m else None
 
 
-def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host, what: str = "Map optimization", pins=None):
+def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host, what: str = "Map optimization", pins=None,
+                           pins_dev=None):
     """Run K2 for all rows of A at once; returns (X device (m, n), stats host).  ``pins`` (int32 array): the rows of
-    A are unit vectors at these columns (A_host may then be None); otherwise A_host is inspected for that."""
+    A are unit vectors at these columns (A_host may then be None); otherwise A_host is inspected for that.
+    ``pins_dev``: ``pins`` already on the device of G (a pageable upload here is a blocking copy: the host would wait
+    for the Gram kernel in flight before it can queue the solve)."""
     import torch
 
     dev = G.device
     if pins is None:
         A_host = np.ascontiguousarray(A_host, dtype=np.float64)
         pins = _one_hot_rows(A_host)
+        pins_dev = None
     A = None
 
     def solve(l2, n_refine=1):
@@ -83,7 +87,10 @@ def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host, what: s
         if pins is not None:
             # every row of A is a unit vector (slice coordinate map): the constraints pin variables, one
             # factorisation of the free block does it (aggf_eq_qp_solve_pinned)
-            return K.eq_qp_solve_pinned(G, l2, l2_diag, torch.from_numpy(pins).to(dev))
+            nonlocal pins_dev
+            if pins_dev is None:
+                pins_dev = torch.from_numpy(pins).to(dev)
+            return K.eq_qp_solve_pinned(G, l2, l2_diag, pins_dev)
         if A is None:
             A = torch.from_numpy(A_host).to(dev)
         return K.eq_qp_solve(G, l2, l2_diag, A, n_refine=n_refine)
@@ -143,15 +150,18 @@ class LinearProblem:
             self.grp_ptr = torch.from_numpy(self._csr[0]).to(device)
             self.grp_atoms = torch.from_numpy(self._csr[1]).to(device)
         self.sizes = torch.from_numpy(np.bincount(self.goa, minlength=self.n_red).astype(np.float64)).to(device)
-        self._goa_d = None
+        self._goa_d = torch.from_numpy(self.goa).to(device)  # for tmap(): uploaded while the device is still idle
         # a slice coordinate map (the map object caches its row -> atom index): A = M C has unit rows at the reduced
         # variables of the mapped atoms -- the pinned variables of aggf_eq_qp_solve_pinned; A itself is not formed
-        self.pins = None
+        self.pins = self._pins_d = None
         idx = coord_map._onehot_index() if hasattr(coord_map, "_onehot_index") else None
         if idx is not None and len(idx) < self.n_red:
             pins = self.goa[idx].astype(np.int32)
             if len(np.unique(pins)) == len(pins):
                 self.pins = pins
+                # uploaded now, before the Gram kernel is queued: the copy of a pageable array blocks the host until
+                # the device is idle, and behind the Gram kernel it would hold back the launches of the solve
+                self._pins_d = torch.from_numpy(pins).to(device)
 
     @property
     def A(self) -> np.ndarray:
@@ -182,7 +192,7 @@ class LinearProblem:
 
     def solve(self, G, l2_regularization: float = 0.0):
         X, _ = solve_constrained_maps(G, float(l2_regularization), self.sizes, self.A if self.pins is None else None,
-                                      pins=self.pins)
+                                      pins=self.pins, pins_dev=self._pins_d)
         return X
 
     def tmap(self, X) -> SeperableTMap:

@@ -38,3 +38,5 @@ for _ in range(30):
     project_forces(coords, forces, cmap, constrained_inds=set())
 torch.cuda.synchronize()
 print("ms per step without the profiler: %.3f" % ((time.perf_counter() - t0) / 30 * 1e3))
+print("---- who calls the synchronising tensor methods")
+st.print_callers(r"method 'to' of|method 'item' of|method 'cpu' of")
