@@ -4,7 +4,9 @@
 // `reg_mat.T @ reg_mat`).  Three kernels:
 //   pack_groups_kernel   (T,N,3) -> (T,n_pad,3): constraint-group column sums, dtype
 //                        conversion and zero padding to a multiple of 128 columns
-//                        (skipped when the input already has that shape and dtype);
+//                        (skipped when the tile kernel can read the input where it lies: no
+//                        groups, rows of whole 16-byte pieces, the product dtype -- or float32
+//                        frames with float64 products, widened out of LDS);
 //   gram_tile_dma_kernel split-K SYRK: one 128x128 upper-triangle tile x one frame
 //                        range per workgroup, MFMA 16x16x4 (f64 or f32), frame rows
 //                        staged through LDS exactly as they lie in HBM -- the
@@ -206,17 +208,20 @@ constexpr int dma_pieces_upto(int groups, int ppw, int g) {
 // LDS slots are zeroed once and stay zero -- and a piece without an active lane does not count in vmcnt, so the
 // counted waits take their numbers from wave-uniform tallies instead of the template's constants.
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, int ES = 0,
-          bool ES_DMA_AFTER = false, bool TWO = false, bool EDGE = false>
+          bool ES_DMA_AFTER = false, bool TWO = false, bool EDGE = false, typename TS = T>
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
-    const T* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
+    const TS* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs,
-    const T* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0, int32_t row_elems = 0) {
+    const TS* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0, int32_t row_elems = 0) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
-  constexpr int KB = GramCfg<T>::KB;
-  constexpr bool F32 = sizeof(T) == 4;
-  constexpr int PE = DmaCfg<T>::PIECE_ELEMS;
-  constexpr int UNITS = DmaCfg<T>::UNITS;
+  // TS: the type of the frames in HBM and in the LDS ring (its stage layout and row count); T: the type of the products.
+  // TS = float with T = double: float32 frames staged as they lie, every MFMA operand widened on its way out of LDS
+  // (v_cvt_f64_f32: exact) -- the reference's float64 products of a float32 trajectory without a converted copy.
+  constexpr int KB = GramCfg<TS>::KB;
+  constexpr bool F32 = sizeof(TS) == 4;
+  constexpr int PE = DmaCfg<TS>::PIECE_ELEMS;
+  constexpr int UNITS = DmaCfg<TS>::UNITS;
   constexpr int PANELS = 2;  // diagonal tiles stage their panel twice (one code path, fixed vmcnt)
   constexpr int PIECES = PANELS * UNITS * 3;         // per stage: 24 for both dtypes
   constexpr int PPW = PIECES / NW;                   // per wave: 6 with 4 waves, 3 with 8
@@ -228,13 +233,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   constexpr int WCOLS = TILE / WN;                   // columns per wave: 64 / 32
   constexpr int NACC = WCOLS / 16;                   // 16-column accumulator tiles per wave: 4 / 2
   constexpr int NTHREADS = 64 * NW;
-  constexpr int PANEL_ELEMS = dma_panel_elems<T>();
+  constexpr int PANEL_ELEMS = dma_panel_elems<TS>();
   constexpr int BUF_ELEMS = PANELS * PANEL_ELEMS;
   constexpr int AHEAD = NBUF - 1;  // stages in flight ahead of the one being computed
   constexpr bool EARLY_SYNC = ES > 0 && SPREAD_DMA && ABL == 0;
 
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  T* smem = reinterpret_cast<T*>(smem_raw);
+  TS* smem = reinterpret_cast<TS*>(smem_raw);
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -264,7 +269,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
   int64_t g_off[PPW];
   int l_off[PPW], p_row[PPW];
   bool c_ok[PPW];
-  const T* g_base[TWO ? PPW : 1];
+  const TS* g_base[TWO ? PPW : 1];
   int64_t g_ld[TWO ? PPW : 1];
   (void)g_base;
   (void)g_ld;
@@ -296,8 +301,8 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
       const int64_t col = (int64_t)(panel ? tj : ti) * ROW_ELEMS;
       g_off[q] = (int64_t)r * ld + col + elem;
     }
-    l_off[q] = panel * PANEL_ELEMS + unit * DmaCfg<T>::UNIT_STRIDE + cp * PE;
-    c_ok[q] = !EDGE || (panel ? tj : ti) * ROW_ELEMS + elem + (int)(16 / sizeof(T)) <= row_elems;
+    l_off[q] = panel * PANEL_ELEMS + unit * DmaCfg<TS>::UNIT_STRIDE + cp * PE;
+    c_ok[q] = !EDGE || (panel ? tj : ti) * ROW_ELEMS + elem + (int)(16 / sizeof(TS)) <= row_elems;
   }
   // EDGE: pieces with an active lane (wave-uniform; the others never count in vmcnt), all and those in front of the
   // early barrier
@@ -331,13 +336,13 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const int s = seq;  // ring slot follows the sequence position
     const int64_t t0 = t_begin + (int64_t)stage_of(seq) * KB;
     if (t0 + KB > t_end) {
-      T* lbase = smem + (s % NBUF) * BUF_ELEMS;
+      TS* lbase = smem + (s % NBUF) * BUF_ELEMS;
       const int first = (int)(t_end - t0);
       for (int e = tid; e < PANELS * (KB - first) * ROW_ELEMS; e += NTHREADS) {
         const int panel = e / ((KB - first) * ROW_ELEMS);
         const int rem = e - panel * (KB - first) * ROW_ELEMS;
         const int r = first + rem / ROW_ELEMS, c = rem % ROW_ELEMS;
-        lbase[panel * PANEL_ELEMS + DmaCfg<T>::row_off(r) + c] = 0;
+        lbase[panel * PANEL_ELEMS + DmaCfg<TS>::row_off(r) + c] = 0;
       }
     }
   };
@@ -347,7 +352,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const int64_t t0 = t_begin + (ABL == 3 ? 0 : ABL == 4 ? (int64_t)(stage_of(s) & 7) * KB : (int64_t)stage_of(s) * KB);
     const bool row_ok = t0 + p_row[q] < t_end && c_ok[q];
     if (row_ok) {
-      const T* src = TWO ? g_base[TWO ? q : 0] + t0 * g_ld[TWO ? q : 0] + g_off[q] : X + t0 * ld + g_off[q];
+      const TS* src = TWO ? g_base[TWO ? q : 0] + t0 * g_ld[TWO ? q : 0] + g_off[q] : X + t0 * ld + g_off[q];
       __builtin_amdgcn_global_load_lds(
           (const __attribute__((address_space(1))) void*)src,
           (__attribute__((address_space(3))) void*)(smem + (s % NBUF) * BUF_ELEMS + l_off[q]), 16, 0, 0);
@@ -366,9 +371,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     for (int n = 0; n < NACC; ++n) acc[m][n] = acc_zero<T>();
   // MFMA operand of row group kk: rows kk*4 + (lane >> 4) -- f64: four consecutive rows; f32: member kk of
   // the four pairs
-  const int offA = (lane >> 4) * DmaCfg<T>::UNIT_STRIDE + 3 * (wm * 64 + (lane & 15));
-  const int offB = PANEL_ELEMS + (lane >> 4) * DmaCfg<T>::UNIT_STRIDE + 3 * (wn * WCOLS + (lane & 15));
-  constexpr int KKS = DmaCfg<T>::KK_STRIDE;
+  const int offA = (lane >> 4) * DmaCfg<TS>::UNIT_STRIDE + 3 * (wm * 64 + (lane & 15));
+  const int offB = PANEL_ELEMS + (lane >> 4) * DmaCfg<TS>::UNIT_STRIDE + 3 * (wn * WCOLS + (lane & 15));
+  constexpr int KKS = DmaCfg<TS>::KK_STRIDE;
 
   if (n_it > 0) issue_stage(0);
   if (AHEAD > 1 && n_it > 1) issue_stage(1);
@@ -397,7 +402,7 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     if (issue_now) {
       if (SPREAD) prep_stage(it + AHEAD); else issue_stage(it + AHEAD);
     }
-    const T* pa = smem + (((ABL == 1 || ABL == 2) ? it % 2 : it % NBUF)) * BUF_ELEMS;
+    const TS* pa = smem + (((ABL == 1 || ABL == 2) ? it % 2 : it % NBUF)) * BUF_ELEMS;
     AGGF_PROF_T(p1);
     T aL[ES > 0 ? ES : 1][4], bL[ES > 0 ? ES : 1][NACC];  // operands of the groups behind an early barrier
     (void)aL;
@@ -416,9 +421,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           for (int h = 0; h < (ESG > 0 ? ESG : 1); ++h) {
             const int kh = (GROUPS - ESG + h) / 3, dh = (GROUPS - ESG + h) % 3;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) aL[h][m] = pa[offA + kh * KKS + 48 * m + dh];
+            for (int m = 0; m < 4; ++m) aL[h][m] = (T)pa[offA + kh * KKS + 48 * m + dh];
 #pragma unroll
-            for (int n = 0; n < NACC; ++n) bL[h][n] = pa[offB + kh * KKS + 48 * n + dh];
+            for (int n = 0; n < NACC; ++n) bL[h][n] = (T)pa[offB + kh * KKS + 48 * n + dh];
           }
         }
         if (ESG > 0 && g >= GROUPS - ESG) {
@@ -428,9 +433,9 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
           for (int n = 0; n < NACC; ++n) bb[n] = bL[g - (GROUPS - ESG)][n];
         } else {
 #pragma unroll
-          for (int m = 0; m < 4; ++m) a[m] = pa[offA + kk * KKS + 48 * m + d];
+          for (int m = 0; m < 4; ++m) a[m] = (T)pa[offA + kk * KKS + 48 * m + d];
 #pragma unroll
-          for (int n = 0; n < NACC; ++n) bb[n] = pa[offB + kk * KKS + 48 * n + d];
+          for (int n = 0; n < NACC; ++n) bb[n] = (T)pa[offB + kk * KKS + 48 * n + d];
         }
         // between the operand reads and the MFMAs of the group: the reads are in flight while the DMA
         // waits to be accepted (before the reads: +3.5 %, after the MFMAs: +1 %, tools/clock_probe.hip)
@@ -982,11 +987,14 @@ struct GramPlan {
   size_t slab_bytes, pack_bytes;
 };
 
-static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t max_splits) {
+static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t max_splits, int stage_rows = 0) {
+  // kb: 4 = float64 products, 8 = float32 (cost per frame and slab size); stage_rows: frames per LDS stage when that is
+  // not kb (float32 frames with float64 products: 8)
+  if (stage_rows <= 0) stage_rows = kb;
   // Minimise a simple time model over the split count k: workgroups run in rounds of `slots`
   // (2 per CU); a workgroup costs its frames plus a fixed prologue/epilogue, and every
   // workgroup writes (and the reducer re-reads) one 128x128 slab.
-  int64_t hi = ceil_div(frames, (int64_t)kb * 8);  // at least 8 stages per split
+  int64_t hi = ceil_div(frames, (int64_t)stage_rows * 8);  // at least 8 stages per split
   if (hi < 1) hi = 1;
   if (hi > max_splits) hi = max_splits;
   if (hi > 1024) hi = 1024;
@@ -1000,7 +1008,7 @@ static int choose_ksplit(int n_tiles, int64_t frames, int kb, int slots, int64_t
   for (int64_t k = 1; k <= hi; ++k) {
     const int64_t blocks = k * n_tiles;
     const double rounds = (double)ceil_div(blocks, slots);
-    const double fpb = (double)round_up(ceil_div(frames, k), kb);
+    const double fpb = (double)round_up(ceil_div(frames, k), stage_rows);
     const double cost = rounds * (fpb + fixed_frames) * us_per_frame + blocks * slab_us;
     if (cost < best_cost * (1.0 - 1e-6)) {
       best_cost = cost;
@@ -1024,8 +1032,10 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
   // in place: no groups, no conversion, 16-byte aligned rows of 16-byte multiples; N % 128 != 0 takes the EDGE form of
   // the tile kernel (aggf_gram_pair's two-array form needs whole panels)
+  // (float32 frames with float64 products too: the tile kernel widens the operands as it reads them from LDS)
   p->edge = N % TILE != 0;
-  p->direct = !has_groups && in_dtype == compute_dtype && aligned &&
+  const bool widen = in_dtype == AGGF_F32 && compute_dtype == AGGF_F64;
+  p->direct = !has_groups && (in_dtype == compute_dtype || (widen && !tiles_only)) && aligned &&
               (!p->edge || (!tiles_only && ((int64_t)3 * N * (int64_t)dtype_size(in_dtype)) % 16 == 0));
   p->staging = STAGE_DMA8;
   static const char* no_small = getenv("AGGF_GRAM_NO_SMALL");  // tests: force the tiled pipeline on small systems
@@ -1059,10 +1069,13 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   const char* route = getenv("AGGF_GRAM_ROUTE");
   const bool force_stream = route && route[0] == 's', force_tile = route && route[0] == 't';
   const bool f64p = compute_dtype == AGGF_F64;
+  const int edge3_max = widen ? routing::stream_edge3_max_cols_widen : routing::stream_edge3_max_cols;
+  const int edge4_max = widen ? routing::stream_edge4_max_cols_widen
+                              : (f64p ? routing::stream_edge4_max_cols_f64 : routing::stream_edge4_max_cols_f32);
   const bool wide = wide_fits && (p->nt1 == 2 || (force_stream && p->nt1 <= 4) ||
-                                  (p->nt1 == 3 && (!p->direct || (p->edge && n_red <= routing::stream_edge3_max_cols))) ||
+                                  (p->nt1 == 3 && (!p->direct || (p->edge && n_red <= edge3_max))) ||
                                   (p->nt1 == 4 && !p->direct && n_red <= (f64p ? routing::stream_pack4_max_cols_f64 : routing::stream_pack4_max_cols_f32)) ||
-                                  (p->nt1 == 4 && p->direct && p->edge && n_red <= (f64p ? routing::stream_edge4_max_cols_f64 : routing::stream_edge4_max_cols_f32)));
+                                  (p->nt1 == 4 && p->direct && p->edge && n_red <= edge4_max));
   p->parts = 1;
   p->wide256 = wide_fits && p->nt1 == 1 && n_red > routing::wide256_min_cols && !has_groups;
   // (16-byte loads per thread and stage <= SM_MAXVEC; 3 N + xyz must fit the 16-bit member table)
@@ -1102,6 +1115,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->n_entries = p->n_tiles - p->first_tile * (p->first_tile + 1) / 2;
   }
   const int kb = compute_dtype == AGGF_F64 ? GramCfg<double>::KB : GramCfg<float>::KB;
+  const int stage_rows = p->direct && widen ? GramCfg<float>::KB : kb;
   const size_t cs = dtype_size(compute_dtype);
   const int slots = 2 * device_cu_count();
   const size_t slab1 = (size_t)p->n_tiles * TILE * TILE * cs;  // one split
@@ -1121,7 +1135,7 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
       if (cf > T) cf = T;
       p->chunk_frames = cf > 0 ? cf : 1;
     }
-    p->ksplit = choose_ksplit(p->n_entries, p->chunk_frames, kb, slots, 1 << 20);
+    p->ksplit = choose_ksplit(p->n_entries, p->chunk_frames, kb, slots, 1 << 20, stage_rows);
     p->slab_bytes = slab1 * p->ksplit;
     p->pack_bytes = p->direct ? 0 : round_up((int64_t)(p->chunk_frames * row_bytes), 256);
     return AGGF_OK;
@@ -1146,21 +1160,21 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   avail = avail > 512 ? avail - 512 : 0;  // room for the 256-byte roundings
   const int64_t max_splits = (int64_t)(avail / slab1);
   if (max_splits < 1) return fail(AGGF_ERR_WORKSPACE, "gram workspace too small for one slab set");
-  p->ksplit = choose_ksplit(p->n_entries, p->chunk_frames, kb, slots, max_splits);
+  p->ksplit = choose_ksplit(p->n_entries, p->chunk_frames, kb, slots, max_splits, stage_rows);
   p->slab_bytes = slab1 * p->ksplit;
   return AGGF_OK;
 }
 
-template <typename T, bool EDGE = false>
-static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs,
+template <typename T, bool EDGE = false, typename TS = T>
+static int launch_gram(const TS* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs,
                        int32_t* tile_table, double* G, int32_t n_red, int accumulate, hipStream_t stream) {
-  constexpr int KB = GramCfg<T>::KB;
+  constexpr int KB = GramCfg<TS>::KB;
   const int ksplit = p.ksplit;
   int64_t fps = round_up(ceil_div(rows, ksplit), KB);
   if (fps < KB) fps = KB;
   const int64_t nblocks = (int64_t)ksplit * p.n_tiles;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "gram grid too large");
-  const size_t lds3 = (size_t)3 * 2 * dma_panel_elems<T>() * sizeof(T);
+  const size_t lds3 = (size_t)3 * 2 * dma_panel_elems<TS>() * sizeof(TS);
   // The stage barrier sits in front of the last MFMA group instead of behind it (its operands are in registers by then,
   // the 8 MFMAs run while the waves meet), and the DMA piece that goes with that group is issued BEHIND the barrier
   // (template ES = 1, ES_DMA_AFTER).  Same box, back to back: float32 c5 60.2 -> 58.6 ms, c2 3.25 -> 3.16 ms; float64
@@ -1170,16 +1184,16 @@ static int launch_gram(const T* X, int64_t rows, int64_t ld, const GramPlan& p, 
   static thread_local PerDeviceOnce attr_once;
   bool& attr_done = *attr_once.flag();
   if (!attr_done) {
-    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE>,
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE, TS>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds3));
     attr_done = true;
   }
   AGGF_LAUNCH(build_tile_table_kernel, dim3(1), dim3(256), 0, stream, p.nt1, tile_table, p.first_tile);
   AGGF_LAUNCH_OK();
   const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
-  AGGF_LAUNCH((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE>), dim3((unsigned)round_up(nblk, 512)),
+  AGGF_LAUNCH((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE, TS>), dim3((unsigned)round_up(nblk, 512)),
                      dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs,
-                     (const T*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0));
+                     (const TS*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0));
   AGGF_LAUNCH_OK();
   AGGF_LAUNCH_GATED(1024, (gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                      slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
@@ -1313,12 +1327,12 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     return AGGF_OK;
   }
   if (p.direct) {
-    // only reachable with TIn == TC
+    // TIn == TC, or float32 frames widened inside the tile kernel
     if (p.edge)
-      return launch_gram<TC, true>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G, n_red,
-                                   accumulate, stream);
-    return launch_gram<TC>(reinterpret_cast<const TC*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,
-                           n_red, accumulate, stream);
+      return launch_gram<TC, true, TIn>(reinterpret_cast<const TIn*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,
+                                        n_red, accumulate, stream);
+    return launch_gram<TC, false, TIn>(reinterpret_cast<const TIn*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,
+                                       n_red, accumulate, stream);
   }
   TC* pack = reinterpret_cast<TC*>(ws + round_up((int64_t)p.slab_bytes, 256));
   const TIn* F = reinterpret_cast<const TIn*>(Fv);

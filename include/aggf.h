@@ -69,7 +69,10 @@ int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes)
  * (then column j is atom j and n_red <= N: only the first n_red atoms are used, the
  * rest of each frame row is ignored -- row padding).  Products are formed in `compute_dtype`
  * (AGGF_F64 reproduces the reference, whose con_mat is float64 even for float32
- * forces; AGGF_F32 uses fp32 MFMA with partial sums combined in fp64).
+ * forces; AGGF_F32 uses fp32 MFMA with partial sums combined in fp64).  float32 F with
+ * AGGF_F64 products and no constraint groups is read in place (rows of whole 16-byte
+ * pieces, i.e. N % 4 == 0, F 16-byte aligned): the operands are widened inside the
+ * kernel, no converted copy is made and the workspace holds partial tiles only.
  * G: (n_red, n_red) float64, full symmetric matrix; accumulate != 0 adds to it
  * (frame chunks, cross-validation folds).  Partial sums are combined in a fixed
  * order: two runs are bit-identical.
@@ -87,8 +90,8 @@ int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dty
  * regression matrix -- the group force sums -- is the same for every site, so its Gram block is
  * formed once and pasted.  No constraint groups here (F is a regression matrix).  Guarantee:
  * with accumulate == 0 every entry outside the leading block is written; the leading block is
- * either left untouched (in-place tile kernel: N % 128 == 0, in_dtype == compute_dtype, F
- * 16-byte aligned) or overwritten with its own correct values (any other layout computes the
+ * either left untouched (in-place tile kernel: N % 128 == 0, in_dtype == compute_dtype or
+ * float32 frames with float64 products, F 16-byte aligned) or overwritten with its own correct values (any other layout computes the
  * whole matrix), so the caller may paste its copy afterwards either way.  accumulate != 0 with
  * first_col > 0 is refused (AGGF_ERR_ARG): the two cases would differ there. */
 int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,

@@ -3,7 +3,9 @@ make_plan both routes are forced (AGGF_GRAM_ROUTE=stream | tile; AGGF_GRAM_PACK=
 systems around the threshold, ~6 GB of frames each; the table's `measurements` are replaced, the crossovers printed,
 and with --accept written into `thresholds` (then run tools/gen_routing.py and rebuild).
 
-    python tools/routing_sweep.py [--accept] [out.json]
+    python tools/routing_sweep.py [--accept] [--only rule1,rule2] [out.json]
+
+--only: re-measure just these rules (the other rules' measurements and thresholds stay as they are).
 """
 import json
 import os
@@ -63,6 +65,9 @@ RULES = [
     ("stream_pack4_max_cols_f32", torch.float32, torch.float32, True, [400, 448, 480, 496, 512]),
     ("stream_edge4_max_cols_f64", torch.float64, torch.float64, False, [392, 400, 424, 448, 472, 504]),
     ("stream_edge4_max_cols_f32", torch.float32, torch.float32, False, [392, 424, 456, 480, 504]),
+    # float32 frames with float64 products, read in place by the widening tile kernel
+    ("stream_edge3_max_cols_widen", torch.float32, torch.float64, False, [264, 288, 304, 320, 336, 352, 376]),
+    ("stream_edge4_max_cols_widen", torch.float32, torch.float64, False, [392, 400, 424, 448, 472, 504]),
 ]
 
 
@@ -70,8 +75,14 @@ def main():
     accept = "--accept" in sys.argv
     out = next((a for a in sys.argv[1:] if a.endswith(".json")), TABLE)
     table = json.load(open(TABLE))
+    only = next((a.split("=", 1)[1] if "=" in a else sys.argv[sys.argv.index(a) + 1] for a in sys.argv[1:] if a.startswith("--only")), None)
+    only = set(only.split(",")) if only else None
     meas, proposed = [], {}
+    if only:
+        meas = [r for r in table.get("measurements", []) if r["rule"] not in only]
     for name, sdt, cdt, pairs, cols in RULES:
+        if only and name not in only:
+            continue
         best_stream = None
         for n_red in cols:
             f, gp, ga, N, T = system(n_red, pairs, sdt)
@@ -92,7 +103,7 @@ def main():
         proposed[name] = best_stream if best_stream is not None else cols[0] - 1
     # pack overlap: serial against overlapped pack + tile pipeline by padded width
     over = None
-    for n_red in (860, 1100, 1400, 1800, 2200, 2731):
+    for n_red in (() if only and "pack_overlap_min_pad" not in only else (860, 1100, 1400, 1800, 2200, 2731)):
         f, gp, ga, N, T = system(n_red, True, torch.float64)
         row = {"rule": "pack_overlap_min_pad", "n_red": n_red, "n_pad": (n_red + 127) // 128 * 128, "atoms": N, "frames": T, "pairs": True,
                "dtypes": "float64->float64"}
@@ -107,9 +118,10 @@ def main():
         meas.append(row)
         print(json.dumps(row), flush=True)
         del f
-    proposed["pack_overlap_min_pad"] = over if over is not None else table["thresholds"]["pack_overlap_min_pad"]["value"]
+    if not only or "pack_overlap_min_pad" in only:
+        proposed["pack_overlap_min_pad"] = over if over is not None else table["thresholds"]["pack_overlap_min_pad"]["value"]
     table["measurements"] = meas
-    table["proposed_by_last_sweep"] = proposed
+    table["proposed_by_last_sweep"] = {**table.get("proposed_by_last_sweep", {}), **proposed} if only else proposed
     for k, v in proposed.items():
         cur = table["thresholds"][k]["value"]
         print(f"{k}: table {cur}, sweep proposes {v}")
