@@ -21,6 +21,17 @@ constexpr int AP_KA = 16;   // atoms per stage
 constexpr int AP_XS = AP_KA * 3 + 2;  // LDS row stride of the P tile (elements)
 constexpr int AP_MS = AP_KA + 2;      // LDS row stride of the M tile
 
+// a 16-byte vector load from an address that is only element-aligned (frame rows of an odd atom count are 8-byte --
+// float64 -- or 4-byte -- float32 -- aligned): still ONE global_load_dwordx4, the memory system takes any byte address
+// (tools/dma_align_probe.hip); through an element-wise loop the 1001-atom apply took 1.75x the time of 1000 atoms
+template <typename V, typename E>
+__device__ __forceinline__ V load_vec_elem_aligned(const E* p) {
+  struct __attribute__((packed, aligned(alignof(E)))) U {
+    V v;
+  };
+  return reinterpret_cast<const U*>(p)->v;
+}
+
 template <typename TC>
 __device__ __forceinline__ TC fix_nan(TC v, bool replace, TC fill) {
   return (replace && v != v) ? fill : v;
@@ -94,7 +105,7 @@ __global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_
         vin_t v;
 #pragma unroll
         for (int e = 0; e < VI; ++e) v[e] = 0;
-        if (c < P_CH && t < T) v = *reinterpret_cast<const vin_t*>(P + t * rowP + (int64_t)a0 * 3 + col);
+        if (c < P_CH && t < T) v = load_vec_elem_aligned<vin_t>(P + t * rowP + (int64_t)a0 * 3 + col);
 #pragma unroll
         for (int e = 0; e < VI; ++e) rp[SET][q][e] = v[e];
       }
@@ -107,7 +118,7 @@ __global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_
         vm_t v;
 #pragma unroll
         for (int e = 0; e < VM; ++e) v[e] = 0;
-        if (c < M_CH && cg < n_cg) v = *reinterpret_cast<const vm_t*>(Mx + (int64_t)cg * N + a0 + col);
+        if (c < M_CH && cg < n_cg) v = load_vec_elem_aligned<vm_t>(Mx + (int64_t)cg * N + a0 + col);
 #pragma unroll
         for (int e = 0; e < VM; ++e) rm[SET][q][e] = v[e];
       }
@@ -125,7 +136,7 @@ __global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_
         const TIn* src = P + t * rowP + e0;
         if (p_vec_ok && e0 + VI <= rowP) {
           typedef TIn __attribute__((ext_vector_type(VI))) vin_t;
-          vin_t v = *reinterpret_cast<const vin_t*>(src);
+          vin_t v = load_vec_elem_aligned<vin_t>(src);
 #pragma unroll
           for (int e = 0; e < VI; ++e) rp[SET][q][e] = v[e];
         } else {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(AP_THREADS, AP_THREADS >= 1024 ? 4 : 2) void apply_
         const TC* src = Mx + (int64_t)cg * N + a;
         if (m_vec_ok && a + VM <= N) {
           typedef TC __attribute__((ext_vector_type(VM))) vm_t;
-          vm_t v = *reinterpret_cast<const vm_t*>(src);
+          vm_t v = load_vec_elem_aligned<vm_t>(src);
 #pragma unroll
           for (int e = 0; e < VM; ++e) rm[SET][q][e] = v[e];
         } else {
@@ -594,8 +605,9 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
       return fail(AGGF_ERR_WORKSPACE, "aggf_linearmap_apply: workspace too small for sumsq");
     partials = reinterpret_cast<double*>(ws);
   }
-  const int p_vec_ok = (((uintptr_t)P & 15) == 0) && (((int64_t)N * 3 * sizeof(TIn)) % 16 == 0);
-  const int m_vec_ok = (((uintptr_t)Mx & 15) == 0) && (((int64_t)N * sizeof(TC)) % 16 == 0);
+  // 16-byte loads wherever a chunk lies inside its row: the pointers need element alignment only
+  const int p_vec_ok = ((uintptr_t)P % sizeof(TIn)) == 0;
+  const int m_vec_ok = ((uintptr_t)Mx % sizeof(TC)) == 0;
   const size_t lds = (size_t)2 * (TF * AP_XS + TCB * AP_MS) * sizeof(TC);
   if (lds > 65536) {
     static thread_local PerDeviceOnce once_t, once_f;

@@ -204,7 +204,8 @@ constexpr int dma_pieces_upto(int groups, int ppw, int g) {
 // row stride ld; the rest from X2, row stride ld2) -- the noised maps' [forces | generated-site forces], which round 2
 // materialised as one (T, N + n_cg, 3) array twice per step (aggf_gram_pair).
 // EDGE: X is read where it lies although its rows are NOT padded to whole panels (ld = row_elems = 3 N with
-// N % 128 != 0, rows still 16-byte multiples): lanes whose chunk lies past the end of a row issue no DMA -- their
+// N % 128 != 0; rows of whole 16-byte pieces, or `straddle` -- the LDS-DMA takes any byte address,
+// tools/dma_align_probe.hip): lanes whose chunk lies past the end of a row issue no DMA -- their
 // LDS slots are zeroed once and stay zero -- and a piece without an active lane does not count in vmcnt, so the
 // counted waits take their numbers from wave-uniform tallies instead of the template's constants.
 template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool SPREAD_DMA = false, int ES = 0,
@@ -212,7 +213,7 @@ template <typename T, int ABL = 0, int NBUF = 3, int WPS = 2, int NW = 4, bool S
 __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
     const TS* __restrict__ X, int64_t n_rows, int64_t ld, int32_t nt1, int32_t n_tiles, int32_t ksplit,
     const int32_t* __restrict__ tile_table, int64_t frames_per_split, T* __restrict__ slabs,
-    const TS* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0, int32_t row_elems = 0) {
+    const TS* __restrict__ X2 = nullptr, int64_t ld2 = 0, int32_t np1 = 0, int32_t row_elems = 0, int32_t straddle = 0) {
   using M = Mfma<T>;
   using acc_t = typename M::acc_t;
   // TS: the type of the frames in HBM and in the LDS ring (its stage layout and row count); T: the type of the products.
@@ -302,7 +303,10 @@ __global__ __launch_bounds__(64 * NW, WPS) void gram_tile_dma_kernel(
       g_off[q] = (int64_t)r * ld + col + elem;
     }
     l_off[q] = panel * PANEL_ELEMS + unit * DmaCfg<TS>::UNIT_STRIDE + cp * PE;
-    c_ok[q] = !EDGE || (panel ? tj : ti) * ROW_ELEMS + elem + (int)(16 / sizeof(TS)) <= row_elems;
+    // straddle (rows that are not whole 16-byte pieces): the piece that starts inside the row is read although it ends
+    // in the next row -- what it brings beyond the row's end lands in columns past n_red, whose products nobody reads;
+    // the caller keeps the array's last row out of this launch (gram_tail_row_kernel adds it)
+    c_ok[q] = !EDGE || (panel ? tj : ti) * ROW_ELEMS + elem + (straddle ? 1 : (int)(16 / sizeof(TS))) <= row_elems;
   }
   // EDGE: pieces with an active lane (wave-uniform; the others never count in vmcnt), all and those in front of the
   // early barrier
@@ -980,6 +984,7 @@ struct GramPlan {
   bool direct;         // gram kernel reads F in place
   int ksplit;
   bool edge = false;     // tile kernel reads rows that are not padded to whole panels (N % 128 != 0, in place)
+  bool straddle = false; // ... and the rows are not whole 16-byte pieces: the last frame goes through gram_tail_row_kernel
   bool wide256 = false;  // small-system kernel: 113-128 columns on the 256-column panel (16 waves, 3 blocks per wave)
   int parts = 1;       // small-system kernel above 256 columns: workgroups that share a frame range and split the block list
   int64_t frames_per_split;
@@ -1035,8 +1040,14 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   // (float32 frames with float64 products too: the tile kernel widens the operands as it reads them from LDS)
   p->edge = N % TILE != 0;
   const bool widen = in_dtype == AGGF_F32 && compute_dtype == AGGF_F64;
+  const bool rows16 = ((int64_t)3 * N * (int64_t)dtype_size(in_dtype)) % 16 == 0;
+  // rows that are not whole 16-byte pieces (an odd atom count; float32: N % 4 != 0): the piece across a row's end is
+  // read into columns nobody uses, and the array's last row -- behind which nothing may be read -- is added by a
+  // rank-3 update kernel.  Not for aggf_gram_from_column (the caller's leading block must stay what it is).
+  p->straddle = p->edge && !rows16 && !tiles_only && first_col == 0 && T >= 2;
   p->direct = !has_groups && (in_dtype == compute_dtype || (widen && !tiles_only)) && aligned &&
-              (!p->edge || (!tiles_only && ((int64_t)3 * N * (int64_t)dtype_size(in_dtype)) % 16 == 0));
+              (!p->edge || (!tiles_only && (rows16 || p->straddle)));
+  if (!p->direct) p->straddle = false;
   p->staging = STAGE_DMA8;
   static const char* no_small = getenv("AGGF_GRAM_NO_SMALL");  // tests: force the tiled pipeline on small systems
   // The streaming kernel (gram_small_kernel: the frames pass through LDS once, group sums / conversion / padding on the
@@ -1165,9 +1176,23 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   return AGGF_OK;
 }
 
+// G += x x' over the three xyz components of ONE frame (float64 products whatever the dtypes of the call: exact
+// products of the stored values, the same in both triangles): the last frame of an array whose rows are not whole
+// 16-byte pieces (GramPlan::straddle).  A thread owns one entry of G; runs behind gram_reduce_kernel on the stream.
+template <typename TIn>
+__global__ __launch_bounds__(256) void gram_tail_row_kernel(const TIn* __restrict__ row, int32_t n_red, double* __restrict__ G) {
+  const int i = blockIdx.y * 16 + threadIdx.y, j = blockIdx.x * 16 + threadIdx.x;
+  if (i >= n_red || j >= n_red) return;
+  double s = 0.0;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) s += (double)row[3 * i + d] * (double)row[3 * j + d];
+  G[(int64_t)i * n_red + j] += s;
+}
+
 template <typename T, bool EDGE = false, typename TS = T>
 static int launch_gram(const TS* X, int64_t rows, int64_t ld, const GramPlan& p, T* slabs,
-                       int32_t* tile_table, double* G, int32_t n_red, int accumulate, hipStream_t stream) {
+                       int32_t* tile_table, double* G, int32_t n_red, int accumulate, hipStream_t stream,
+                       bool straddle = false) {
   constexpr int KB = GramCfg<TS>::KB;
   const int ksplit = p.ksplit;
   int64_t fps = round_up(ceil_div(rows, ksplit), KB);
@@ -1193,7 +1218,7 @@ static int launch_gram(const TS* X, int64_t rows, int64_t ld, const GramPlan& p,
   const int64_t nblk = (int64_t)ksplit * p.n_entries;  // n_entries = tiles actually computed
   AGGF_LAUNCH((gram_tile_dma_kernel<T, 0, 3, 2, 8, true, 1, true, false, EDGE, TS>), dim3((unsigned)round_up(nblk, 512)),
                      dim3(512), lds3, stream, X, rows, ld, p.nt1, p.n_entries, ksplit, tile_table, fps, slabs,
-                     (const TS*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0));
+                     (const TS*)nullptr, (int64_t)0, 0, (int32_t)(EDGE ? ld : 0), (int32_t)(straddle ? 1 : 0));
   AGGF_LAUNCH_OK();
   AGGF_LAUNCH_GATED(1024, (gram_reduce_kernel<T>), dim3(p.n_tiles, TILE / 8), dim3(256), 0, stream,
                      slabs, p.nt1, ksplit, n_red, accumulate, G, p.first_tile);
@@ -1328,6 +1353,17 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
   }
   if (p.direct) {
     // TIn == TC, or float32 frames widened inside the tile kernel
+    if (p.edge && p.straddle) {
+      // all frames but the last through the tile kernel (the piece across the end of row t reads the head of row t + 1),
+      // the last one as a rank-3 update of G
+      const TIn* F = reinterpret_cast<const TIn*>(Fv);
+      int rc = launch_gram<TC, true, TIn>(F, T - 1, (int64_t)N * 3, p, slabs, tile_table, G, n_red, accumulate, stream, true);
+      if (rc) return rc;
+      AGGF_LAUNCH((gram_tail_row_kernel<TIn>), dim3((unsigned)ceil_div((int64_t)n_red, 16), (unsigned)ceil_div((int64_t)n_red, 16)),
+                  dim3(16, 16), 0, stream, F + (T - 1) * (int64_t)N * 3, n_red, G);
+      AGGF_LAUNCH_OK();
+      return AGGF_OK;
+    }
     if (p.edge)
       return launch_gram<TC, true, TIn>(reinterpret_cast<const TIn*>(Fv), T, (int64_t)N * 3, p, slabs, tile_table, G,
                                         n_red, accumulate, stream);

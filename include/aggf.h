@@ -70,9 +70,10 @@ int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes)
  * rest of each frame row is ignored -- row padding).  Products are formed in `compute_dtype`
  * (AGGF_F64 reproduces the reference, whose con_mat is float64 even for float32
  * forces; AGGF_F32 uses fp32 MFMA with partial sums combined in fp64).  float32 F with
- * AGGF_F64 products and no constraint groups is read in place (rows of whole 16-byte
- * pieces, i.e. N % 4 == 0, F 16-byte aligned): the operands are widened inside the
- * kernel, no converted copy is made and the workspace holds partial tiles only.
+ * AGGF_F64 products and no constraint groups is read in place (F 16-byte aligned): the
+ * operands are widened inside the kernel, no converted copy is made and the workspace
+ * holds partial tiles only.  Rows need not be multiples of 16 bytes (odd N): nothing is
+ * read beyond F + T*3*N elements.
  * G: (n_red, n_red) float64, full symmetric matrix; accumulate != 0 adds to it
  * (frame chunks, cross-validation folds).  Partial sums are combined in a fixed
  * order: two runs are bit-identical.
