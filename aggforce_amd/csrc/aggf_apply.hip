@@ -659,41 +659,53 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
 // frame and component): nan_seen is conservative -- an infinity meeting a zero coefficient sets it too.
 // Workgroups b and b + 8 (same XCD under round-robin dispatch; speed only) take the two 128-site blocks of one frame
 // block: the second reader of a P tile finds it in that XCD's L2.
-constexpr int AD_TC = 128, AD_KA = 16;
-constexpr int AD_M_ELEMS = AD_TC * 16;
+constexpr int AD_KA = 16;
 
 __device__ __forceinline__ void ad_wait_vmcnt(int n) {
-  if (n <= 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  else if (n == 1) asm volatile("s_waitcnt vmcnt(1)" ::: "memory");
-  else if (n == 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
-  else if (n == 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");
-  else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+  // s_waitcnt takes an immediate: dispatch on the (wave-uniform) count
+  switch (n < 0 ? 0 : n) {
+#define AGGF_VMCNT(k) case k: asm volatile("s_waitcnt vmcnt(" #k ")" ::: "memory"); break;
+    AGGF_VMCNT(0) AGGF_VMCNT(1) AGGF_VMCNT(2) AGGF_VMCNT(3) AGGF_VMCNT(4) AGGF_VMCNT(5) AGGF_VMCNT(6) AGGF_VMCNT(7)
+    AGGF_VMCNT(8) AGGF_VMCNT(9) AGGF_VMCNT(10) AGGF_VMCNT(11) AGGF_VMCNT(12) AGGF_VMCNT(13) AGGF_VMCNT(14) AGGF_VMCNT(15)
+#undef AGGF_VMCNT
+    default: asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  }
 }
 
-// TF frames x 128 sites per workgroup, TF / 16 x 4 waves (wave tile 16 frames x 32 sites), NBUF ring slots:
-//   <2, 64, 3> (n_cg > 128): 16 waves, one workgroup per CU (144 KB of LDS), the second wave pair of every SIMD half
-//                         a stage behind; the site blocks of a frame block stay in lock-step and share P through the L2;
-//   <1, 32, 2> (n_cg <= 128): 8 waves, 64 KB of LDS -- two INDEPENDENT workgroups per CU as in K1: one's barrier and
-//                         operand-read phase is covered by the other's MFMAs.
+// TF frames x TCW sites per workgroup, TF / 16 x TCW / 32 waves (wave tile 16 frames x 32 sites), NBUF ring slots:
+//   <2, 64, 3, ., 128> (n_cg > 128): 16 waves, one workgroup per CU (144 KB of LDS), the second wave pair of every SIMD
+//                         half a stage behind; the site blocks of a frame block stay in lock-step and share P through the L2;
+//   <1, 32, 2, ., 128> (n_cg <= 128): 8 waves, 64 KB of LDS -- two INDEPENDENT workgroups per CU as in K1: one's barrier
+//                         and operand-read phase is covered by the other's MFMAs;
+//   <1, 64, ., ., 64>  (n_cg <= 64, round 5): 8 waves on 64 frames x 64 sites, two workgroups per CU.
+// TS (round 5): the type of the frames.  float: a stage's piece of a frame row is 48 floats = 12 chunks of 16 bytes in
+// a row of 16 slots, chunk c of row i in slot (c + i) & 15 (one DMA instruction = 4 rows); an operand read (element
+// e = 3 (4 kk + k') + d of row i: float ((e >> 2) + i & 15) * 4 + (e & 3)) touches 64 different banks -- the 16 rows of
+// a k' group give the 16 slots, and 3 k' mod 4 gives the four k' groups four different floats of a slot; the operand
+// is widened in a register (exact), the map and the result are float64 as in the reference (map/core.py:219-240).
 // c3 (n_cg 256), same box: <2, 64, 3> 105.2-105.3 ms, FETCH x 2 109.5 GB; <1, 32, 2> 103.2-103.9 ms (MFMA-busy 0.86 against
 // 0.83; the dense variant's two applies 194.8 -> 189.6 ms) but FETCH x 2 145.7 GB: its pairs drift apart.
 // With two slots a stage has exactly one stage time to land: spreading its four pieces over the NEXT stage's MFMA groups
 // instead of issuing them right behind the barrier costs 6 % (109.5 ms) -- the kernel is sensitive to landing latency,
 // and a third slot does not fit twice into 160 KB.
-template <int MODE, int TF, int NBUF>
-__global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(const double* __restrict__ P, int64_t T, int32_t N,
-                                                                 const double* __restrict__ Mx, int32_t n_cg, int32_t ncb,
-                                                                 int64_t nfb, double* __restrict__ out,
-                                                                 double* __restrict__ sumsq_partials,
-                                                                 int32_t* __restrict__ nan_seen) {
+template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2>
+__global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void apply_dma_kernel(
+    const TS* __restrict__ P, int64_t T, int32_t N, const double* __restrict__ Mx, int32_t n_cg, int32_t ncb, int64_t nfb,
+    double* __restrict__ out, double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
   using MF = Mfma<double>;
   static_assert(NBUF == 3 || MODE == 1, "two slots: every piece behind the barrier, no stagger");
-  constexpr int NWF = TF / 16, NW = NWF * 4;       // waves along the frames x 4 along the sites
-  constexpr int PP = (TF / 2) / NW, MP = 16 / NW;  // DMA pieces per wave and stage: P (2 rows each), M (8 rows each)
+  constexpr bool F32 = sizeof(TS) == 4;
+  constexpr int TCW = NWS * NCT * 16;             // sites per workgroup: NWS waves along the sites, NCT 16-site tiles each
+  constexpr int NWF = TF / 16, NW = NWF * NWS;    // waves along the frames x along the sites
+  constexpr int RPP = F32 ? 4 : 2;                // frame rows per DMA piece (a row = 64 elements of TS in LDS)
+  constexpr int SLOTS = 64 / RPP;                 // 16-byte slots per row: 32 (24 used) / 16 (12 used)
+  constexpr int USED = F32 ? 12 : 24, EPC = F32 ? 4 : 2;  // chunks of a stage's row piece, elements per chunk
+  constexpr int PP = (TF / RPP) / NW, MP = (TCW / 8 + NW - 1) / NW;  // DMA pieces per wave and stage: P, M (8 rows each)
+  static_assert(PP >= 1 && PP * NW * RPP == TF && TCW % 8 == 0, "piece split");
   constexpr int NPIECE = PP + MP;
-  constexpr int P_ELEMS = TF * 64, BUF = P_ELEMS + AD_M_ELEMS;
+  static_assert(NPIECE <= 16, "ad_wait_vmcnt");
+  constexpr int P_BYTES = TF * 64 * (int)sizeof(TS), BUF_BYTES = P_BYTES + TCW * 16 * 8;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
-  double* smem = reinterpret_cast<double*>(smem_raw);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block -> (frame block, site block): 8 consecutive frame blocks x ncb site blocks per group of 8 ncb workgroups,
@@ -705,31 +717,31 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
   const int64_t fb = grp * 8 + (rem & 7);
   if (fb >= nfb) return;  // (the grid is padded to whole groups; uniform: no barrier has been reached)
   const int64_t t0 = fb * TF;
-  const int c0 = cb * AD_TC;
+  const int c0 = cb * TCW;
   const int64_t rowP = (int64_t)N * 3;
   const int n_stage = N / AD_KA;
 
-  // this wave's DMA pieces: PP pieces of the P tile (2 rows each), then MP pieces of the M tile (8 rows each)
-  const double* gsrc[NPIECE];
+  // this wave's DMA pieces: PP pieces of the P tile (RPP rows each), then MP pieces of the M tile (8 rows each)
+  const char* gsrc[NPIECE];
   int lbase[NPIECE];
   bool ok[NPIECE];
 #pragma unroll
   for (int q = 0; q < PP; ++q) {
     const int pp = wave + NW * q;
-    const int row = 2 * pp + (lane >> 5), slot = lane & 31;
-    const int chunk = (slot - (row & 15)) & 31;
-    ok[q] = chunk < 24 && t0 + row < T;
-    gsrc[q] = P + (t0 + row) * rowP + chunk * 2;
-    lbase[q] = pp * 128;
+    const int row = RPP * pp + lane / SLOTS, slot = lane % SLOTS;
+    const int chunk = (slot - (row & 15)) & (SLOTS - 1);
+    ok[q] = chunk < USED && t0 + row < T;
+    gsrc[q] = reinterpret_cast<const char*>(P + (t0 + row) * rowP + chunk * EPC);
+    lbase[q] = pp * 1024;
   }
 #pragma unroll
   for (int q = 0; q < MP; ++q) {
     const int mp = wave + NW * q;
     const int row = 8 * mp + (lane >> 3), slot = lane & 7;
     const int chunk = (slot - (row >> 1)) & 7;
-    ok[PP + q] = c0 + row < n_cg;
-    gsrc[PP + q] = Mx + (int64_t)(c0 + row) * N + chunk * 2;
-    lbase[PP + q] = P_ELEMS + mp * 128;
+    ok[PP + q] = mp < TCW / 8 && c0 + row < n_cg;
+    gsrc[PP + q] = reinterpret_cast<const char*>(Mx + (int64_t)(c0 + row) * N + chunk * 2);
+    lbase[PP + q] = P_BYTES + mp * 1024;
   }
   // pieces with no active lane are skipped by the hardware and do not count in vmcnt: wave-uniform tallies
   int n_first = 0, n_all = 0;  // (n_first: the two pieces MODE 0 issues in front of the stage barrier)
@@ -744,11 +756,11 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
   auto issue_piece = [&](int s, int q) {
     if (ok[q])
       __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(gsrc[q] + (int64_t)s * (q >= PP ? AD_KA : AD_KA * 3)),
-          (__attribute__((address_space(3))) void*)(smem + (s % NBUF) * BUF + lbase[q]), 16, 0, 0);
+          (const __attribute__((address_space(1))) void*)(gsrc[q] + (int64_t)s * (q >= PP ? AD_KA * 8 : AD_KA * 3 * (int)sizeof(TS))),
+          (__attribute__((address_space(3))) void*)(smem_raw + (s % NBUF) * BUF_BYTES + lbase[q]), 16, 0, 0);
   };
 
-  // MFMA operand offsets (doubles, inside a stage buffer)
+  // MFMA operand offsets inside a stage buffer: elements of TS (P tile), doubles behind P_BYTES (M tile)
   const int wf = wave % NWF, wc = wave / NWF;
   int offA[4][3], offB[4];
   {
@@ -758,19 +770,20 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const int e = 12 * kk + 3 * kq + d;
-        offA[kk][d] = row * 64 + (((e >> 1) + (row & 15)) & 31) * 2 + (e & 1);
+        offA[kk][d] = F32 ? row * 64 + (((e >> 2) + (row & 15)) & 15) * 4 + (e & 3)
+                          : row * 64 + (((e >> 1) + (row & 15)) & 31) * 2 + (e & 1);
       }
-    const int j = 32 * wc + (lane & 15);
+    const int j = 16 * NCT * wc + (lane & 15);  // (the n-th tile of the wave: j + 16 n -- the rotation (j >> 1) & 7 is the same)
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
       const int e = 4 * kk + kq;
-      offB[kk] = P_ELEMS + j * 16 + (((e >> 1) + (j >> 1)) & 7) * 2 + (e & 1);
+      offB[kk] = j * 16 + (((e >> 1) + (j >> 1)) & 7) * 2 + (e & 1);
     }
   }
 
-  f64x4 acc[2][3];
+  f64x4 acc[NCT][3];
 #pragma unroll
-  for (int n = 0; n < 2; ++n)
+  for (int n = 0; n < NCT; ++n)
 #pragma unroll
     for (int d = 0; d < 3; ++d) acc[n][d] = acc_zero<double>();
 
@@ -785,8 +798,8 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
   asm volatile("" ::: "memory");
 
   // MODE 0: pieces 0, 1 of stage it + 2 beside the first two MFMA groups, piece 2 behind the barrier (in front of the
-  //         last group's MFMAs).  MODE 1: all three pieces behind the barrier.  MODE 2 (shipped): as 1, and waves 8..15
-  //         (the second pair of every SIMD) meet the barrier two groups EARLIER in their own stream -- they run half a
+  //         last group's MFMAs).  MODE 1: all pieces behind the barrier.  MODE 2 (shipped for n_cg > 128): as 1, and waves
+  //         NW/2.. (the second pair of every SIMD) meet the barrier two groups EARLIER in their own stream -- they run half a
   //         stage behind waves 0..7, so the two pairs of a SIMD are never in their operand-read / barrier phase together
   //         (a slot is refilled only behind the barrier after which nobody reads it: three slots still suffice).
   //         c3, same box, two runs each: MODE 0 107.1 / 106.6 ms, MODE 1 106.0 / 106.5, MODE 2 104.9 / 105.5 (the
@@ -798,15 +811,17 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
   // rotated chunks), i.e. 16 address registers; with the slot base added at run time every read cost a vector add --
   // 20 of the 1.7 non-MFMA vector instructions per MFMA of this kernel (rocprofv3: SQ_INSTS_VALU / MFMA = 2.7 against
   // 1.6 in K1), and float64 MFMAs share their SIMD's vector datapath with them.
-  auto stage = [&](int it, const double* buf) {
+  auto stage = [&](int it, const char* buf) {
     const bool issue_now = it + 2 < n_stage;
+    const TS* bufP = reinterpret_cast<const TS*>(buf);
+    const double* bufM = reinterpret_cast<const double*>(buf + P_BYTES);
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      double a[3], bq[2];
+      double a[3], bq[NCT];
 #pragma unroll
-      for (int d = 0; d < 3; ++d) a[d] = buf[offA[kk][d]];
+      for (int d = 0; d < 3; ++d) a[d] = (double)bufP[offA[kk][d]];
 #pragma unroll
-      for (int n = 0; n < 2; ++n) bq[n] = buf[offB[kk] + 256 * n];
+      for (int n = 0; n < NCT; ++n) bq[n] = bufM[offB[kk] + 256 * n];
       if (MODE == 0 && issue_now && kk < 2) issue_piece(it + 2, kk);
       if (kk == bar_kk) {
         // stage it + 1 has landed (this wave's pieces; pieces of stage it + 2 issued above may stay in flight), every
@@ -821,7 +836,7 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
         }
       }
 #pragma unroll
-      for (int n = 0; n < 2; ++n)
+      for (int n = 0; n < NCT; ++n)
 #pragma unroll
         for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], bq[n], acc[n][d]);
     }
@@ -830,27 +845,27 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
     // three stages per pass: the slot of each is a constant
     int it = 0;
     for (; it + 2 < n_stage; it += 3) {
-      stage(it, smem);
-      stage(it + 1, smem + BUF);
-      stage(it + 2, smem + 2 * BUF);
+      stage(it, smem_raw);
+      stage(it + 1, smem_raw + BUF_BYTES);
+      stage(it + 2, smem_raw + 2 * BUF_BYTES);
     }
-    if (it < n_stage) stage(it, smem);
-    if (it + 1 < n_stage) stage(it + 1, smem + BUF);
+    if (it < n_stage) stage(it, smem_raw);
+    if (it + 1 < n_stage) stage(it + 1, smem_raw + BUF_BYTES);
   } else {
     static_assert(NBUF == 2, "ring of two or three slots");
     int it = 0;
     for (; it + 1 < n_stage; it += 2) {
-      stage(it, smem);
-      stage(it + 1, smem + BUF);
+      stage(it, smem_raw);
+      stage(it + 1, smem_raw + BUF_BYTES);
     }
-    if (it < n_stage) stage(it, smem);
+    if (it < n_stage) stage(it, smem_raw);
   }
 
   double ss = 0.0;
   bool saw_nan = false;
 #pragma unroll
-  for (int n = 0; n < 2; ++n) {
-    const int c = c0 + (wc * 2 + n) * 16 + (lane & 15);
+  for (int n = 0; n < NCT; ++n) {
+    const int c = c0 + (wc * NCT + n) * 16 + (lane & 15);
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
       const int64_t t = t0 + 16 * wf + MF::row(lane, r);
@@ -882,10 +897,11 @@ __global__ __launch_bounds__(TF * 16, TF == 64 ? 4 : 2) void apply_dma_kernel(co
   }
 }
 
-template <int MODE, int TF, int NBUF>
-static int apply_dma_launch(const double* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
+template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2>
+static int apply_dma_launch(const TS* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
                             double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, hipStream_t stream) {
-  const int ncb = (int)ceil_div(n_cg, AD_TC);
+  constexpr int TCW = NWS * NCT * 16;
+  const int ncb = (int)ceil_div(n_cg, TCW);
   const int64_t nfb = ceil_div(T, TF);
   const int64_t nblocks = round_up(nfb, 8) * ncb;
   if (nblocks > 0x7fffffffLL) return fail(AGGF_ERR_ARG, "apply grid too large");
@@ -895,16 +911,17 @@ static int apply_dma_launch(const double* P, int64_t T, int32_t N, const double*
       return fail(AGGF_ERR_WORKSPACE, "aggf_linearmap_apply: workspace too small for sumsq");
     partials = reinterpret_cast<double*>(ws);
   }
-  constexpr size_t lds = (size_t)NBUF * (TF * 64 + AD_M_ELEMS) * sizeof(double);  // <64, 3>: 144 KB; <32, 2>: 64 KB
+  // <64, 3, double, 128>: 144 KB; <32, 2, double, 128>: 64 KB; <64, 3, float, 64>: 72 KB
+  constexpr size_t lds = (size_t)NBUF * (TF * 64 * sizeof(TS) + TCW * 16 * sizeof(double));
   static thread_local PerDeviceOnce once;
   bool& done = *once.flag();
   if (!done) {
-    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<MODE, TF, NBUF>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)lds));
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<MODE, TF, NBUF, TS, NWS, NCT>,
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
   }
-  AGGF_LAUNCH((apply_dma_kernel<MODE, TF, NBUF>), dim3((unsigned)nblocks), dim3(TF * 16), lds, stream, P, T, N, Mx,
-                     n_cg, ncb, nfb, out, partials, nan_seen);
+  AGGF_LAUNCH((apply_dma_kernel<MODE, TF, NBUF, TS, NWS, NCT>), dim3((unsigned)nblocks), dim3(TF * NWS * 4), lds, stream, P, T, N,
+              Mx, n_cg, ncb, nfb, out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
     AGGF_LAUNCH(sum_partials_kernel, dim3(1), dim3(256), 0, stream, partials, nfb * ncb, sumsq);
@@ -932,22 +949,48 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
       return apply_small_launch<TIn, TC, 12, 4>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
     return apply_small_launch<TIn, TC, 8, 2>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   }
+  // LDS-DMA form: float64 map and result, frames float64 or float32 (widened out of LDS), whole 16-atom stages
+  constexpr bool dma_types = std::is_same<TC, double>::value;
+  const char* k3_route = getenv("AGGF_APPLY_ROUTE");  // measurement: "reg" = the register-staged kernel everywhere
+  const bool dma_ok = dma_types && nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && N >= 2 * AD_KA &&
+                      (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && !(k3_route && k3_route[0] == 'r');
   if (n_cg > 64) {
-    if constexpr (std::is_same<TIn, double>::value && std::is_same<TC, double>::value) {
-      if (nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && N >= 2 * AD_KA)
-      {
+    if constexpr (dma_types) {
+      if (dma_ok) {
         // More than one 128-site block: the 16-wave form, whose site blocks of a frame block run in lock-step on one XCD
         // and share the P tile through its L2 (FETCH x 2 = 109.5 GB per launch at c3; the two-workgroup form drifts:
         // 145.7 GB).  A single site block has no second reader: the faster two-workgroup form.
-        if (n_cg > AD_TC)
-          return apply_dma_launch<2, 64, 3>((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws,
-                                            ws_bytes, stream);
-        return apply_dma_launch<1, 32, 2>((const double*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, nan_seen, ws,
-                                          ws_bytes, stream);
+        if (n_cg > 128)
+          return apply_dma_launch<2, 64, 3, TIn, 4, 2>((const TIn*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq,
+                                                      nan_seen, ws, ws_bytes, stream);
+        return apply_dma_launch<1, 32, 2, TIn, 4, 2>((const TIn*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq,
+                                                    nan_seen, ws, ws_bytes, stream);
       }
     }
     return apply_launch<TIn, TC, 1024, 128>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws,
                                             ws_bytes, stream);
+  }
+  if constexpr (dma_types) {
+    if (dma_ok && n_cg > 16) {
+      // 17-64 sites (round 5): the same ring with narrower site tiles.  Against the register-staged kernel, same box:
+      // 64 sites on 1024 atoms x 1e5 frames (BASELINE config 2's apply) float32 0.84-0.85 -> 0.63-0.70 ms, float64
+      // 0.80-0.83 -> 0.68 ms; 35 sites on 576 atoms 2.97 -> 2.67 ms (float32, 1e6 frames) / 1.75 -> 1.54 (float64, 5e5);
+      // 20 sites on 320 atoms 2.50 -> 2.09 / 1.54 -> 1.45.  Measured and not kept: one wave column of four site tiles for
+      // 64 sites (0.71-0.78 ms), 32-frame workgroups for the 32- and 48-site tiles (2.30 / 2.78 ms float32), the early
+      // pieces of MODE 0 for them (2.26 / 2.67).
+#define AGGF_DMA(M_, TF_, NB_, NWS_, NCT_)                                                                              \
+  return apply_dma_launch<M_, TF_, NB_, TIn, NWS_, NCT_>((const TIn*)P, T, N, (const double*)Mx, n_cg, (double*)out, sumsq, \
+                                                         nan_seen, ws, ws_bytes, stream)
+      if (n_cg > 48) {
+        // 32 frames x 64 sites, 4 waves, three workgroups per CU: float32 frames with three slots and the first two
+        // pieces beside the MFMA groups, float64 with two slots
+        if constexpr (sizeof(TIn) == 4) AGGF_DMA(0, 32, 3, 2, 2);
+        else AGGF_DMA(1, 32, 2, 2, 2);
+      }
+      if (n_cg > 32) AGGF_DMA(1, 64, 2, 1, 3);  // 64 frames x 48 sites, 4 waves of 16 frames x 48 sites
+      AGGF_DMA(1, 64, 2, 1, 2);                 // 64 frames x 32 sites
+#undef AGGF_DMA
+    }
   }
   // 17-48 sites: a 32- or 48-site tile -- the 64-site tile multiplies its empty 16-site column tiles all the same
   // (20 sites on 320 atoms of float32 frames, float64 map: 6.5 ms for 12 GB, 0.75 of the fp64 MFMA peak in EXECUTED flops)

@@ -3,14 +3,17 @@
 #define AGGF_APPLY_PROF 1
 #include "../aggforce_amd/csrc/aggf_apply.hip"
 using namespace aggf;
-int main() {
-  const int64_t T = 200000;
-  const int N = 4096, n_cg = 256;
+// args: [frames atoms sites [f32]]  (f32: float32 frames, float64 map and result)
+int main(int argc, char** argv) {
+  const int64_t T = argc > 1 ? atoll(argv[1]) : 200000;
+  const int N = argc > 2 ? atoi(argv[2]) : 4096, n_cg = argc > 3 ? atoi(argv[3]) : 256;
+  const bool f32 = argc > 4 && argv[4][0] == 'f' && argv[4][1] == '3';
+  const int pdt = f32 ? AGGF_F32 : AGGF_F64;
   double *P, *M, *out;
   hipMalloc(&P, (size_t)T * N * 3 * 8);
   hipMalloc(&M, (size_t)n_cg * (N / 3 + 1) * 3 * 8);  // the synthetic fill below writes whole (atom, xyz) triples
   hipMalloc(&out, (size_t)T * n_cg * 3 * 8);
-  aggf_synth_normal(P, T, N, AGGF_F64, 1, 0, 0.0, 30.0, 0.0, nullptr);
+  aggf_synth_normal(P, T, N, pdt, 1, 0, 0.0, 30.0, 0.0, nullptr);
   aggf_synth_normal(M, n_cg, N / 3 + 1, AGGF_F64, 2, 0, 0.0, 1.0, 0.0, nullptr);
   size_t need = aggf_linearmap_apply_workspace_bytes(T, N, n_cg) + 256;
   void* ws;
@@ -22,7 +25,7 @@ int main() {
     unsigned long long zero[5] = {0, 0, 0, 0, 0};
     hipMemcpyToSymbol(HIP_SYMBOL(aggf_apply_prof), zero, sizeof zero);
     hipEventRecord(a);
-    int rc = aggf_linearmap_apply(P, T, N, AGGF_F64, M, n_cg, AGGF_F64, AGGF_NAN_PROPAGATE, 0.0, out, nullptr, nullptr, ws, need, nullptr);
+    int rc = aggf_linearmap_apply(P, T, N, pdt, M, n_cg, AGGF_F64, AGGF_NAN_PROPAGATE, 0.0, out, nullptr, nullptr, ws, need, nullptr);
     hipEventRecord(b);
     hipEventSynchronize(b);
     float ms;
