@@ -688,7 +688,7 @@ __device__ __forceinline__ void ad_wait_vmcnt(int n) {
 // With two slots a stage has exactly one stage time to land: spreading its four pieces over the NEXT stage's MFMA groups
 // instead of issuing them right behind the barrier costs 6 % (109.5 ms) -- the kernel is sensitive to landing latency,
 // and a third slot does not fit twice into 160 KB.
-template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2>
+template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2, bool RAGGED = false>
 __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void apply_dma_kernel(
     const TS* __restrict__ P, int64_t T, int32_t N, const double* __restrict__ Mx, int32_t n_cg, int32_t ncb, int64_t nfb,
     double* __restrict__ out, double* __restrict__ sumsq_partials, int32_t* __restrict__ nan_seen) {
@@ -719,7 +719,12 @@ __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void ap
   const int64_t t0 = fb * TF;
   const int c0 = cb * TCW;
   const int64_t rowP = (int64_t)N * 3;
-  const int n_stage = N / AD_KA;
+  // RAGGED (N % 16 != 0; its own instantiation: the extra stage form costs the whole-stage kernels registers -- 7 spilled
+  // in the 16-wave form): the LAST stage is the window of atoms N - 16 .. N - 1 -- it overlaps the stage before it by 16 - N % 16
+  // atoms, so every byte it reads lies inside the rows -- and the lanes of the overlapped atoms feed zeros to the MFMAs
+  // in place of what they read (a select, not a product: an infinity counted once stays an infinity)
+  const int n_stage = (N + AD_KA - 1) / AD_KA;
+  const int tail = RAGGED ? N % AD_KA : 0;
 
   // this wave's DMA pieces: PP pieces of the P tile (RPP rows each), then MP pieces of the M tile (8 rows each)
   const char* gsrc[NPIECE];
@@ -754,10 +759,15 @@ __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void ap
   n_first = __builtin_amdgcn_readfirstlane(n_first);
   n_all = __builtin_amdgcn_readfirstlane(n_all);
   auto issue_piece = [&](int s, int q) {
-    if (ok[q])
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(gsrc[q] + (int64_t)s * (q >= PP ? AD_KA * 8 : AD_KA * 3 * (int)sizeof(TS))),
-          (__attribute__((address_space(3))) void*)(smem_raw + (s % NBUF) * BUF_BYTES + lbase[q]), 16, 0, 0);
+    if (ok[q]) {
+      const char* src = gsrc[q] + (int64_t)s * (q >= PP ? AD_KA * 8 : AD_KA * 3 * (int)sizeof(TS));
+      if constexpr (RAGGED) {  // (wave-uniform)
+        if (s == n_stage - 1) src = gsrc[q] + (int64_t)(N - AD_KA) * (q >= PP ? 8 : 3 * (int)sizeof(TS));
+      }
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(smem_raw + (s % NBUF) * BUF_BYTES + lbase[q]),
+                                       16, 0, 0);
+    }
   };
 
   // MFMA operand offsets inside a stage buffer: elements of TS (P tile), doubles behind P_BYTES (M tile)
@@ -811,7 +821,8 @@ __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void ap
   // rotated chunks), i.e. 16 address registers; with the slot base added at run time every read cost a vector add --
   // 20 of the 1.7 non-MFMA vector instructions per MFMA of this kernel (rocprofv3: SQ_INSTS_VALU / MFMA = 2.7 against
   // 1.6 in K1), and float64 MFMAs share their SIMD's vector datapath with them.
-  auto stage = [&](int it, const char* buf) {
+  auto stage = [&](int it, const char* buf, auto masked_c) {
+    constexpr bool MASKED = decltype(masked_c)::value;  // the ragged last stage: lanes of atoms already counted feed zeros
     const bool issue_now = it + 2 < n_stage;
     const TS* bufP = reinterpret_cast<const TS*>(buf);
     const double* bufM = reinterpret_cast<const double*>(buf + P_BYTES);
@@ -822,6 +833,13 @@ __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void ap
       for (int d = 0; d < 3; ++d) a[d] = (double)bufP[offA[kk][d]];
 #pragma unroll
       for (int n = 0; n < NCT; ++n) bq[n] = bufM[offB[kk] + 256 * n];
+      if constexpr (MASKED) {
+        const bool fresh = 4 * kk + (lane >> 4) >= AD_KA - tail;  // window position of this lane's atom
+#pragma unroll
+        for (int d = 0; d < 3; ++d) a[d] = fresh ? a[d] : 0.0;
+#pragma unroll
+        for (int n = 0; n < NCT; ++n) bq[n] = fresh ? bq[n] : 0.0;
+      }
       if (MODE == 0 && issue_now && kk < 2) issue_piece(it + 2, kk);
       if (kk == bar_kk) {
         // stage it + 1 has landed (this wave's pieces; pieces of stage it + 2 issued above may stay in flight), every
@@ -841,24 +859,44 @@ __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void ap
         for (int d = 0; d < 3; ++d) acc[n][d] = MF::mma(a[d], bq[n], acc[n][d]);
     }
   };
+  using plain = std::false_type;
+  using masked = std::true_type;
+  const int n_plain = RAGGED ? n_stage - 1 : n_stage;  // stages of whole 16-atom blocks
   if constexpr (NBUF == 3) {
     // three stages per pass: the slot of each is a constant
     int it = 0;
-    for (; it + 2 < n_stage; it += 3) {
-      stage(it, smem_raw);
-      stage(it + 1, smem_raw + BUF_BYTES);
-      stage(it + 2, smem_raw + 2 * BUF_BYTES);
+    for (; it + 2 < n_plain; it += 3) {
+      stage(it, smem_raw, plain{});
+      stage(it + 1, smem_raw + BUF_BYTES, plain{});
+      stage(it + 2, smem_raw + 2 * BUF_BYTES, plain{});
     }
-    if (it < n_stage) stage(it, smem_raw);
-    if (it + 1 < n_stage) stage(it + 1, smem_raw + BUF_BYTES);
+    if constexpr (!RAGGED) {
+      if (it < n_stage) stage(it, smem_raw, plain{});
+      if (it + 1 < n_stage) stage(it + 1, smem_raw + BUF_BYTES, plain{});
+    } else {
+      // the rest of the plain stages, then the ragged one in the slot that follows
+      const int left = n_plain - it;  // 0, 1 or 2
+      if (left >= 1) stage(it, smem_raw, plain{});
+      if (left >= 2) stage(it + 1, smem_raw + BUF_BYTES, plain{});
+      if (left == 0) stage(n_plain, smem_raw, masked{});
+      else if (left == 1) stage(n_plain, smem_raw + BUF_BYTES, masked{});
+      else stage(n_plain, smem_raw + 2 * BUF_BYTES, masked{});
+    }
   } else {
     static_assert(NBUF == 2, "ring of two or three slots");
     int it = 0;
-    for (; it + 1 < n_stage; it += 2) {
-      stage(it, smem_raw);
-      stage(it + 1, smem_raw + BUF_BYTES);
+    for (; it + 1 < n_plain; it += 2) {
+      stage(it, smem_raw, plain{});
+      stage(it + 1, smem_raw + BUF_BYTES, plain{});
     }
-    if (it < n_stage) stage(it, smem_raw);
+    if constexpr (!RAGGED) {
+      if (it < n_stage) stage(it, smem_raw, plain{});
+    } else {
+      const int left = n_plain - it;  // 0 or 1
+      if (left >= 1) stage(it, smem_raw, plain{});
+      if (left == 0) stage(n_plain, smem_raw, masked{});
+      else stage(n_plain, smem_raw + BUF_BYTES, masked{});
+    }
   }
 
   double ss = 0.0;
@@ -897,8 +935,8 @@ __global__ __launch_bounds__(TF * NWS * 4, TF * NWS * 4 >= 1024 ? 4 : 2) void ap
   }
 }
 
-template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2>
-static int apply_dma_launch(const TS* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
+template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2, bool RAGGED = false>
+static int apply_dma_launch_r(const TS* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
                             double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, hipStream_t stream) {
   constexpr int TCW = NWS * NCT * 16;
   const int ncb = (int)ceil_div(n_cg, TCW);
@@ -916,11 +954,11 @@ static int apply_dma_launch(const TS* P, int64_t T, int32_t N, const double* Mx,
   static thread_local PerDeviceOnce once;
   bool& done = *once.flag();
   if (!done) {
-    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<MODE, TF, NBUF, TS, NWS, NCT>,
+    AGGF_HIP_OK(hipFuncSetAttribute((const void*)apply_dma_kernel<MODE, TF, NBUF, TS, NWS, NCT, RAGGED>,
                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     done = true;
   }
-  AGGF_LAUNCH((apply_dma_kernel<MODE, TF, NBUF, TS, NWS, NCT>), dim3((unsigned)nblocks), dim3(TF * NWS * 4), lds, stream, P, T, N,
+  AGGF_LAUNCH((apply_dma_kernel<MODE, TF, NBUF, TS, NWS, NCT, RAGGED>), dim3((unsigned)nblocks), dim3(TF * NWS * 4), lds, stream, P, T, N,
               Mx, n_cg, ncb, nfb, out, partials, nan_seen);
   AGGF_LAUNCH_OK();
   if (sumsq) {
@@ -928,6 +966,14 @@ static int apply_dma_launch(const TS* P, int64_t T, int32_t N, const double* Mx,
     AGGF_LAUNCH_OK();
   }
   return AGGF_OK;
+}
+
+template <int MODE, int TF, int NBUF, typename TS = double, int NWS = 4, int NCT = 2>
+static int apply_dma_launch(const TS* P, int64_t T, int32_t N, const double* Mx, int32_t n_cg, double* out,
+                            double* sumsq, int32_t* nan_seen, void* ws, size_t ws_bytes, hipStream_t stream) {
+  if (N % AD_KA != 0)
+    return apply_dma_launch_r<MODE, TF, NBUF, TS, NWS, NCT, true>(P, T, N, Mx, n_cg, out, sumsq, nan_seen, ws, ws_bytes, stream);
+  return apply_dma_launch_r<MODE, TF, NBUF, TS, NWS, NCT, false>(P, T, N, Mx, n_cg, out, sumsq, nan_seen, ws, ws_bytes, stream);
 }
 
 template <typename TIn, typename TC>
@@ -952,7 +998,7 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   // LDS-DMA form: float64 map and result, frames float64 or float32 (widened out of LDS), whole 16-atom stages
   constexpr bool dma_types = std::is_same<TC, double>::value;
   const char* k3_route = getenv("AGGF_APPLY_ROUTE");  // measurement: "reg" = the register-staged kernel everywhere
-  const bool dma_ok = dma_types && nan_mode != AGGF_NAN_REPLACE && N % AD_KA == 0 && N >= 2 * AD_KA &&
+  const bool dma_ok = dma_types && nan_mode != AGGF_NAN_REPLACE && N >= 2 * AD_KA &&
                       (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && !(k3_route && k3_route[0] == 'r');
   if (n_cg > 64) {
     if constexpr (dma_types) {

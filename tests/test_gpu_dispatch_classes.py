@@ -32,9 +32,12 @@ def launched(family):
 
 # ------------------------------------------------------------------ K3: every tile x dtype pair x NaN mode
 # (n_cg, N, T): few sites with 8 / 12 / 20 / 40 frames per stage (by frame size, per input dtype), 32- / 48- / 64-site
-# tiles, the 128-site 16-wave tile (N % 16 != 0 keeps float64 x float64 off the LDS-DMA kernels)
+# tiles, the 128-site 16-wave tile (with a float64 map and 32 atoms or more the plain mode of these goes to the LDS-DMA
+# kernels -- tests/test_gpu_parity.py::test_apply_wide_tile_nan_scan_and_ragged_tiles -- so each tile also gets a shape
+# with fewer than 32 atoms, which keeps it on the register-staged kernel)
 APPLY_SHAPES = [(10, 175, 5003), (4, 20, 100003), (5, 64, 5003), (16, 40, 5001), (16, 97, 5003), (7, 130, 5003), (3, 300, 5003),
-                (20, 77, 333), (40, 200, 257), (60, 130, 300), (130, 150, 200), (200, 1001, 129)]
+                (20, 77, 333), (40, 200, 257), (60, 130, 300), (130, 150, 200), (200, 1001, 129),
+                (20, 24, 333), (40, 28, 257), (60, 30, 300), (130, 31, 200)]
 
 
 @pytest.mark.parametrize("pdt,mdt", [(np.float64, np.float64), (np.float32, np.float64), (np.float32, np.float32),
