@@ -70,13 +70,15 @@ def group_layout(n_sites: int, constraints: Constraints) -> Tuple[np.ndarray, in
         if not 0 <= s < n_sites or not 0 <= lookup[s] < n_sites:
             raise ValueError(f"constraint index {s} outside 0..{n_sites - 1}")
     goa = np.full(n_sites, -1, dtype=np.int32)
-    col = 0
-    for site in range(n_sites):
-        if site not in lookup:
-            goa[site] = col
-            col += 1
-    for site, anchor in lookup.items():
-        goa[site] = goa[anchor]
+    free = np.ones(n_sites, dtype=bool)
+    if lookup:
+        members = np.fromiter(lookup.keys(), dtype=np.int64, count=len(lookup))
+        anchors = np.fromiter(lookup.values(), dtype=np.int64, count=len(lookup))
+        free[members] = False
+    col = int(free.sum())
+    goa[free] = np.arange(col, dtype=np.int32)
+    if lookup:
+        goa[members] = goa[anchors]  # (an anchor is never a non-anchor member: its column is set)
     return goa, col
 
 

@@ -127,6 +127,24 @@ def solve_constrained_maps(G, l2_regularization: float, l2_diag, A_host, what: s
     return X, st
 
 
+def _upload_together(arrays, device):
+    """Device copies of a dict of small host arrays through ONE host-to-device transfer (16-byte aligned pieces of one
+    byte buffer, viewed with their own dtypes)."""
+    import torch
+
+    offs, total = {}, 0
+    for k, a in arrays.items():
+        offs[k] = total
+        total += -(-a.nbytes // 16) * 16
+    buf = np.zeros(max(total, 16), dtype=np.uint8)
+    for k, a in arrays.items():
+        buf[offs[k]:offs[k] + a.nbytes] = np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+    dbuf = torch.from_numpy(buf).to(device)
+    tdt = {np.dtype(np.float64): torch.float64, np.dtype(np.float32): torch.float32, np.dtype(np.int32): torch.int32,
+           np.dtype(np.int64): torch.int64}
+    return {k: dbuf[offs[k]:offs[k] + a.nbytes].view(tdt[a.dtype]).reshape(a.shape) for k, a in arrays.items()}
+
+
 class LinearProblem:
     """Reduced-variable layout of one (coord_map, constraints) pair: Gram, solve and map assembly.
 
@@ -145,12 +163,10 @@ class LinearProblem:
         self.grp_ptr = self.grp_atoms = None
         self._csr = None
         self._A = None
+        host = {"sizes": np.bincount(self.goa, minlength=self.n_red).astype(np.float64), "goa": self.goa}
         if self.n_red != self.n_fg:
             self._csr = groups_csr(self.goa, self.n_red)
-            self.grp_ptr = torch.from_numpy(self._csr[0]).to(device)
-            self.grp_atoms = torch.from_numpy(self._csr[1]).to(device)
-        self.sizes = torch.from_numpy(np.bincount(self.goa, minlength=self.n_red).astype(np.float64)).to(device)
-        self._goa_d = torch.from_numpy(self.goa).to(device)  # for tmap(): uploaded while the device is still idle
+            host["grp_ptr"], host["grp_atoms"] = self._csr
         # a slice coordinate map (the map object caches its row -> atom index): A = M C has unit rows at the reduced
         # variables of the mapped atoms -- the pinned variables of aggf_eq_qp_solve_pinned; A itself is not formed
         self.pins = self._pins_d = None
@@ -158,10 +174,15 @@ class LinearProblem:
         if idx is not None and len(idx) < self.n_red:
             pins = self.goa[idx].astype(np.int32)
             if len(np.unique(pins)) == len(pins):
-                self.pins = pins
-                # uploaded now, before the Gram kernel is queued: the copy of a pageable array blocks the host until
-                # the device is idle, and behind the Gram kernel it would hold back the launches of the solve
-                self._pins_d = torch.from_numpy(pins).to(device)
+                self.pins = host["pins"] = pins
+        # ONE upload for all the index arrays, now, before the Gram kernel is queued: the copy of a pageable array
+        # blocks the host until the device is idle (behind the Gram kernel it would hold back the launches of the
+        # solve), and five separate copies are five round trips of ~30 us with the device idle
+        dev_arrays = _upload_together(host, device)
+        self.sizes = dev_arrays["sizes"]
+        self._goa_d = dev_arrays["goa"]  # for tmap()
+        self.grp_ptr, self.grp_atoms = dev_arrays.get("grp_ptr"), dev_arrays.get("grp_atoms")
+        self._pins_d = dev_arrays.get("pins")
 
     @property
     def A(self) -> np.ndarray:
