@@ -650,6 +650,9 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   constexpr int SM_MAXBLK = C;
   static_assert(KBS * RE % SM_THREADS == 0 && KBS >= 4 && (KBS * W == 8 * TILE || (KBS == 4 && W > 2 * TILE) || (KBS == 8 && W == 2 * TILE)), "entry split");
   typedef float __attribute__((ext_vector_type(4))) v16_t;  // one 16-byte piece, whatever the dtype
+  // ... as it lies in HBM: F needs element alignment only (a frame block that starts at an odd row of a larger array is
+  // 8- or 4-byte aligned) -- still one global_load_dwordx4 per piece, the memory system takes any byte address
+  typedef float __attribute__((ext_vector_type(4), aligned(4))) v16g_t;
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   TC* panel = reinterpret_cast<TC*>(smem_raw);                         // [KBS][RS]
   TIn* raw = reinterpret_cast<TIn*>(smem_raw + KBS * RS * sizeof(TC));  // SM_KB frames as in HBM
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
           const int v = tid + SM_THREADS * i;
           const char* base_i = src + (int64_t)i * (SM_THREADS * 16);
           v16_t x = {0.f, 0.f, 0.f, 0.f};
-          if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16_t*>(base_i + voff));
+          if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16g_t*>(base_i + voff));
           hold[i] = x;
         }
       } else {
@@ -723,7 +726,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
           const int v = tid + SM_THREADS * i;
           const char* base_i = src + (int64_t)i * (SM_THREADS * 16);
           v16_t x = {0.f, 0.f, 0.f, 0.f};
-          if (v < n_vec) x = *reinterpret_cast<const v16_t*>(base_i + voff);
+          if (v < n_vec) x = *reinterpret_cast<const v16g_t*>(base_i + voff);
           hold[i] = x;
         }
       }
@@ -735,7 +738,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
         if (v < n_vec) {
           const int64_t off = (int64_t)v * 16;
           if (off + 16 <= valid) {
-            x = *reinterpret_cast<const v16_t*>(src + off);
+            x = *reinterpret_cast<const v16g_t*>(src + off);
           } else if (off < valid) {  // the ragged end of the trajectory: element by element
             TIn tmp[16 / sizeof(TIn)];
 #pragma unroll
@@ -1035,8 +1038,8 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
   p->n_pad = (int32_t)round_up(n_red, TILE);
   p->nt1 = p->n_pad / TILE;
   p->n_tiles = p->nt1 * (p->nt1 + 1) / 2;
-  // in place: no groups, no conversion, 16-byte aligned rows of 16-byte multiples; N % 128 != 0 takes the EDGE form of
-  // the tile kernel (aggf_gram_pair's two-array form needs whole panels)
+  // in place: no groups (`aligned`: the two-array form of aggf_gram_pair asks for 16-byte aligned arrays of whole
+  // panels; aggf_gram's kernels read F at any element-aligned address); N % 128 != 0 takes the EDGE form of the tile kernel
   // (float32 frames with float64 products too: the tile kernel widens the operands as it reads them from LDS)
   p->edge = N % TILE != 0;
   const bool widen = in_dtype == AGGF_F32 && compute_dtype == AGGF_F64;
@@ -1495,7 +1498,10 @@ static int gram_impl(const void* F, int64_t T, int32_t N, int in_dtype, int comp
   // would ADD) it, so the result of accumulate + first_col would depend on pointer alignment: refused
   if (first_col > 0 && accumulate) return fail(AGGF_ERR_ARG, "aggf_gram_from_column: accumulate != 0 needs first_col == 0");
   if (((uintptr_t)ws & 255) != 0) return fail(AGGF_ERR_ARG, "aggf_gram: workspace not 256-byte aligned");
-  const bool aligned = ((uintptr_t)F & 15) == 0;
+  // (the kernels take F at any element-aligned address: the launch plan does not depend on where a frame block starts,
+  // so the workspace query, which sees no pointer, always describes the plan of the call)
+  if (((uintptr_t)F & (dtype_size(in_dtype) - 1)) != 0) return fail(AGGF_ERR_ARG, "aggf_gram: F is not aligned to its element size");
+  const bool aligned = true;
   GramPlan p;
   int rc = make_plan(T, N, n_red, in_dtype, compute_dtype, has_groups, aligned, ws_bytes, false, &p, first_col);
   if (rc) return rc;

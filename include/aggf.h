@@ -70,10 +70,12 @@ int aggf_device_info(int32_t* cu_count, size_t* free_bytes, size_t* total_bytes)
  * rest of each frame row is ignored -- row padding).  Products are formed in `compute_dtype`
  * (AGGF_F64 reproduces the reference, whose con_mat is float64 even for float32
  * forces; AGGF_F32 uses fp32 MFMA with partial sums combined in fp64).  float32 F with
- * AGGF_F64 products and no constraint groups is read in place (F 16-byte aligned): the
- * operands are widened inside the kernel, no converted copy is made and the workspace
- * holds partial tiles only.  Rows need not be multiples of 16 bytes (odd N): nothing is
- * read beyond F + T*3*N elements.
+ * AGGF_F64 products and no constraint groups is read in place: the operands are widened
+ * inside the kernel, no converted copy is made and the workspace holds partial tiles only.
+ * F needs the alignment of its element type only (a frame block may start at any row of
+ * a larger array) and rows need not be multiples of 16 bytes (odd N); nothing is read
+ * beyond F + T*3*N elements.  The launch plan -- and with it the workspace size -- depends
+ * on (T, N, n_red, dtypes, has_groups) alone.
  * G: (n_red, n_red) float64, full symmetric matrix; accumulate != 0 adds to it
  * (frame chunks, cross-validation folds).  Partial sums are combined in a fixed
  * order: two runs are bit-identical.
@@ -92,7 +94,7 @@ int aggf_gram(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dty
  * formed once and pasted.  No constraint groups here (F is a regression matrix).  Guarantee:
  * with accumulate == 0 every entry outside the leading block is written; the leading block is
  * either left untouched (in-place tile kernel: N % 128 == 0, in_dtype == compute_dtype or
- * float32 frames with float64 products, F 16-byte aligned) or overwritten with its own correct values (any other layout computes the
+ * float32 frames with float64 products) or overwritten with its own correct values (any other layout computes the
  * whole matrix), so the caller may paste its copy afterwards either way.  accumulate != 0 with
  * first_col > 0 is refused (AGGF_ERR_ARG): the two cases would differ there. */
 int aggf_gram_from_column(const void* F, int64_t T, int32_t N, int in_dtype, int compute_dtype,

@@ -1,0 +1,59 @@
+"""GPU box: randomized sweep of aggf_gram on systems the tile kernel reads in place -- no constraint groups, more than
+512 columns, every atom count (whole panels / EDGE / rows that are not whole 16-byte pieces), the three dtype pairs
+(float32 frames with float64 products: widened out of LDS), frame blocks that start at an odd row of a larger array
+(an unaligned base: the pack route), accumulation -- against NumPy's float64 products of the same stored values.
+    python tools/stress_gram_tile.py [cases] [seed]"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+from aggforce_amd import _kernels as K  # noqa: E402
+from aggforce_amd import _lib  # noqa: E402
+
+
+def main():
+    n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
+    rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 0)
+    worst = {"f64": 0.0, "f32f64": 0.0, "f32": 0.0}
+    routes = {}
+    for case in range(n_cases):
+        N = int(rng.integers(257, 1500))
+        T = int(rng.integers(2, 3000))
+        mode = str(rng.choice(["f64", "f32f64", "f32"]))
+        sdt = torch.float64 if mode == "f64" else torch.float32
+        cdt = torch.float32 if mode == "f32" else torch.float64
+        skip = int(rng.integers(0, 2))  # 1: the block starts at row 1 of the array
+        f_all = K.synth_normal(T + skip, N, sdt, int(rng.integers(1, 1 << 30)), sigma=10.0)
+        f = f_all[skip:]
+        _lib.load().aggf_coverage_reset()
+        if rng.random() < 0.3 and T > 4:
+            cut = int(rng.integers(1, T))
+            G = K.gram(f[:cut], None, None, N, cdt)
+            K.gram(f[cut:], None, None, N, cdt, out=G, accumulate=True)
+        else:
+            G = K.gram(f, None, None, N, cdt)
+        names = sorted({n.split("(")[0].replace("void aggf::", "").split("<")[0] for n, c in _lib.coverage(names=True).values()
+                        if c > 0 and ("gram_" in n or "pack_" in n)})
+        routes[tuple(names)] = routes.get(tuple(names), 0) + 1
+        x = f.double().cpu().numpy()
+        ref = np.zeros((N, N))
+        for d in range(3):
+            xd = np.ascontiguousarray(x[:, :, d])
+            ref += xd.T @ xd
+        g = G.cpu().numpy()
+        err = float(np.abs(g - ref).max() / np.abs(ref).max())
+        tol = 3e-5 if mode == "f32" else 1e-13
+        if not (err < tol) or not np.array_equal(g, g.T):
+            print(f"FAIL case {case}: T={T} N={N} {mode} skip={skip} err={err:.3e} kernels={names}")
+            sys.exit(1)
+        worst[mode] = max(worst[mode], err)
+    print(f"{n_cases} Gram cases ok; worst relative errors {worst}")
+    for k, v in sorted(routes.items(), key=lambda kv: -kv[1]):
+        print(f"  {v:4d} x {', '.join(k)}")
+
+
+if __name__ == "__main__":
+    main()
