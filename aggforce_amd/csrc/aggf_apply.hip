@@ -388,6 +388,7 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
   using MF = Mfma<TC>;
   using acc_t = typename MF::acc_t;
   typedef float __attribute__((ext_vector_type(4))) v16_t;
+  typedef float __attribute__((ext_vector_type(4), aligned(4))) v16g_t;  // a piece in HBM: P is element-aligned only
   extern __shared__ __attribute__((aligned(16))) char smem_raw[];
   TIn* raw = reinterpret_cast<TIn*>(smem_raw);                       // AS_KB frames as in HBM (+ 64 zero bytes)
   TC* ms = reinterpret_cast<TC*>(smem_raw + raw_bytes + 64);         // [16][n_pad + 2]: the map, zero padded
@@ -423,7 +424,7 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
         v16_t x = {0.f, 0.f, 0.f, 0.f};
         // non-temporal: every byte of the trajectory is read once (tools/ldsdma_fill.hip: 6.8 against 6.1 TB/s for
         // this load shape on a stream that is read once)
-        if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16_t*>(src + (int64_t)v * 16));
+        if (v < n_vec) x = __builtin_nontemporal_load(reinterpret_cast<const v16g_t*>(src + (int64_t)v * 16));
         hold[i] = x;
       }
     } else {
@@ -434,7 +435,7 @@ __global__ __launch_bounds__(AS_THREADS, 4) void apply_small_kernel(
         if (v < n_vec) {
           const int64_t off = (int64_t)v * 16;
           if (off + 16 <= valid) {
-            x = *reinterpret_cast<const v16_t*>(src + off);
+            x = *reinterpret_cast<const v16g_t*>(src + off);
           } else if (off < valid) {  // the ragged end of the trajectory: element by element
             TIn tmp[16 / sizeof(TIn)];
 #pragma unroll
@@ -984,9 +985,10 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   // (profiles/r04_pruned_variants.patch): 8 waves on 64 x 128 (104.5 against 102.4 ms at c3), 32 x 128 with two
   // workgroups per CU (103 ms), 64 x 256 at 4 waves per SIMD (spills: 282 ms), 32 x 256 at 2 waves per SIMD (P read
   // once, 232 registers: 109.8 against 108.4 ms).
-  // few sites: the streaming kernel (frames of a stage must fit AS_NV 16-byte loads per thread; P 16-byte aligned)
+  // few sites: the streaming kernel (frames of a stage must fit AS_NV 16-byte loads per thread; P at any
+  // element-aligned address)
   const int small_kb = apply_small_frames<TIn>(N);
-  if (n_cg <= 16 && small_kb > 0 && (((uintptr_t)P & 15) == 0) && T >= 64) {
+  if (n_cg <= 16 && small_kb > 0 && T >= 64) {
     if (small_kb == 40)
       return apply_small_launch<TIn, TC, 40, 8>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
     if (small_kb == 20)
@@ -998,8 +1000,8 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
   // LDS-DMA form: float64 map and result, frames float64 or float32 (widened out of LDS), whole 16-atom stages
   constexpr bool dma_types = std::is_same<TC, double>::value;
   const char* k3_route = getenv("AGGF_APPLY_ROUTE");  // measurement: "reg" = the register-staged kernel everywhere
-  const bool dma_ok = dma_types && nan_mode != AGGF_NAN_REPLACE && N >= 2 * AD_KA &&
-                      (((uintptr_t)P | (uintptr_t)Mx) & 15) == 0 && !(k3_route && k3_route[0] == 'r');
+  // (P and the map at any element-aligned address: the LDS-DMA takes every byte address)
+  const bool dma_ok = dma_types && nan_mode != AGGF_NAN_REPLACE && N >= 2 * AD_KA && !(k3_route && k3_route[0] == 'r');
   if (n_cg > 64) {
     if constexpr (dma_types) {
       if (dma_ok) {
