@@ -31,9 +31,9 @@ else
   done
   timeout -k 10 300 python tools/next_rows_bench.py > gpurun_out/r05_next_rows.jsonl 2> gpurun_out/r05_next_rows.err; tail -2 gpurun_out/r05_next_rows.jsonl
   timeout -k 10 300 python tools/stream_kernels_bench.py > gpurun_out/r05_stream_kernels.jsonl 2> gpurun_out/r05_stream_kernels.err; tail -2 gpurun_out/r05_stream_kernels.jsonl
-  timeout -k 10 600 python tools/size_sweep.py 130 144 160 192 224 250 260 300 320 340 360 400 448 470 500 640 700 768 1000 1024 2048 > gpurun_out/r05_size_sweep.jsonl 2> gpurun_out/r05_size_sweep.err
-  timeout -k 10 300 python tools/size_sweep.py f32 64 144 260 400 500 640 1000 1024 >> gpurun_out/r05_size_sweep.jsonl 2>> gpurun_out/r05_size_sweep.err
-  timeout -k 10 300 python tools/size_sweep.py f32f64 144 260 400 500 640 1024 >> gpurun_out/r05_size_sweep.jsonl 2>> gpurun_out/r05_size_sweep.err
+  timeout -k 10 600 python tools/size_sweep.py 130 144 160 192 224 250 260 300 320 340 360 400 448 470 500 501 640 700 768 1000 1001 1024 2047 2048 4095 > gpurun_out/r05_size_sweep.jsonl 2> gpurun_out/r05_size_sweep.err
+  timeout -k 10 300 python tools/size_sweep.py f32 64 144 260 400 500 501 640 1000 1001 1024 2048 >> gpurun_out/r05_size_sweep.jsonl 2>> gpurun_out/r05_size_sweep.err
+  timeout -k 10 300 python tools/size_sweep.py f32f64 144 260 320 384 400 470 500 501 640 1001 1024 2048 4096 >> gpurun_out/r05_size_sweep.jsonl 2>> gpurun_out/r05_size_sweep.err
   : > gpurun_out/r05_midsize.jsonl
   for sz in "304 20 2000000" "582 35 1000000" "860 56 600000"; do
     timeout -k 10 200 python tools/midsize_bench.py $sz >> gpurun_out/r05_midsize.jsonl 2>> gpurun_out/r05_midsize.err
