@@ -1102,7 +1102,12 @@ static int make_plan(int64_t T, int32_t N, int32_t n_red, int in_dtype, int comp
     p->chunk_frames = T;
     p->pack_bytes = 0;
     const int nb16 = (n_red + 15) / 16, n_blocks = nb16 * (nb16 + 1) / 2;
-    if (p->nt1 > 2) p->parts = (int)ceil_div((int64_t)n_blocks, 144);
+    // A block's accumulators are 8 registers in float64 and 4 in float32: with float32 products a workgroup takes up
+    // to 192 blocks (12 per wave) -- 257-304 columns in ONE workgroup per frame range, up to 512 in three (a workgroup
+    // stages the whole panel whatever its share of the blocks).  12 GB of float32 frames, 144 / 192 / 224 / 288 blocks:
+    // 267 columns (400 atoms in bond pairs) 10.8 / 7.6 / 7.8 / 7.6 ms, 388 (villin's size) 13.9 / 10.8 / 10.8 / 10.8,
+    // 512 columns 15.1 / 12.5 / 12.4 / 47.6 -- beyond 13 blocks per wave the accumulators spill.
+    if (p->nt1 > 2) p->parts = (int)ceil_div((int64_t)n_blocks, compute_dtype == AGGF_F32 ? 192 : 144);
     // one resident generation of workgroups (2 per CU; 1 with the 256- and 512-column panels), each looping over
     // strided stages
     int64_t nwg = (int64_t)(p->nt1 >= 2 || p->wide256 ? 1 : 2) * device_cu_count() / p->parts;
@@ -1332,11 +1337,28 @@ static int gram_typed(const void* Fv, int64_t T, int32_t N, const int32_t* grp_p
     else if (width == 2 * TILE && per_wave == 7) AGGF_SMALL_WIDE(2 * TILE, 7);   // 105
     else if (width == 2 * TILE && per_wave == 8) AGGF_SMALL_WIDE(2 * TILE, 8);   // 120
     else if (width == 2 * TILE) AGGF_SMALL_WIDE(2 * TILE, 9);                    // 136
-    else if (per_wave <= 5) AGGF_SMALL_WIDE(4 * TILE, 5);            // 512-column panel: 77 - 80 blocks per workgroup
-    else if (per_wave == 6) AGGF_SMALL_WIDE(4 * TILE, 6);
+    else if (per_wave <= 6) {
+      // 512-column panel: 77 - 96 blocks per workgroup (float64 products: with float32 a workgroup has at least 97)
+      if constexpr (std::is_same<TC, float>::value) {
+        AGGF_SMALL_WIDE(4 * TILE, 7);
+      } else {
+        if (per_wave <= 5) AGGF_SMALL_WIDE(4 * TILE, 5);
+        else AGGF_SMALL_WIDE(4 * TILE, 6);
+      }
+    }
     else if (per_wave == 7) AGGF_SMALL_WIDE(4 * TILE, 7);
     else if (per_wave == 8) AGGF_SMALL_WIDE(4 * TILE, 8);
-    else AGGF_SMALL_WIDE(4 * TILE, 9);                               // <= 144
+    else if (per_wave == 9) AGGF_SMALL_WIDE(4 * TILE, 9);            // <= 144
+    else {
+      // float32 products only (make_plan): up to 12 blocks per wave, 192 per workgroup
+      if constexpr (std::is_same<TC, float>::value) {
+        if (per_wave == 10) AGGF_SMALL_WIDE(4 * TILE, 10);
+        else if (per_wave == 11) AGGF_SMALL_WIDE(4 * TILE, 11);
+        else AGGF_SMALL_WIDE(4 * TILE, 12);
+      } else {
+        return fail(AGGF_ERR_ARG, "aggf_gram: streaming kernel: more than 144 blocks per workgroup with float64 products");
+      }
+    }
 #undef AGGF_SMALL_WIDE
 #undef AGGF_SMALL_WIDE8
 #undef AGGF_SMALL_NV
