@@ -641,7 +641,8 @@ static int apply_launch(const void* P, int64_t T, int32_t N, const void* Mx, int
 }
 
 // ---------------------------------------------------------------------------
-// K3 for float64 x float64 with many sites (n_cg > 64, N % 16 == 0): the 64-frame x 128-site tile of apply_kernel with
+// K3 with a float64 map and result for more than 16 sites (round 4: float64 frames, n_cg > 64, N % 16 == 0; round 5: any
+// atom count from 32, float32 frames, 17-64 sites -- see the template parameters below): the tiles of apply_kernel with
 // the operand tiles travelling HBM/L2 -> LDS by LDS-DMA (global_load_lds_dwordx4) through a ring of three stages, as
 // in K1 -- no VGPR round trip, no ds_write, no conversion or NaN-scan VALU work beside the MFMAs (the register-staged
 // kernel spends 7.6 % of its time refilling LDS and holds the clock at ~2.2 GHz; K1 runs at 2.38).
@@ -997,7 +998,8 @@ static int apply_typed(const void* P, int64_t T, int32_t N, const void* Mx, int3
       return apply_small_launch<TIn, TC, 12, 4>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
     return apply_small_launch<TIn, TC, 8, 2>(P, T, N, Mx, n_cg, nan_mode, nan_fill, out, sumsq, nan_seen, ws, ws_bytes, stream);
   }
-  // LDS-DMA form: float64 map and result, frames float64 or float32 (widened out of LDS), whole 16-atom stages
+  // LDS-DMA form: float64 map and result, frames float64 or float32 (widened out of LDS), at least two 16-atom stages
+  // (an atom count that is not a multiple of 16: the RAGGED instantiations)
   constexpr bool dma_types = std::is_same<TC, double>::value;
   const char* k3_route = getenv("AGGF_APPLY_ROUTE");  // measurement: "reg" = the register-staged kernel everywhere
   // (P and the map at any element-aligned address: the LDS-DMA takes every byte address)

@@ -8,18 +8,31 @@
 // usage: small_probe            CLN025-like (175 atoms, 97 reduced columns)
 //        small_probe <atoms>    unconstrained system of that many atoms, 16.8 GB of frames
 int main(int argc, char** argv) {
-  const bool plain = argc > 1;
-  const int32_t N = plain ? atoi(argv[1]) : 175, n_red = plain ? N : 97;
-  const int64_t T = plain ? (int64_t)(16.8e9 / (24.0 * N)) : 4000000;
+  //        small_probe <atoms> pairs   bond pairs {3i, 3i+1} on that many atoms (n_red = N - N / 3)
+  const bool pairs = argc > 2 && argv[2][0] == 'p';
+  const bool plain = argc > 1 && !pairs;
+  const int32_t N = argc > 1 ? atoi(argv[1]) : 175, n_red = plain ? N : (pairs ? N - N / 3 : 97);
+  const int64_t T = argc > 1 ? (int64_t)(16.8e9 / (24.0 * N)) : 4000000;
   // CLN025-like groups: 59 groups (38 anchors alone ... here: first 38 atoms alone, then groups of 2-3)
   std::vector<int32_t> ptr(n_red + 1), atoms(N);
   int a = 0;
-  for (int g = 0; g < n_red; ++g) {
-    ptr[g] = a;
-    const int size = g < 38 ? 1 : (a + 3 * (n_red - g) <= N ? 3 : 2);
-    for (int j = 0; j < size && a < N; ++j) atoms[a++] = a;
+  if (pairs) {
+    int g = 0;
+    for (int i = 0; i < N; ++g) {
+      ptr[g] = a;
+      const bool two = i % 3 == 0 && i / 3 < N / 3 && i + 1 < N;
+      atoms[a++] = i++;
+      if (two) atoms[a++] = i++;
+    }
+    if (g != n_red) { printf("pair layout: %d groups for n_red %d\n", g, n_red); return 1; }
+  } else {
+    for (int g = 0; g < n_red; ++g) {
+      ptr[g] = a;
+      const int size = g < 38 ? 1 : (a + 3 * (n_red - g) <= N ? 3 : 2);
+      for (int j = 0; j < size && a < N; ++j) atoms[a++] = a;
+    }
+    while (a < N) { atoms[a] = a; ++a; }
   }
-  while (a < N) { atoms[a] = a; ++a; }
   ptr[n_red] = N;
   double* F;
   hipMalloc(&F, (size_t)T * N * 3 * 8);
