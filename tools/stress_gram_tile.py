@@ -1,5 +1,6 @@
 """GPU box: randomized sweep of aggf_gram on systems the tile kernel reads in place -- no constraint groups, more than
-512 columns, every atom count (whole panels / EDGE / rows that are not whole 16-byte pieces), the three dtype pairs
+512 columns or constraint groups (random disjoint groups of 2-4 atoms: streaming kernel / pack pass), every atom count
+(whole panels / EDGE / rows that are not whole 16-byte pieces), the three dtype pairs
 (float32 frames with float64 products: widened out of LDS), frame blocks that start at an odd row of a larger array
 (an unaligned base: the pack route), accumulation -- against NumPy's float64 products of the same stored values.
     python tools/stress_gram_tile.py [cases] [seed]"""
@@ -12,6 +13,7 @@ import torch  # noqa: E402
 
 from aggforce_amd import _kernels as K  # noqa: E402
 from aggforce_amd import _lib  # noqa: E402
+from aggforce_amd.constraints import group_layout, groups_csr  # noqa: E402
 
 
 def main():
@@ -28,18 +30,36 @@ def main():
         skip = int(rng.integers(0, 2))  # 1: the block starts at row 1 of the array
         f_all = K.synth_normal(T + skip, N, sdt, int(rng.integers(1, 1 << 30)), sigma=10.0)
         f = f_all[skip:]
+        # a third of the cases with constraint groups: random disjoint groups of 2-4 atoms (the pack pass above 400-512
+        # reduced columns, the streaming kernel's group sums below)
+        gp = ga = None
+        n_red, goa = N, None
+        if rng.random() < 0.33:
+            perm = rng.permutation(N)
+            cons, i = set(), 0
+            while i + 4 <= N and len(cons) < N // 5:
+                size = int(rng.integers(2, 5))
+                cons.add(frozenset(int(a) for a in perm[i:i + size]))
+                i += size
+            goa, n_red = group_layout(N, cons)
+            p_h, a_h = groups_csr(goa, n_red)
+            gp, ga = torch.from_numpy(p_h).cuda(), torch.from_numpy(a_h).cuda()
         _lib.load().aggf_coverage_reset()
         if rng.random() < 0.3 and T > 4:
             cut = int(rng.integers(1, T))
-            G = K.gram(f[:cut], None, None, N, cdt)
-            K.gram(f[cut:], None, None, N, cdt, out=G, accumulate=True)
+            G = K.gram(f[:cut], gp, ga, n_red, cdt)
+            K.gram(f[cut:], gp, ga, n_red, cdt, out=G, accumulate=True)
         else:
-            G = K.gram(f, None, None, N, cdt)
+            G = K.gram(f, gp, ga, n_red, cdt)
         names = sorted({n.split("(")[0].replace("void aggf::", "").split("<")[0] for n, c in _lib.coverage(names=True).values()
                         if c > 0 and ("gram_" in n or "pack_" in n)})
         routes[tuple(names)] = routes.get(tuple(names), 0) + 1
         x = f.double().cpu().numpy()
-        ref = np.zeros((N, N))
+        if goa is not None:  # column sums over the groups, as `@ con_mat` (qplinear.py:70)
+            xs = np.zeros((x.shape[0], n_red, 3))
+            np.add.at(xs, (slice(None), goa), x)
+            x = xs
+        ref = np.zeros((n_red, n_red))
         for d in range(3):
             xd = np.ascontiguousarray(x[:, :, d])
             ref += xd.T @ xd
@@ -47,7 +67,7 @@ def main():
         err = float(np.abs(g - ref).max() / np.abs(ref).max())
         tol = 3e-5 if mode == "f32" else 1e-13
         if not (err < tol) or not np.array_equal(g, g.T):
-            print(f"FAIL case {case}: T={T} N={N} {mode} skip={skip} err={err:.3e} kernels={names}")
+            print(f"FAIL case {case}: T={T} N={N} n_red={n_red} {mode} skip={skip} err={err:.3e} kernels={names}")
             sys.exit(1)
         worst[mode] = max(worst[mode], err)
     print(f"{n_cases} Gram cases ok; worst relative errors {worst}")
