@@ -1,8 +1,9 @@
-"""GPU box: randomized sweep of aggf_gram on systems the tile kernel reads in place -- no constraint groups, more than
-512 columns or constraint groups (random disjoint groups of 2-4 atoms: streaming kernel / pack pass), every atom count
-(whole panels / EDGE / rows that are not whole 16-byte pieces), the three dtype pairs
-(float32 frames with float64 products: widened out of LDS), frame blocks that start at an odd row of a larger array
-(an unaligned base: the pack route), accumulation -- against NumPy's float64 products of the same stored values.
+"""GPU box: randomized sweep of aggf_gram over its routes above 256 columns: every atom count (whole panels / EDGE / rows
+that are not whole 16-byte pieces: read in place by the tile kernel), the three dtype pairs (float32 frames with float64
+products are widened out of LDS), random disjoint constraint groups of 2-4 atoms in a third of the cases (the streaming
+kernel's group sums, the pack pass in front of the tile kernel), frame blocks that start at an odd row of a larger
+array (an address off the 16-byte grid) and accumulation over two blocks -- against NumPy's float64 products of the
+same stored values.
     python tools/stress_gram_tile.py [cases] [seed]"""
 import os
 import sys
