@@ -682,7 +682,11 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
   if (tid < 16 / (int)sizeof(TIn)) raw[zero_idx + tid] = (TIn)0;
   __syncthreads();
   bool big_groups = false;  // uniform: some group has more than SM_FAST_MEMBERS members
-  for (int g = 0; g < n_red; ++g) big_groups |= ptr_s[g + 1] - ptr_s[g] > SM_FAST_MEMBERS;
+  bool pair_groups = true;  // uniform: no group has more than two (bond pairs: the common constraint pattern)
+  for (int g = 0; g < n_red; ++g) {
+    big_groups |= ptr_s[g + 1] - ptr_s[g] > SM_FAST_MEMBERS;
+    pair_groups &= ptr_s[g + 1] - ptr_s[g] <= 2;
+  }
   for (int c = tid; c < RE; c += SM_THREADS) {
     const int g = c / 3, d = c - 3 * g;
 #pragma unroll
@@ -771,6 +775,31 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
         const int e = tid + SM_THREADS * i;
         const int r = e / RE, c = e - r * RE;
         sum[i] = (TC)raw[c < 3 * n_red ? r * (int)row_in + c : zero_idx];
+      }
+#pragma unroll
+      for (int i = 0; i < SM_ENT; ++i) {
+        const int e = tid + SM_THREADS * i;
+        const int r = e / RE, c = e - r * RE;
+        panel[r * RS + c] = sum[i];
+      }
+      return;
+    }
+    if (pair_groups) {
+      // at most two members everywhere: the same straight-line sequence with half the table and half the frame reads
+      // (one 4-byte table entry and two values per panel entry instead of 8 bytes and four)
+      unsigned mem2[SM_ENT];
+#pragma unroll
+      for (int i = 0; i < SM_ENT; ++i) {
+        const int e = tid + SM_THREADS * i;
+        mem2[i] = *reinterpret_cast<const unsigned*>(memb_s + (e % RE) * 4);
+      }
+#pragma unroll
+      for (int i = 0; i < SM_ENT; ++i) {
+        const int e = tid + SM_THREADS * i;
+        const int base = (e / RE) * (int)row_in;
+        const int o0 = mem2[i] & 0xFFFF, o1 = mem2[i] >> 16;
+        const TC v0 = (TC)raw[o0 == 0xFFFF ? zero_idx : base + o0], v1 = (TC)raw[o1 == 0xFFFF ? zero_idx : base + o1];
+        sum[i] = v0 + v1;
       }
 #pragma unroll
       for (int i = 0; i < SM_ENT; ++i) {
