@@ -1,6 +1,6 @@
 """GPU box: randomized sweep of aggf_gram over its routes above 256 columns: every atom count (whole panels / EDGE / rows
 that are not whole 16-byte pieces: read in place by the tile kernel), the three dtype pairs (float32 frames with float64
-products are widened out of LDS), random disjoint constraint groups of 2-4 atoms in a third of the cases (the streaming
+products are widened out of LDS), random disjoint constraint groups of 2-4 atoms (or pairs only) in a third of the cases (the streaming
 kernel's group sums, the pack pass in front of the tile kernel), frame blocks that start at an odd row of a larger
 array (an address off the 16-byte grid) and accumulation over two blocks -- against NumPy's float64 products of the
 same stored values.
@@ -38,8 +38,9 @@ def main():
         if rng.random() < 0.33:
             perm = rng.permutation(N)
             cons, i = set(), 0
+            only_pairs = rng.random() < 0.5  # (no group of more than two atoms: the streaming kernel's two-member sums)
             while i + 4 <= N and len(cons) < N // 5:
-                size = int(rng.integers(2, 5))
+                size = 2 if only_pairs else int(rng.integers(2, 5))
                 cons.add(frozenset(int(a) for a in perm[i:i + size]))
                 i += size
             goa, n_red = group_layout(N, cons)
