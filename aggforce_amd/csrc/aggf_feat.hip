@@ -487,15 +487,15 @@ extern "C" int aggf_gb_channels(const void* Pg, const void* cg, int g_dtype, int
     if (g_dtype == AGGF_F32) {                                                                                 \
       GbParams<float> gp{(const float*)centers, n_basis, (float)width, (float)clip};                           \
       typedef float TG;                                                                                        \
-      if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32) { typedef float TF; typedef float TO; LAUNCH; }        \
-      else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64) { typedef float TF; typedef double TO; LAUNCH; }  \
-      else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64) { typedef double TF; typedef double TO; LAUNCH; } \
+      if (f_dtype == AGGF_F32 && out_dtype == AGGF_F32) { typedef float TF; typedef float TO __attribute__((unused)); LAUNCH; }        \
+      else if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64) { typedef float TF; typedef double TO __attribute__((unused)); LAUNCH; }  \
+      else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64) { typedef double TF; typedef double TO __attribute__((unused)); LAUNCH; } \
       else return fail(AGGF_ERR_ARG, WHO ": bad dtype (out must be the product dtype or float64)");            \
     } else if (g_dtype == AGGF_F64) {                                                                          \
       GbParams<double> gp{(const double*)centers, n_basis, width, clip};                                       \
       typedef double TG;                                                                                       \
-      if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64) { typedef float TF; typedef double TO; LAUNCH; }       \
-      else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64) { typedef double TF; typedef double TO; LAUNCH; } \
+      if (f_dtype == AGGF_F32 && out_dtype == AGGF_F64) { typedef float TF; typedef double TO __attribute__((unused)); LAUNCH; }       \
+      else if (f_dtype == AGGF_F64 && out_dtype == AGGF_F64) { typedef double TF; typedef double TO __attribute__((unused)); LAUNCH; } \
       else return fail(AGGF_ERR_ARG, WHO ": bad dtype (float64 features give float64 products)");              \
     } else {                                                                                                   \
       return fail(AGGF_ERR_ARG, WHO ": bad feature dtype");                                                    \
