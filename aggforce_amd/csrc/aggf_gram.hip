@@ -919,9 +919,7 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 3 : 4) void gram_small_kernel(
 #pragma unroll
         for (int i = 0; i < NPROD; ++i) {
           if (i + 1 < NPROD) {
-            // EXPERIMENT: consecutive blocks of one block row share the A operand
-            if ((i + 1) % C != 0 && b_i[(i + 1) % C] == b_i[i % C]) oa[(i + 1) & 1] = oa[i & 1];
-            else oa[(i + 1) & 1] = panel[addr_a(i + 1)];
+            oa[(i + 1) & 1] = panel[addr_a(i + 1)];
             ob[(i + 1) & 1] = panel[addr_b(i + 1)];
           }
           __builtin_amdgcn_sched_barrier(0);  // (the reads stay IN FRONT of the MFMA: otherwise they reuse its operand registers)
